@@ -1,0 +1,644 @@
+"""CPU oracle for the FITC nLML + hyper-gradient path of mmottl/gpr.
+
+TEST INFRASTRUCTURE ONLY.  Only tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg may import this module; the product path (gpr_amd/) never does.
+
+This is a numpy / scipy-LAPACK restatement of the reference's *own* operation
+sequence (direct-difference covariance loops -> dpotrf -> dtrsm -> stacked
+dgeqrf/dorgqr -> dpotri x2 -> dtrsm x2 -> dsyr/dsyrk x2 -> per-hyper traces).
+Every function cites the reference file:line it follows (paths relative to the
+reference root).  Matrices are Fortran-ordered like the reference's Bigarrays:
+inputs d x n (one point per column), inducing d x m, knm n x m.
+
+PARITY UNPINNED BY REFERENCE FIXTURES: the reference ships no golden vectors
+(its test/ executables print values, `dune runtest` runs nothing) and no OCaml
+toolchain exists in the build image, so the reference itself cannot be run.
+The oracle is pinned instead by (see tests/test_oracle.py):
+  * the algebraic identity  l1+l2 == dense textbook FITC log-likelihood,
+  * central finite differences of that dense likelihood for every hyper,
+  * an mpmath 50-digit evaluation at tiny n,
+  * the formulas of the reference's Octave cross-check test/oct.m:88-180,
+  * the reference's own gradient self-test recipe (lib/fitc_gp.ml:1223-1462).
+
+Lacaml semantics assumed (Lacaml is not vendored in the reference tree):
+  Mat.syrk_diag ~alpha a ~beta ~y : y <- alpha*diag(a a^T) + beta*y
+  Mat.symm2_trace a b             : tr(a b), a and b symmetric, upper stored
+  Mat.gemm_trace ~transa:`T a b   : tr(a^T b) = sum(a .* b)
+  potri (on a potrf'd upper factor U) : upper triangle of (U^T U)^-1
+    -- lib/block_diag.mli:39-41 documents exactly this use ("using its already
+    precomputed Cholesky factor"), and doc/manual/gpr_manual.tex:710 requires
+    T = K_m^-1 - B^-1.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+from typing import Optional
+
+import numpy as np
+from scipy.linalg import blas, lapack
+
+CHOLESKY_JITTER = 1e-6  # lib/utils.ml:35
+LOG_2PI = math.log(2.0 * (4.0 * math.atan(1.0)))  # lib/utils.ml:39-40
+
+
+class NotPositiveDefinite(RuntimeError):
+    """Mirrors Lacaml's Failure on potrf info > 0."""
+
+
+def _F(a):
+    return np.asfortranarray(a, dtype=np.float64)
+
+
+# ---------------------------------------------------------------------------
+# Cov_se_iso  (lib/cov_se_iso.ml)
+# ---------------------------------------------------------------------------
+@dataclass
+class SeIsoKernel:
+    """lib/cov_se_iso.ml:33-44 (Eval.Kernel.t / create)."""
+
+    log_ell: float
+    log_sf2: float
+    inv_ell2: float = field(init=False)
+    inv_ell2_05: float = field(init=False)
+    sf2: float = field(init=False)
+
+    def __post_init__(self):
+        self.inv_ell2 = math.exp(-2.0 * self.log_ell)
+        self.inv_ell2_05 = -0.5 * self.inv_ell2
+        self.sf2 = math.exp(self.log_sf2)
+
+
+def _sqr_diff_cross(inputs, inducing):
+    """lib/cov_se_iso.ml:128-144: res[r,c] = sum_i (inputs[i,r]-inducing[i,c])^2,
+    accumulated over i in increasing order (same rounding as the scalar loop)."""
+    d, n = inputs.shape
+    m = inducing.shape[1]
+    res = np.zeros((n, m), order="F")
+    for i in range(d):
+        diff = inputs[i, :][:, None] - inducing[i, :][None, :]
+        res += diff * diff
+    return res
+
+
+def se_iso_calc_sqr_diff_upper(inducing):
+    """lib/cov_se_iso.ml:56-72.  Note the operand order: inducing[i,c]-inducing[i,r].
+    The strict lower triangle is left uninitialised by the reference; here NaN so
+    that any consumer reading it is caught."""
+    d, m = inducing.shape
+    res = np.zeros((m, m), order="F")
+    for i in range(d):
+        diff = inducing[i, :][None, :] - inducing[i, :][:, None]  # [r,c] = z_c - z_r
+        res += diff * diff
+    res[np.tril_indices(m, -1)] = np.nan
+    return res
+
+
+def se_iso_calc_upper_with_sqr_diff(k: SeIsoKernel, sqr_diff):
+    """lib/cov_se_iso.ml:74-84; diagonal is exactly sf2."""
+    res = np.exp(k.log_sf2 + k.inv_ell2_05 * sqr_diff)
+    m = res.shape[0]
+    res[np.diag_indices(m)] = k.sf2
+    return _F(res)
+
+
+def se_iso_calc_cross_with_sqr_diff(k: SeIsoKernel, sqr_diff):
+    """lib/cov_se_iso.ml:146-156."""
+    return _F(np.exp(k.log_sf2 + k.inv_ell2_05 * sqr_diff))
+
+
+def se_iso_hypers(d, m):
+    """lib/cov_se_iso.ml:188-202: [Log_ell; Log_sf2; (ind=1,dim=1..d); (ind=2,..); ...]."""
+    hypers = [("log_ell",), ("log_sf2",)]
+    for ind in range(1, m + 1):
+        for dim in range(1, d + 1):
+            hypers.append(("inducing", ind, dim))
+    return hypers
+
+
+# ---------------------------------------------------------------------------
+# Cov_se_fat, projection-only sub-case  (lib/cov_se_fat.ml)
+# ---------------------------------------------------------------------------
+@dataclass
+class SeFatKernel:
+    """lib/cov_se_fat.ml:55-75 with log_hetero_skedasticity = None and
+    log_multiscales_m05 = None (the sub-case on the hot path)."""
+
+    d: int
+    log_sf2: float
+    tproj: Optional[np.ndarray]  # big_dim x d, or None
+    sf2: float = field(init=False)
+
+    def __post_init__(self):
+        self.sf2 = math.exp(self.log_sf2)
+        if self.tproj is not None:
+            self.tproj = _F(self.tproj)
+            if self.tproj.shape[1] != self.d:  # lib/cov_se_fat.ml:38-48
+                raise ValueError("Cov_se_fat.Params.create: tproj projection (%d) disagrees "
+                                 "with target dimension d (%d)" % (self.tproj.shape[1], self.d))
+
+
+def se_fat_project(k: SeFatKernel, inputs):
+    """lib/cov_se_fat.ml:215-218: gemm ~transa:`T tproj inputs."""
+    if k.tproj is None:
+        return _F(inputs)
+    return _F(blas.dgemm(1.0, k.tproj, _F(inputs), trans_a=1))
+
+
+def se_fat_calc_upper_vanilla(k: SeFatKernel, mat):
+    """lib/cov_se_fat.ml:85-100 (diff = mat[i,r]-mat[i,c]; exp(log_sf2 - 0.5*x))."""
+    d, n = mat.shape
+    acc = np.zeros((n, n), order="F")
+    for i in range(k.d):
+        diff = mat[i, :][:, None] - mat[i, :][None, :]
+        acc += diff * diff
+    res = np.exp(k.log_sf2 - 0.5 * acc)
+    res[np.diag_indices(n)] = k.sf2
+    res[np.tril_indices(n, -1)] = np.nan
+    return _F(res)
+
+
+def se_fat_calc_cross_with_projections(k: SeFatKernel, projections, inducing):
+    """lib/cov_se_fat.ml:224-240 (multiscales = None branch)."""
+    acc = np.zeros((projections.shape[1], inducing.shape[1]), order="F")
+    for i in range(k.d):
+        diff = projections[i, :][:, None] - inducing[i, :][None, :]
+        acc += diff * diff
+    return _F(np.exp(k.log_sf2 - 0.5 * acc))
+
+
+def se_fat_hypers(k: SeFatKernel, m):
+    """lib/cov_se_fat.ml:290-342: [Log_sf2; inducing (ind-major); Proj (big_dim-major)]."""
+    hypers = [("log_sf2",)]
+    for ind in range(1, m + 1):
+        for dim in range(1, k.d + 1):
+            hypers.append(("inducing", ind, dim))
+    if k.tproj is not None:
+        for big in range(1, k.tproj.shape[0] + 1):
+            for small in range(1, k.d + 1):
+                hypers.append(("proj", big, small))
+    return hypers
+
+
+# ---------------------------------------------------------------------------
+# Spec dispatch (the two Specs.Deriv instances on the path)
+# ---------------------------------------------------------------------------
+def spec_calc_shared_upper(k, inducing):
+    """Cov_se_iso.Deriv.Inducing.calc_shared_upper lib/cov_se_iso.ml:241-245 /
+    Cov_se_fat.Deriv.Inducing.calc_shared_upper lib/cov_se_fat.ml:414-416."""
+    inducing = _F(inducing)
+    if isinstance(k, SeIsoKernel):
+        sq = se_iso_calc_sqr_diff_upper(inducing)
+        km = se_iso_calc_upper_with_sqr_diff(k, sq)
+        return km, dict(kernel=k, inducing=inducing, sqr_diff_mat=sq, eval_mat=km)
+    km = se_fat_calc_upper_vanilla(k, inducing)
+    return km, dict(kernel=k, inducing=inducing, eval_mat=km)
+
+
+def spec_calc_shared_cross(k, inputs, inducing):
+    """lib/cov_se_iso.ml:290-295 / lib/cov_se_fat.ml:546-554."""
+    inputs = _F(inputs)
+    inducing = _F(inducing)
+    if isinstance(k, SeIsoKernel):
+        sq = _sqr_diff_cross(inputs, inducing)
+        knm = se_iso_calc_cross_with_sqr_diff(k, sq)
+        return knm, dict(kernel=k, inputs=inputs, inducing=inducing, sqr_diff_mat=sq, eval_mat=knm)
+    proj = se_fat_project(k, inputs)
+    knm = se_fat_calc_cross_with_projections(k, proj, inducing)
+    return knm, dict(kernel=k, inputs=inputs, inducing=inducing, projections=proj, eval_mat=knm)
+
+
+def spec_calc_diag(k, n):
+    """lib/cov_se_iso.ml:126 / lib/cov_se_fat.ml:222: constant vector sf2."""
+    return np.full(n, k.sf2)
+
+
+def spec_hypers(k, d_inducing, m):
+    if isinstance(k, SeIsoKernel):
+        return se_iso_hypers(d_inducing, m)
+    return se_fat_hypers(k, m)
+
+
+def spec_calc_deriv_upper(shared_upper, hyper):
+    """lib/cov_se_iso.ml:247-280 / lib/cov_se_fat.ml:418-516 (no hetero/multiscale)."""
+    k = shared_upper["kernel"]
+    eval_mat = shared_upper["eval_mat"]
+    inducing = shared_upper["inducing"]
+    m = eval_mat.shape[0]
+    iso = isinstance(k, SeIsoKernel)
+    kind = hyper[0]
+    if kind == "log_sf2":
+        return ("factor", 1.0)
+    if kind == "log_ell":
+        res = eval_mat * shared_upper["sqr_diff_mat"] * k.inv_ell2
+        res[np.diag_indices(m)] = 0.0
+        return ("dense", _F(res))
+    if kind == "proj":
+        return ("const", 0.0)
+    if kind == "inducing":
+        _, ind, dim = hyper
+        scale = k.inv_ell2 if iso else 1.0
+        res = np.zeros(m)
+        zc = inducing[dim - 1, ind - 1]
+        for i in range(1, m + 1):
+            if i == ind:
+                continue
+            kel = eval_mat[i - 1, ind - 1] if i < ind else eval_mat[ind - 1, i - 1]
+            if iso:
+                res[i - 1] = scale * (inducing[dim - 1, i - 1] - zc) * kel
+            else:
+                res[i - 1] = (inducing[dim - 1, i - 1] - zc) * kel
+        return ("sparse_rows", res, ind)
+    raise ValueError(hyper)
+
+
+def spec_calc_deriv_diag(k, hyper):
+    """lib/cov_se_iso.ml:297-299 / lib/cov_se_fat.ml:527-531."""
+    return ("factor", 1.0) if hyper[0] == "log_sf2" else ("const", 0.0)
+
+
+def spec_calc_deriv_cross(shared_cross, hyper):
+    """lib/cov_se_iso.ml:301-327 / lib/cov_se_fat.ml:563-641 (no multiscale)."""
+    k = shared_cross["kernel"]
+    eval_mat = shared_cross["eval_mat"]
+    inducing = shared_cross["inducing"]
+    iso = isinstance(k, SeIsoKernel)
+    kind = hyper[0]
+    if kind == "log_sf2":
+        return ("factor", 1.0)
+    if kind == "log_ell":
+        return ("dense", _F(eval_mat * shared_cross["sqr_diff_mat"] * k.inv_ell2))
+    if kind == "inducing":
+        _, ind, dim = hyper
+        zc = inducing[dim - 1, ind - 1]
+        if iso:
+            col = k.inv_ell2 * (shared_cross["inputs"][dim - 1, :] - zc) * eval_mat[:, ind - 1]
+        else:
+            col = (shared_cross["projections"][dim - 1, :] - zc) * eval_mat[:, ind - 1]
+        return ("sparse_cols", col, ind)
+    if kind == "proj":
+        _, big, small = hyper
+        if k.tproj is None:
+            raise RuntimeError("Cov_se_fat.Deriv.Inputs.calc_deriv_cross: tproj disabled, "
+                               "cannot calculate derivative")
+        alpha = shared_cross["inputs"][big - 1, :][:, None]
+        proj = shared_cross["projections"][small - 1, :][:, None]
+        ind_el = inducing[small - 1, :][None, :]
+        return ("dense", _F(alpha * (ind_el - proj) * eval_mat))
+    raise ValueError(hyper)
+
+
+# ---------------------------------------------------------------------------
+# Fitc_gp engine  (lib/fitc_gp.ml)
+# ---------------------------------------------------------------------------
+def log_det(chol):
+    """lib/utils.ml:95-101: 2*sum(log diag), summed from i=n down to 1."""
+    acc = 0.0
+    for v in np.diag(chol)[::-1]:
+        acc += math.log(v)
+    return acc + acc
+
+
+def potrf_upper(a):
+    c, info = lapack.dpotrf(a, lower=0, clean=0, overwrite_a=0)
+    if info != 0:
+        raise NotPositiveDefinite("potrf: leading minor of order %d is not positive definite" % info)
+    return _F(c)
+
+
+def ichol(chol):
+    """lib/utils.ml:110-113: upper triangle of (U^T U)^-1 via dpotri."""
+    inv, info = lapack.dpotri(np.triu(chol), lower=0, overwrite_c=0)
+    if info != 0:
+        raise NotPositiveDefinite("potri info=%d" % info)
+    return _F(inv)
+
+
+def inducing_calc_internal(k, points, km):
+    """lib/fitc_gp.ml:53-57."""
+    chol_km = np.triu(km).copy(order="F")  # lacpy ~uplo:`U
+    chol_km[np.diag_indices(chol_km.shape[0])] += CHOLESKY_JITTER
+    chol_km = potrf_upper(chol_km)
+    return dict(kernel=k, points=_F(points), km=km, chol_km=chol_km, log_det_km=log_det(chol_km))
+
+
+def model_calc_internal(inducing, knm, sigma2, kn_diag, v_mat, r_vec):
+    """Common_model.calc_internal lib/fitc_gp.ml:151-220."""
+    if sigma2 < 0.0:
+        raise ValueError("Model.check_sigma2: sigma2 < 0")
+    n, m = v_mat.shape
+    s_vec = r_vec + sigma2
+    is_vec = 1.0 / s_vec
+    log_det_s_vec = 0.0
+    for i in range(n - 1, -1, -1):  # loop from n down to 1
+        log_det_s_vec += math.log(s_vec[i])
+    sqrt_is_vec = np.sqrt(is_vec)
+    q_mat = np.zeros((n + m, m), order="F")
+    q_mat[:n, :] = knm * sqrt_is_vec[:, None]  # lacpy + scal_rows
+    q_mat[n:, :] = np.triu(inducing["chol_km"])
+    qr, tau, _, info = lapack.dgeqrf(q_mat)
+    assert info == 0
+    r_mat = np.triu(qr[:m, :m]).copy(order="F")
+    q_full, _, info = lapack.dorgqr(qr, tau)
+    assert info == 0
+    q_full = _F(q_full)
+    log_det_r = 0.0
+    for r in range(m - 1, -1, -1):  # lib/fitc_gp.ml:183-203 incl. sign fix
+        el = r_mat[r, r]
+        if not el > 0.0:
+            r_mat[r, r:] = -r_mat[r, r:]
+            q_full[:n, r] = -q_full[:n, r]
+            el = -el
+        log_det_r += math.log(el)
+    log_det_r += log_det_r
+    l1 = -0.5 * (log_det_r - inducing["log_det_km"] + log_det_s_vec + float(n) * LOG_2PI)
+    return dict(inducing=inducing, knm=knm, sigma2=sigma2, kn_diag=kn_diag, v_mat=v_mat,
+                r_vec=r_vec, is_vec=is_vec, sqrt_is_vec=sqrt_is_vec, q_mat=q_full,
+                r_mat=r_mat, l1=l1, n=n, m=m)
+
+
+def model_calc_with_kn_diag(inducing, knm, sigma2, kn_diag, variational=False):
+    """lib/fitc_gp.ml:222-229 (+ Variational_model.from_common :262-263)."""
+    v_mat = _F(blas.dtrsm(1.0, inducing["chol_km"], knm, side=1, lower=0, trans_a=0))
+    r_vec = kn_diag - np.einsum("ij,ij->i", v_mat, v_mat)  # Mat.syrk_diag ~alpha:-1 ~beta:1
+    model = model_calc_internal(inducing, knm, sigma2, kn_diag, v_mat, r_vec)
+    model["model_kind"] = "variational" if variational else "standard"
+    if variational:
+        model["l1"] = model["l1"] + (-0.5 * float(np.dot(model["is_vec"], r_vec)))
+    return model
+
+
+def trained_prepare_internal(model, y):
+    """lib/fitc_gp.ml:279-286."""
+    n = model["n"]
+    if y.shape[0] != n:
+        raise ValueError("Trained.calc: Vec.dim targets (%d) <> n (%d)" % (y.shape[0], n))
+    y_ = y * model["sqrt_is_vec"]
+    qt_y_ = model["q_mat"][:n, :].T @ y_
+    return y_, qt_y_
+
+
+def trained_calc_eval(model, y):
+    """Eval Trained.calc lib/fitc_gp.ml:288-292."""
+    y_, qt_y_ = trained_prepare_internal(model, y)
+    l2 = -0.5 * (float(y_ @ y_) - float(qt_y_ @ qt_y_))
+    coeffs = blas.dtrsv(model["r_mat"], qt_y_, lower=0)
+    return dict(model=model, y=y, coeffs=coeffs, l=model["l1"] + l2, l2=l2)
+
+
+def cm_calc(model):
+    """Deriv Common_model.calc_common/calc_internal lib/fitc_gp.ml:1037-1078."""
+    n, m = model["n"], model["m"]
+    inv_km = ichol(model["inducing"]["chol_km"])
+    t_mat = np.triu(inv_km) - np.triu(ichol(model["r_mat"]))
+    q_n = model["q_mat"][:n, :]
+    q_diag = np.einsum("ij,ij->i", q_n, q_n)
+    return dict(eval_model=model, inv_km=inv_km, t_mat=_F(t_mat), q_diag=q_diag)
+
+
+def cm_calc_v1_vec(cm):
+    """lib/fitc_gp.ml:1092-1108."""
+    model = cm["eval_model"]
+    is_vec = model["is_vec"]
+    if model["model_kind"] == "standard":
+        return is_vec * (1.0 - cm["q_diag"])
+    return is_vec * (2.0 - is_vec * model["r_vec"] - cm["q_diag"])
+
+
+def common_calc_log_evidence_sigma2(cm, v_vec):
+    """lib/fitc_gp.ml:1112-1119."""
+    s = float(np.sum(v_vec))
+    if cm["eval_model"]["model_kind"] == "variational":
+        s -= float(np.sum(cm["eval_model"]["is_vec"]))
+    return -0.5 * s
+
+
+def calc_us_mat(model):
+    """Shared.calc_us_mat lib/fitc_gp.ml:931-939."""
+    n = model["n"]
+    u_mat = _F(blas.dtrsm(1.0, model["inducing"]["chol_km"], model["v_mat"], side=1, lower=0, trans_a=1))
+    s_mat = _F(blas.dtrsm(1.0, model["r_mat"], _F(model["q_mat"][:n, :]), side=1, lower=0, trans_a=1))
+    s_mat *= model["sqrt_is_vec"][:, None]
+    return u_mat, s_mat
+
+
+def deriv_trained_calc(cm, y):
+    """Deriv Trained.calc lib/fitc_gp.ml:1158-1181."""
+    model = cm["eval_model"]
+    n = model["n"]
+    y_, qt_y_ = trained_prepare_internal(model, y)
+    u_vec = y_ - model["q_mat"][:n, :] @ qt_y_
+    l2 = -0.5 * float(u_vec @ y_)
+    coeffs = blas.dtrsv(model["r_mat"], qt_y_, lower=0)
+    w_vec = u_vec * model["sqrt_is_vec"]
+    v_vec = cm_calc_v1_vec(cm) - w_vec * w_vec
+    return dict(common_model=cm, w_vec=w_vec, v_vec=v_vec, coeffs=coeffs, l2=l2,
+                l=model["l1"] + l2, y=y)
+
+
+def _upper_to_full(a):
+    return np.triu(a) + np.triu(a, 1).T
+
+
+def model_prepare_hyper(cm):
+    """Cm.prepare_hyper lib/fitc_gp.ml:1126-1136 (model log-evidence only)."""
+    model = cm["eval_model"]
+    v_vec = cm_calc_v1_vec(cm)
+    u_mat, x_mat = calc_us_mat(model)
+    u1 = u_mat * np.sqrt(v_vec)[:, None]
+    w_mat = np.triu(cm["t_mat"]) - np.triu(u1.T @ u1)
+    x_mat = x_mat - u_mat * v_vec[:, None]
+    return dict(cm=cm, v_vec=v_vec, w_mat=_F(w_mat), x_mat=_F(x_mat))
+
+
+def trained_prepare_hyper(tr):
+    """Trained.prepare_hyper lib/fitc_gp.ml:1192-1207."""
+    cm = tr["common_model"]
+    model = cm["eval_model"]
+    u_mat, x_mat = calc_us_mat(model)
+    t_vec = tr["coeffs"]
+    w_mat = np.triu(cm["t_mat"]) - np.triu(np.outer(t_vec, t_vec))  # syr ~alpha:-1
+    u1 = u_mat * np.sqrt(cm_calc_v1_vec(cm))[:, None]
+    w_mat = w_mat - np.triu(u1.T @ u1)  # syrk ~trans:`T ~alpha:-1
+    u2 = u_mat * tr["w_vec"][:, None]
+    w_mat = w_mat + np.triu(u2.T @ u2)
+    x_mat = x_mat - u_mat * tr["v_vec"][:, None] - np.outer(tr["w_vec"], t_vec)  # axpy, ger
+    return dict(cm=cm, v_vec=tr["v_vec"], w_mat=_F(w_mat), x_mat=_F(x_mat))
+
+
+def symm2_trace(a, b):
+    """Mat.symm2_trace: tr(a b) for symmetric a, b referenced by their upper triangles."""
+    ua, ub = np.triu(a, 1), np.triu(b, 1)
+    return float(np.sum(np.diag(a) * np.diag(b)) + 2.0 * np.sum(ua * ub))
+
+
+def sum_symm_mat(a):
+    """lib/utils.ml:81-92."""
+    rest = float(np.sum(np.triu(a, 1)))
+    return rest + float(np.sum(np.diag(a))) + rest
+
+
+def symm2_sparse_trace_single(w_mat, srow, ind):
+    """lib/utils.ml:196-220 specialised to one sparse row (rows = [ind]):
+    full = sum_{r != ind} W[min,max] * s_r ; half = W[ind,ind]*s_ind ; result 2*full+half."""
+    m = w_mat.shape[0]
+    c = ind
+    full = 0.0
+    half = 0.0
+    for r in range(1, m + 1):
+        mat_el = w_mat[c - 1, r - 1] if r > c else w_mat[r - 1, c - 1]
+        if r == c:      # rows_ix = 1, rows_el = c: neither r < c nor c < c -> half branch
+            half += mat_el * srow[c - 1]
+        else:           # r < c: full; r > c: rows_ix was incremented past m -> full
+            full += mat_el * srow[r - 1]
+    return full + half + full
+
+
+def shared_calc_log_evidence(hyper_t, shared, hyper):
+    """Shared.calc_log_evidence lib/fitc_gp.ml:1005-1021 with the term functions
+    calc_dkn_diag_term :943-954, calc_dkm_term :956-973, calc_dknm_term :975-1003."""
+    v_vec, w_mat, x_mat = hyper_t["v_vec"], hyper_t["w_mat"], hyper_t["x_mat"]
+    k = shared["kernel"]
+    dd = spec_calc_deriv_diag(k, hyper)
+    if dd[0] == "factor":
+        dkn_diag_term = 0.0 if dd[1] == 0.0 else dd[1] * float(shared["kn_diag"] @ v_vec)
+    else:
+        dkn_diag_term = 0.0 if dd[1] == 0.0 else dd[1] * float(np.sum(v_vec))
+    dk = spec_calc_deriv_upper(shared["shared_upper"], hyper)
+    if dk[0] == "dense":
+        dkm_term = symm2_trace(w_mat, dk[1])
+    elif dk[0] == "sparse_rows":
+        dkm_term = symm2_sparse_trace_single(w_mat, dk[1], dk[2])
+    elif dk[0] == "const":
+        dkm_term = 0.0 if dk[1] == 0.0 else dk[1] * sum_symm_mat(w_mat)
+    else:  # factor
+        dkm_term = 0.0 if dk[1] == 0.0 else dk[1] * symm2_trace(w_mat, shared["km"])
+    dx = spec_calc_deriv_cross(shared["shared_cross"], hyper)
+    if dx[0] == "dense":
+        dknm_term = float(np.sum(x_mat * dx[1]))
+    elif dx[0] == "sparse_cols":
+        dknm_term = float(x_mat[:, dx[2] - 1] @ dx[1])
+    elif dx[0] == "const":
+        dknm_term = 0.0 if dx[1] == 0.0 else dx[1] * float(np.sum(x_mat))
+    else:
+        dknm_term = 0.0 if dx[1] == 0.0 else dx[1] * float(np.sum(x_mat * shared["knm"]))
+    return (-0.5 * (dkn_diag_term - dkm_term)) - dknm_term
+
+
+# ---------------------------------------------------------------------------
+# One full evaluation, the reference way (multim_dcommon lib/fitc_gp.ml:1612-1636)
+# ---------------------------------------------------------------------------
+def evaluate(k, inducing_points, inputs, targets, sigma2, variational=False,
+             want_grad=True, hypers=None, keep=False):
+    """Returns dict(l1, l2, l, coeffs, dl_dsigma2, grad (reference hyper order),
+    model_dl_dsigma2, model_grad [l1 only]).  `hypers` restricts the gradient
+    (the optimiser's ?hypers, lib/fitc_gp.ml:1535); default = Hyper.get_all."""
+    inducing_points = _F(inducing_points)
+    inputs = _F(inputs)
+    targets = np.asarray(targets, dtype=np.float64)
+    n = inputs.shape[1]
+    km, shared_upper = spec_calc_shared_upper(k, inducing_points)       # Deriv.Inducing.calc :881-888
+    inducing = inducing_calc_internal(k, inducing_points, km)
+    knm, shared_cross = spec_calc_shared_cross(k, inputs, inducing_points)  # Deriv.Inputs.calc :902-911
+    kn_diag = spec_calc_diag(k, n)
+    model = model_calc_with_kn_diag(inducing, knm, sigma2, kn_diag, variational)
+    out = dict(l1=model["l1"])
+    if not want_grad:
+        tr = trained_calc_eval(model, targets)
+        out.update(l2=tr["l2"], l=tr["l"], coeffs=tr["coeffs"])
+        if keep:
+            out["model"] = model
+        return out
+    cm = cm_calc(model)
+    tr = deriv_trained_calc(cm, targets)
+    out.update(l2=tr["l2"], l=tr["l"], coeffs=tr["coeffs"])
+    out["dl_dsigma2"] = common_calc_log_evidence_sigma2(cm, tr["v_vec"])
+    out["model_dl_dsigma2"] = common_calc_log_evidence_sigma2(cm, cm_calc_v1_vec(cm))
+    shared = dict(kernel=k, km=km, knm=knm, kn_diag=kn_diag, shared_upper=shared_upper,
+                  shared_cross=shared_cross)
+    if hypers is None:
+        hypers = spec_hypers(k, inducing_points.shape[0], inducing_points.shape[1])
+    ht = trained_prepare_hyper(tr)
+    out["grad"] = np.array([shared_calc_log_evidence(ht, shared, h) for h in hypers])
+    hm = model_prepare_hyper(cm)
+    out["model_grad"] = np.array([shared_calc_log_evidence(hm, shared, h) for h in hypers])
+    out["hypers"] = hypers
+    if keep:
+        out.update(model=model, cm=cm, trained=tr, hyper_t=ht, shared=shared)
+    return out
+
+
+# ---------------------------------------------------------------------------
+# Vectorised gradient (same math, all hypers at once) -- used where looping over
+# 2+d*m hypers in Python is too slow (cpu_baseline leg, mid-size parity tests).
+# Validated against `evaluate` in tests/test_oracle.py.
+# ---------------------------------------------------------------------------
+def evaluate_fast(k, inducing_points, inputs, targets, sigma2, variational=False):
+    inducing_points = _F(inducing_points)
+    inputs = _F(inputs)
+    targets = np.asarray(targets, dtype=np.float64)
+    n = inputs.shape[1]
+    d, m = inducing_points.shape
+    km, shared_upper = spec_calc_shared_upper(k, inducing_points)
+    inducing = inducing_calc_internal(k, inducing_points, km)
+    knm, shared_cross = spec_calc_shared_cross(k, inputs, inducing_points)
+    kn_diag = spec_calc_diag(k, n)
+    model = model_calc_with_kn_diag(inducing, knm, sigma2, kn_diag, variational)
+    cm = cm_calc(model)
+    tr = deriv_trained_calc(cm, targets)
+    ht = trained_prepare_hyper(tr)
+    v_vec, w_mat, x_mat = ht["v_vec"], ht["w_mat"], ht["x_mat"]
+    out = dict(l1=model["l1"], l2=tr["l2"], l=tr["l"], coeffs=tr["coeffs"],
+               dl_dsigma2=common_calc_log_evidence_sigma2(cm, tr["v_vec"]))
+    iso = isinstance(k, SeIsoKernel)
+    scale = k.inv_ell2 if iso else 1.0
+    wfull = _upper_to_full(w_mat)
+    kmfull = _upper_to_full(km)
+    e_mat = x_mat * knm                       # X .* K_nm
+    g_sf2 = -0.5 * (k.sf2 * float(np.sum(v_vec)) - symm2_trace(w_mat, km)) - float(np.sum(e_mat))
+    wk = wfull * kmfull
+    np.fill_diagonal(wk, 0.0)
+    # inducing hyper (ind=c, dim=kk): 0.5*dkm_term - dknm_term
+    pts = shared_cross["inputs"] if iso else shared_cross["projections"]
+    dkm = 2.0 * scale * (inducing_points @ wk - inducing_points * np.sum(wk, axis=0)[None, :])
+    dknm = scale * (pts @ e_mat - inducing_points * np.sum(e_mat, axis=0)[None, :])
+    g_ind = (0.5 * dkm - dknm).T.reshape(-1)  # ind-major, dim fastest
+    if iso:
+        sq_u = np.nan_to_num(shared_upper["sqr_diff_mat"], nan=0.0)
+        dkm_ell = symm2_trace(w_mat, np.triu(km * sq_u * k.inv_ell2, 1))
+        dknm_ell = float(np.sum(e_mat * shared_cross["sqr_diff_mat"])) * k.inv_ell2
+        g_ell = 0.5 * dkm_ell - dknm_ell
+        out["grad"] = np.concatenate([[g_ell, g_sf2], g_ind])
+    else:
+        parts = [[g_sf2], g_ind]
+        if k.tproj is not None:
+            ez = e_mat @ inducing_points.T                      # n x d : sum_c E_rc z_small,c
+            rs = np.sum(e_mat, axis=1)[:, None] * pts.T          # n x d : rowsum(E)_r p_small,r
+            g_proj = -(shared_cross["inputs"] @ (ez - rs))      # big x small
+            parts.append(g_proj.reshape(-1))
+        out["grad"] = np.concatenate(parts)
+    return out
+
+
+# ---------------------------------------------------------------------------
+# Independent known-answer check: dense textbook FITC log marginal likelihood
+# (doc/manual/gpr_manual.tex:684-701; Snelson & Ghahramani 2006), no QR, no
+# inducing-space tricks.  O(n^3): small n only.
+# ---------------------------------------------------------------------------
+def dense_fitc_log_evidence(k, inducing_points, inputs, targets, sigma2, variational=False):
+    inducing_points = _F(inducing_points)
+    inputs = _F(inputs)
+    n = inputs.shape[1]
+    km, _ = spec_calc_shared_upper(k, inducing_points)
+    km = _upper_to_full(np.nan_to_num(km, nan=0.0)) + CHOLESKY_JITTER * np.eye(km.shape[0])
+    knm, _ = spec_calc_shared_cross(k, inputs, inducing_points)
+    qnn = knm @ np.linalg.solve(km, knm.T)
+    r = k.sf2 - np.diag(qnn)
+    cov = qnn + np.diag(r + sigma2)
+    sign, logdet = np.linalg.slogdet(cov)
+    assert sign > 0
+    alpha = np.linalg.solve(cov, targets)
+    l = -0.5 * (logdet + float(targets @ alpha) + n * LOG_2PI)
+    if variational:
+        l += -0.5 * float(np.sum(r / (r + sigma2)))
+    return l
