@@ -1,0 +1,42 @@
+// Shared declarations for the gprhip library (gfx950 / MI355X only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <string>
+
+namespace gprhip {
+
+// status codes returned across the C ABI (include/gprhip.h)
+enum : int {
+  ST_OK = 0,
+  ST_BAD_ARG = 1,
+  ST_NOT_POSDEF = 2,
+  ST_HIP_ERROR = 3,
+  ST_OOM = 4,
+  ST_STATE = 5,
+};
+
+void set_error(const std::string& msg);
+
+struct HipFail {
+  int status;
+};
+
+#define GPR_HIP(call)                                                                   \
+  do {                                                                                  \
+    hipError_t e__ = (call);                                                            \
+    if (e__ != hipSuccess) {                                                            \
+      ::gprhip::set_error(std::string("gprhip: HIP error: ") + hipGetErrorString(e__) + \
+                          " at " __FILE__ ":" + std::to_string(__LINE__));              \
+      throw ::gprhip::HipFail{e__ == hipErrorOutOfMemory ? ::gprhip::ST_OOM             \
+                                                         : ::gprhip::ST_HIP_ERROR};     \
+    }                                                                                   \
+  } while (0)
+
+constexpr int TILE = 128;  // MFMA engine block tile (rows and columns)
+constexpr int BK = 16;     // MFMA engine k-depth per LDS stage
+
+static inline int64_t round_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
+
+}  // namespace gprhip

@@ -1,0 +1,54 @@
+// fp64 MFMA contraction engine for gfx950 (v_mfma_f64_16x16x4_f64).
+//
+// One kernel family covers every n x m x m / m x m x m contraction on the FITC
+// path: right-side triangular
+// multiplies (the TRSM/TRMM rows), SYRK-shaped accumulations over training
+// points, and the trailing updates of the blocked Cholesky / triangular inverse.
+//
+// All matrices are dense row-major doubles whose dimensions the caller has padded:
+// M, N multiples of 128 (TILE), K a multiple of 16 (BK).
+#pragma once
+#include "common.h"
+
+namespace gprhip {
+
+enum GemmOp : int {
+  OP_NN = 0,  // C[i][j] = sum_k A[i][k]   * B[k][j]     (A row-major M x K, B row-major K x N)
+  OP_NT = 1,  // C[i][j] = sum_k A[i][k]   * B[j][k]     (B row-major N x K)
+  OP_TN = 2,  // C[i][j] = sum_k s[k]*A[k][i] * B[k][j]  (A row-major K x M, B row-major K x N)
+};
+
+// Which k-tiles a block visits: lets triangular operands skip their zero blocks.
+enum GemmTri : int {
+  TRI_NONE = 0,
+  TRI_KHI_BN = 1,   // k <  end of the block's column tile   (NN, B upper triangular)
+  TRI_KLO_BN = 2,   // k >= start of the block's column tile (NT, B upper triangular)
+  TRI_KLO_BM = 3,   // k >= start of the block's row tile    (NN, A upper triangular)
+  TRI_KLO_MAX = 4,  // k >= max(row tile, column tile) start (NT, A and B upper triangular)
+  TRI_KHI_MIN = 5,  // k <  min(row tile, column tile) end   (TN, A and B upper triangular)
+};
+
+struct GemmArgs {
+  const double* A = nullptr;
+  int64_t lda = 0;
+  const double* B = nullptr;
+  int64_t ldb = 0;
+  double* C = nullptr;
+  int64_t ldc = 0;
+  int M = 0, N = 0, K = 0;
+  double alpha = 1.0;
+  double beta = 0.0;              // 0: overwrite, otherwise C = alpha*AB + beta*C
+  const double* scale_k = nullptr;  // OP_TN only: per-k weight on the A operand (may be null)
+  int tri = TRI_NONE;
+  int upper_only = 0;    // compute only tiles with row tile <= column tile
+  int kslices = 1;       // split K over gridDim.z; slice z writes C + z*slice_stride
+  int64_t slice_stride = 0;
+};
+
+// Enqueue on `stream`.  Returns the number of multiply-add flops issued (x2), for accounting.
+void launch_gemm(GemmOp op, const GemmArgs& g, hipStream_t stream);
+
+// One-time per-process setup (raises the dynamic-LDS limit of the kernels).
+void gemm_init();
+
+}  // namespace gprhip

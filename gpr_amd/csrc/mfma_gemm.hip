@@ -1,0 +1,237 @@
+// fp64 MFMA contraction engine (see mfma_gemm.h).
+//
+// Block = 256 threads = 4 wavefronts (2 x 2), block tile 128 x 128, wave tile 64 x 64 held as
+// 4 x 4 accumulators of v_mfma_f64_16x16x4_f64 (4 doubles per lane each = 128 VGPRs).
+// k advances 16 per LDS stage; two stages are double-buffered so the global loads of stage t+1
+// are in flight while stage t is multiplied (one barrier per stage).
+//
+// LDS images (doubles):
+//   x-major operand (global contiguous along k):  [128][18]  -- row stride 18 makes the fragment
+//       read (lane -> row l&15, k l>>4) hit 32 distinct 8-byte bank pairs per half-wave;
+//   k-major operand (global contiguous along x):  [16][144]  -- row stride 144 puts the two k-rows
+//       a half-wave touches on disjoint bank halves.
+// Fragment maps (cdna_hip_programming.md section 3, f64 form): A lane l holds A[i=l&15][k=l>>4],
+// B lane l holds B[k=l>>4][j=l&15], C/D lane l reg r holds C[(l>>4)+4r][l&15].
+#include "mfma_gemm.h"
+
+namespace gprhip {
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+typedef double d2 __attribute__((ext_vector_type(2)));
+
+constexpr int XS = 18;                // x-major row stride
+constexpr int KS = 144;               // k-major row stride
+constexpr int STAGE = 128 * XS;       // == 16 * KS == 2304 doubles per operand per stage
+constexpr int LDS_BYTES = 4 * STAGE * 8;
+
+__device__ __forceinline__ void tile_of_block(const GemmArgs& g, int t, int nbm, int nbn, int& bm,
+                                              int& bn) {
+  if (g.upper_only) {
+    // enumerate (bm <= bn) pairs; heavy tiles first for the triangular k-ranges
+    int total = nbn * (nbn + 1) / 2;
+    if (g.tri == TRI_KHI_MIN) t = total - 1 - t;
+    int c = 0;
+    while (t >= c + 1) {
+      t -= c + 1;
+      ++c;
+    }
+    bn = c;
+    bm = t;
+    return;
+  }
+  if (g.tri == TRI_KLO_BM) {
+    bm = t / nbn;
+    bn = t % nbn;
+    return;
+  }
+  int bi = t / nbm;
+  bm = t % nbm;
+  bn = (g.tri == TRI_KHI_BN) ? (nbn - 1 - bi) : bi;
+}
+
+template <int OP>
+__global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  constexpr bool A_KMAJ = (OP == OP_TN);
+  constexpr bool B_XMAJ = (OP == OP_NT);
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wid = tid >> 6;
+  const int wr = wid >> 1, wc = wid & 1;
+  const int l15 = lane & 15, lq = lane >> 4;
+
+  const int nbm = g.M / TILE, nbn = g.N / TILE;
+  int bm, bn;
+  tile_of_block(g, blockIdx.x, nbm, nbn, bm, bn);
+
+  // k-range of this block, in elements
+  int k_lo = 0, k_hi = g.K;
+  if (g.kslices > 1) {
+    int per = ((g.K / BK + g.kslices - 1) / g.kslices) * BK;
+    k_lo = blockIdx.z * per;
+    k_hi = min(g.K, k_lo + per);
+  }
+  switch (g.tri) {
+    case TRI_KHI_BN: k_hi = min(k_hi, (bn + 1) * TILE); break;
+    case TRI_KLO_BN: k_lo = max(k_lo, bn * TILE); break;
+    case TRI_KLO_BM: k_lo = max(k_lo, bm * TILE); break;
+    case TRI_KLO_MAX: k_lo = max(k_lo, max(bm, bn) * TILE); break;
+    case TRI_KHI_MIN: k_hi = min(k_hi, (min(bm, bn) + 1) * TILE); break;
+    default: break;
+  }
+  const int nk = (k_hi - k_lo) / BK;
+
+  d4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (d4){0.0, 0.0, 0.0, 0.0};
+
+  // ---- per-thread staging coordinates
+  // x-major tile: row = (tid>>3) + 32p, kpair = tid&7 ; k-major tile: k = (tid>>6) + 4p, xpair = tid&63
+  const int xm_row = tid >> 3, xm_kp = tid & 7;
+  const int km_k = tid >> 6, km_xp = tid & 63;
+
+  const double* Ag;
+  int64_t a_step;  // global advance per k-stage
+  if (A_KMAJ) {
+    Ag = g.A + (int64_t)(k_lo + km_k) * g.lda + (int64_t)bm * TILE + 2 * km_xp;
+    a_step = (int64_t)BK * g.lda;
+  } else {
+    Ag = g.A + (int64_t)(bm * TILE + xm_row) * g.lda + k_lo + 2 * xm_kp;
+    a_step = BK;
+  }
+  const double* Bg;
+  int64_t b_step;
+  if (B_XMAJ) {
+    Bg = g.B + (int64_t)(bn * TILE + xm_row) * g.ldb + k_lo + 2 * xm_kp;
+    b_step = BK;
+  } else {
+    Bg = g.B + (int64_t)(k_lo + km_k) * g.ldb + (int64_t)bn * TILE + 2 * km_xp;
+    b_step = (int64_t)BK * g.ldb;
+  }
+  const double* sk = (A_KMAJ && g.scale_k) ? g.scale_k + k_lo + km_k : nullptr;
+
+  d2 ra[4], rb[4];
+  auto load_global = [&](int t) {
+    const double* ap = Ag + (int64_t)t * a_step;
+    const double* bp = Bg + (int64_t)t * b_step;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      if (A_KMAJ) {
+        d2 v = *reinterpret_cast<const d2*>(ap + (int64_t)(4 * p) * g.lda);
+        if (sk) {
+          double s = sk[t * BK + 4 * p];
+          v.x *= s;
+          v.y *= s;
+        }
+        ra[p] = v;
+      } else {
+        ra[p] = *reinterpret_cast<const d2*>(ap + (int64_t)(32 * p) * g.lda);
+      }
+      if (B_XMAJ) {
+        rb[p] = *reinterpret_cast<const d2*>(bp + (int64_t)(32 * p) * g.ldb);
+      } else {
+        rb[p] = *reinterpret_cast<const d2*>(bp + (int64_t)(4 * p) * g.ldb);
+      }
+    }
+  };
+  auto store_lds = [&](int stage) {
+    double* As = smem + stage * 2 * STAGE;
+    double* Bs = As + STAGE;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      if (A_KMAJ)
+        *reinterpret_cast<d2*>(As + (km_k + 4 * p) * KS + 2 * km_xp) = ra[p];
+      else
+        *reinterpret_cast<d2*>(As + (xm_row + 32 * p) * XS + 2 * xm_kp) = ra[p];
+      if (B_XMAJ)
+        *reinterpret_cast<d2*>(Bs + (xm_row + 32 * p) * XS + 2 * xm_kp) = rb[p];
+      else
+        *reinterpret_cast<d2*>(Bs + (km_k + 4 * p) * KS + 2 * km_xp) = rb[p];
+    }
+  };
+
+  // fragment base offsets (doubles) inside a stage
+  const int a_frag = A_KMAJ ? (lq * KS + wr * 64 + l15) : ((wr * 64 + l15) * XS + lq);
+  const int b_frag = B_XMAJ ? ((wc * 64 + l15) * XS + lq) : (lq * KS + wc * 64 + l15);
+  constexpr int A_TM = A_KMAJ ? 16 : 16 * XS;  // advance per 16-row sub-tile
+  constexpr int A_KK = A_KMAJ ? 4 * KS : 4;    // advance per k-step of 4
+  constexpr int B_TN = B_XMAJ ? 16 * XS : 16;
+  constexpr int B_KK = B_XMAJ ? 4 : 4 * KS;
+
+  if (nk > 0) {
+    load_global(0);
+    store_lds(0);
+    __syncthreads();
+    for (int t = 0; t < nk; ++t) {
+      const bool more = (t + 1 < nk);
+      if (more) load_global(t + 1);
+      const double* As = smem + (t & 1) * 2 * STAGE;
+      const double* Bs = As + STAGE;
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        double af[4], bf[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) af[i] = As[a_frag + i * A_TM + kk * A_KK];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bf[j] = Bs[b_frag + j * B_TN + kk * B_KK];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i], bf[j], acc[i][j], 0, 0, 0);
+      }
+      if (more) store_lds((t + 1) & 1);
+      __syncthreads();
+    }
+  }
+
+  // ---- epilogue
+  double* Cp = g.C + (int64_t)blockIdx.z * g.slice_stride +
+               (int64_t)(bm * TILE + wr * 64 + lq) * g.ldc + (int64_t)bn * TILE + wc * 64 + l15;
+  const double alpha = g.alpha, beta = g.beta;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        double* p = Cp + (int64_t)(i * 16 + 4 * r) * g.ldc + j * 16;
+        double v = alpha * acc[i][j][r];
+        if (beta != 0.0) v += beta * (*p);
+        *p = v;
+      }
+}
+
+void gemm_init() {
+  static bool done = false;
+  if (done) return;
+  GPR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<OP_NN>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+  GPR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<OP_NT>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+  GPR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<OP_TN>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+  done = true;
+}
+
+void launch_gemm(GemmOp op, const GemmArgs& g, hipStream_t stream) {
+  if (g.M % TILE || g.N % TILE || g.K % BK || g.M <= 0 || g.N <= 0 || g.K <= 0) {
+    set_error("gprhip: launch_gemm: dimensions must be padded (M,N % 128, K % 16)");
+    throw HipFail{ST_BAD_ARG};
+  }
+  const int nbm = g.M / TILE, nbn = g.N / TILE;
+  int tiles = g.upper_only ? nbn * (nbn + 1) / 2 : nbm * nbn;
+  dim3 grid(tiles, 1, g.kslices > 1 ? g.kslices : 1);
+  dim3 block(256);
+  switch (op) {
+    case OP_NN: hipLaunchKernelGGL(gemm_kernel<OP_NN>, grid, block, LDS_BYTES, stream, g); break;
+    case OP_NT: hipLaunchKernelGGL(gemm_kernel<OP_NT>, grid, block, LDS_BYTES, stream, g); break;
+    case OP_TN: hipLaunchKernelGGL(gemm_kernel<OP_TN>, grid, block, LDS_BYTES, stream, g); break;
+  }
+  GPR_HIP(hipGetLastError());
+}
+
+}  // namespace gprhip

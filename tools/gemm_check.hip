@@ -1,0 +1,110 @@
+// Standalone correctness + timing harness for the fp64 MFMA engine (runs on the GPU box).
+#include <vector>
+#include <cmath>
+#include <cstdlib>
+#include <algorithm>
+#include "../gpr_amd/csrc/mfma_gemm.h"
+using namespace gprhip;
+
+__global__ void naive(int op, const double* A, int64_t lda, const double* B, int64_t ldb, double* C,
+                      int64_t ldc, int M, int N, int K, const double* sk) {
+  int j = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y;
+  if (j >= N) return;
+  double s = 0;
+  for (int k = 0; k < K; ++k) {
+    double a = op == OP_TN ? A[(int64_t)k * lda + i] * (sk ? sk[k] : 1.0) : A[(int64_t)i * lda + k];
+    double b = op == OP_NT ? B[(int64_t)j * ldb + k] : B[(int64_t)k * ldb + j];
+    s += a * b;
+  }
+  C[(int64_t)i * ldc + j] = s;
+}
+
+static double frand() { return (double)rand() / RAND_MAX * 2 - 1; }
+
+int check(GemmOp op, int M, int N, int K, int tri, bool scale) {
+  int64_t ar = op == OP_TN ? K : M, ac = op == OP_TN ? M : K;
+  int64_t br = op == OP_NT ? N : K, bc = op == OP_NT ? K : N;
+  std::vector<double> hA(ar * ac), hB(br * bc), hs(K);
+  for (auto& v : hA) v = frand();
+  for (auto& v : hB) v = frand();
+  for (auto& v : hs) v = frand();
+  // zero the parts the triangular policies assume zero
+  if (tri == TRI_KHI_BN) for (int k = 0; k < K; ++k) for (int j = 0; j < N; ++j) if (k > j) hB[(int64_t)k * bc + j] = 0;
+  if (tri == TRI_KLO_BN) for (int j = 0; j < N; ++j) for (int k = 0; k < K; ++k) if (k < j) hB[(int64_t)j * bc + k] = 0;
+  if (tri == TRI_KLO_BM) for (int i = 0; i < M; ++i) for (int k = 0; k < K; ++k) if (k < i) hA[(int64_t)i * ac + k] = 0;
+  if (tri == TRI_KLO_MAX) {
+    for (int i = 0; i < M; ++i) for (int k = 0; k < K; ++k) if (k < i) hA[(int64_t)i * ac + k] = 0;
+    for (int j = 0; j < N; ++j) for (int k = 0; k < K; ++k) if (k < j) hB[(int64_t)j * bc + k] = 0;
+  }
+  double *dA, *dB, *dC, *dR, *ds;
+  hipMalloc(&dA, hA.size() * 8); hipMalloc(&dB, hB.size() * 8); hipMalloc(&ds, K * 8);
+  hipMalloc(&dC, (int64_t)M * N * 8); hipMalloc(&dR, (int64_t)M * N * 8);
+  hipMemcpy(dA, hA.data(), hA.size() * 8, hipMemcpyHostToDevice);
+  hipMemcpy(dB, hB.data(), hB.size() * 8, hipMemcpyHostToDevice);
+  hipMemcpy(ds, hs.data(), K * 8, hipMemcpyHostToDevice);
+  hipMemset(dC, 0, (int64_t)M * N * 8);
+  GemmArgs g; g.A = dA; g.lda = ac; g.B = dB; g.ldb = bc; g.C = dC; g.ldc = N; g.M = M; g.N = N; g.K = K;
+  g.tri = tri; g.scale_k = scale ? ds : nullptr;
+  launch_gemm(op, g, 0);
+  naive<<<dim3((N + 255) / 256, M), 256>>>(op, dA, ac, dB, bc, dR, N, M, N, K, scale ? ds : nullptr);
+  std::vector<double> hC((int64_t)M * N), hR((int64_t)M * N);
+  hipMemcpy(hC.data(), dC, hC.size() * 8, hipMemcpyDeviceToHost);
+  hipMemcpy(hR.data(), dR, hR.size() * 8, hipMemcpyDeviceToHost);
+  double maxerr = 0;
+  for (size_t i = 0; i < hC.size(); ++i) maxerr = std::max(maxerr, fabs(hC[i] - hR[i]));
+  printf("check op=%d M=%d N=%d K=%d tri=%d scale=%d maxerr=%.3e %s\n", op, M, N, K, tri, (int)scale, maxerr,
+         maxerr < 1e-10 * K ? "OK" : "FAIL");
+  hipFree(dA); hipFree(dB); hipFree(dC); hipFree(dR); hipFree(ds);
+  return maxerr < 1e-10 * K ? 0 : 1;
+}
+
+void timeit(GemmOp op, int M, int N, int K, int tri, int upper, int kslices, const char* name) {
+  int64_t ar = op == OP_TN ? K : M, ac = op == OP_TN ? M : K;
+  int64_t br = op == OP_NT ? N : K, bc = op == OP_NT ? K : N;
+  double *dA, *dB, *dC;
+  hipMalloc(&dA, ar * ac * 8); hipMalloc(&dB, br * bc * 8);
+  hipMalloc(&dC, (int64_t)M * N * 8 * std::max(1, kslices));
+  std::vector<double> h(std::max(ar * ac, br * bc));
+  for (auto& v : h) v = frand();
+  hipMemcpy(dA, h.data(), ar * ac * 8, hipMemcpyHostToDevice);
+  hipMemcpy(dB, h.data(), br * bc * 8, hipMemcpyHostToDevice);
+  hipMemset(dC, 0, (int64_t)M * N * 8 * std::max(1, kslices));
+  GemmArgs g; g.A = dA; g.lda = ac; g.B = dB; g.ldb = bc; g.C = dC; g.ldc = N; g.M = M; g.N = N; g.K = K;
+  g.tri = tri; g.upper_only = upper; g.kslices = kslices; g.slice_stride = (int64_t)M * N; g.beta = kslices > 1 ? 1.0 : 0.0;
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  for (int i = 0; i < 2; ++i) launch_gemm(op, g, 0);
+  hipEventRecord(e0, 0);
+  int reps = 5;
+  for (int i = 0; i < reps; ++i) launch_gemm(op, g, 0);
+  hipEventRecord(e1, 0); hipEventSynchronize(e1);
+  float ms; hipEventElapsedTime(&ms, e0, e1); ms /= reps;
+  double flops = 2.0 * M * N * (double)K;
+  if (tri != TRI_NONE) flops *= 0.5;
+  if (upper) flops *= 0.5;
+  printf("time %-28s M=%d N=%d K=%d tri=%d upper=%d ks=%d : %.3f ms  %.1f TFLOP/s (useful)\n", name, M, N, K, tri,
+         upper, kslices, ms, flops / ms * 1e-9);
+  hipFree(dA); hipFree(dB); hipFree(dC);
+}
+
+int main() {
+  gemm_init();
+  int bad = 0;
+  bad += check(OP_NN, 256, 256, 64, TRI_NONE, false);
+  bad += check(OP_NT, 256, 384, 48, TRI_NONE, false);
+  bad += check(OP_TN, 256, 256, 80, TRI_NONE, true);
+  bad += check(OP_NN, 384, 256, 256, TRI_KHI_BN, false);
+  bad += check(OP_NT, 384, 256, 256, TRI_KLO_BN, false);
+  bad += check(OP_NN, 256, 128, 256, TRI_KLO_BM, false);
+  bad += check(OP_NT, 256, 256, 256, TRI_KLO_MAX, false);
+  printf("checks failed: %d\n", bad);
+  timeit(OP_NN, 8192, 8192, 8192, TRI_NONE, 0, 1, "square NN 8192");
+  timeit(OP_NN, 32768, 2048, 2048, TRI_NONE, 0, 1, "K*Uinv full");
+  timeit(OP_NN, 32768, 2048, 2048, TRI_KHI_BN, 0, 1, "K*Uinv triu");
+  timeit(OP_NT, 32768, 2048, 2048, TRI_KLO_BN, 0, 1, "V*Uinv^T triu");
+  timeit(OP_TN, 2048, 2048, 32768, TRI_NONE, 1, 8, "syrk upper ks8");
+  timeit(OP_TN, 2048, 2048, 32768, TRI_NONE, 1, 16, "syrk upper ks16");
+  timeit(OP_NN, 8192, 2048, 2048, TRI_KHI_BN, 0, 1, "K*Uinv triu small chunk");
+  timeit(OP_NN, 131072, 2048, 2048, TRI_KHI_BN, 0, 1, "K*Uinv triu big chunk");
+  timeit(OP_NN, 32768, 4096, 4096, TRI_KHI_BN, 0, 1, "K*Uinv triu m4096");
+  return bad;
+}
