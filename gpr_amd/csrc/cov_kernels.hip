@@ -1,0 +1,144 @@
+// Covariance builders for Cov_se_iso / Cov_se_fat (projection-only) -- HBM/transcendental-bound.
+//
+// Squared distances are accumulated exactly like the reference's scalar loops
+// (lib/cov_se_iso.ml:128-144, lib/cov_se_fat.ml:232-240): sum over dimensions in
+// increasing order of (x_i - z_i)*(x_i - z_i), separate multiply and add (no FMA
+// contraction), then exp(log_sf2 + inv_ell2_05 * r2).  Only the last-ulp behaviour of
+// exp() can differ from the CPU.
+#include "kernels.h"
+
+namespace gprhip {
+
+#pragma clang fp contract(off)
+
+template <int DT>
+__global__ __launch_bounds__(256) void cov_cross_kernel(CovParams cp, const double* __restrict__ pts,
+                                                        int rows, int rows_p,
+                                                        const double* __restrict__ Z, int m, int mp,
+                                                        int d, double* __restrict__ K) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= mp) return;
+  const int r0 = blockIdx.y * 32;
+  double z[DT];
+#pragma unroll
+  for (int k = 0; k < DT; ++k) z[k] = (k < d && j < m) ? Z[(int64_t)j * d + k] : 0.0;
+  const bool live_col = j < m;
+  for (int i = 0; i < 32; ++i) {
+    const int r = r0 + i;
+    if (r >= rows_p) break;
+    double val = 0.0;
+    if (r < rows && live_col) {
+      const double* x = pts + (int64_t)r * d;
+      double acc = 0.0;
+#pragma unroll
+      for (int k = 0; k < DT; ++k) {
+        if (k < d) {
+          double diff = x[k] - z[k];
+          acc = acc + diff * diff;
+        }
+      }
+      val = exp(cp.log_sf2 + cp.inv_ell2_05 * acc);
+    }
+    K[(int64_t)r * mp + j] = val;
+  }
+}
+
+template <int DT>
+__global__ __launch_bounds__(256) void cov_upper_kernel(CovParams cp, const double* __restrict__ Z,
+                                                        int m, int mp, int d, double jitter,
+                                                        double* __restrict__ km,
+                                                        double* __restrict__ kj) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= mp) return;
+  const int r0 = blockIdx.y * 32;
+  double z[DT];
+#pragma unroll
+  for (int k = 0; k < DT; ++k) z[k] = (k < d && c < m) ? Z[(int64_t)c * d + k] : 0.0;
+  for (int i = 0; i < 32; ++i) {
+    const int r = r0 + i;
+    if (r >= mp) break;
+    double val = 0.0, valj = 0.0;
+    if (r < m && c < m) {
+      if (r == c) {
+        val = cp.sf2;  // lib/cov_se_iso.ml:82, lib/cov_se_fat.ml:98
+        valj = cp.sf2 + jitter;
+      } else {
+        const double* x = Z + (int64_t)r * d;
+        double acc = 0.0;
+#pragma unroll
+        for (int k = 0; k < DT; ++k) {
+          if (k < d) {
+            double diff = z[k] - x[k];
+            acc = acc + diff * diff;
+          }
+        }
+        val = exp(cp.log_sf2 + cp.inv_ell2_05 * acc);
+        valj = val;
+      }
+    } else if (r == c) {
+      valj = 1.0;  // padding: identity block, contributes log 1 = 0 to every determinant
+    }
+    km[(int64_t)r * mp + c] = val;
+    kj[(int64_t)r * mp + c] = valj;
+  }
+}
+
+// P[r][small] = sum_big tproj(big,small) * X[r][big]  -- dgemm ~transa:`T tproj inputs.
+// Accumulation order over `big` is increasing with FMA (BLAS dgemm does not promise an order).
+#pragma clang fp contract(fast)
+__global__ __launch_bounds__(256) void project_kernel(const double* __restrict__ X, int64_t n, int D,
+                                                      int d, const double* __restrict__ tproj,
+                                                      double* __restrict__ P) {
+  int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= n * d) return;
+  int64_t r = idx / d;
+  int small = (int)(idx % d);
+  const double* x = X + r * D;
+  const double* tp = tproj + (int64_t)small * D;
+  double acc = 0.0;
+  for (int b = 0; b < D; ++b) acc += tp[b] * x[b];
+  P[idx] = acc;
+}
+
+template <typename F>
+static void dispatch_dt(int d, F&& f) {
+  if (d <= 4) f(std::integral_constant<int, 4>{});
+  else if (d <= 8) f(std::integral_constant<int, 8>{});
+  else if (d <= 16) f(std::integral_constant<int, 16>{});
+  else if (d <= 32) f(std::integral_constant<int, 32>{});
+  else if (d <= 64) f(std::integral_constant<int, 64>{});
+  else {
+    set_error("gprhip: input dimension d > 64 is not supported by the covariance kernels");
+    throw HipFail{ST_BAD_ARG};
+  }
+}
+
+void launch_cov_upper(const CovParams& cp, const double* Z, int m, int mp, int d, double jitter,
+                      double* km, double* kj, hipStream_t s) {
+  dim3 grid(mp / 256 + (mp % 256 ? 1 : 0), (mp + 31) / 32);
+  dispatch_dt(d, [&](auto dt) {
+    hipLaunchKernelGGL((cov_upper_kernel<decltype(dt)::value>), grid, dim3(256), 0, s, cp, Z, m, mp, d,
+                       jitter, km, kj);
+  });
+  GPR_HIP(hipGetLastError());
+}
+
+void launch_cov_cross(const CovParams& cp, const double* pts, int rows, int rows_p, const double* Z,
+                      int m, int mp, int d, double* K, hipStream_t s) {
+  dim3 grid(mp / 256 + (mp % 256 ? 1 : 0), (rows_p + 31) / 32);
+  dispatch_dt(d, [&](auto dt) {
+    hipLaunchKernelGGL((cov_cross_kernel<decltype(dt)::value>), grid, dim3(256), 0, s, cp, pts, rows,
+                       rows_p, Z, m, mp, d, K);
+  });
+  GPR_HIP(hipGetLastError());
+}
+
+void launch_project(const double* X, int64_t n, int D, int d, const double* tproj, double* P,
+                    hipStream_t s) {
+  int64_t total = n * d;
+  hipLaunchKernelGGL(project_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, X, n, D, d,
+                     tproj, P);
+  GPR_HIP(hipGetLastError());
+}
+
+}  // namespace gprhip

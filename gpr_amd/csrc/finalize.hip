@@ -1,0 +1,119 @@
+// m x m element-wise finalisation kernels (negligible cost next to the n x m x m contractions).
+#include "kernels.h"
+
+namespace gprhip {
+
+// dst = base + sum_z slices[z] on upper tiles (row tile <= column tile), 0 elsewhere.
+__global__ __launch_bounds__(256) void sum_slices_kernel(const double* __restrict__ base,
+                                                         const double* __restrict__ slices, int nslices,
+                                                         int64_t stride, int mp,
+                                                         double* __restrict__ dst) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  const int r = blockIdx.y;
+  if (c >= mp) return;
+  const int64_t off = (int64_t)r * mp + c;
+  double acc = 0.0;
+  if (r / TILE <= c / TILE) {
+    acc = base ? base[off] : 0.0;
+    for (int z = 0; z < nslices; ++z) acc += slices[(int64_t)z * stride + off];
+  }
+  dst[off] = acc;
+}
+
+void launch_sum_slices(const double* base, const double* slices, int nslices, int64_t stride, int mp,
+                       double* dst, hipStream_t s) {
+  hipLaunchKernelGGL(sum_slices_kernel, dim3((mp + 255) / 256, mp), dim3(256), 0, s, base, slices,
+                     nslices, stride, mp, dst);
+  GPR_HIP(hipGetLastError());
+}
+
+// W = T - t t^T - U^T diag(v) U with T = Kminv - Binv   (lib/fitc_gp.ml:1196-1203, :1040-1041),
+// written as a full symmetric matrix (upper tiles are the computed ones; the rest is mirrored).
+__global__ __launch_bounds__(256) void build_w_kernel(const double* __restrict__ kminv,
+                                                      const double* __restrict__ binv,
+                                                      const double* __restrict__ t,
+                                                      const double* __restrict__ G, int mp,
+                                                      double* __restrict__ W) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  const int r = blockIdx.y;
+  if (c >= mp) return;
+  int rr = r, cc = c;
+  if (r / TILE > c / TILE) {  // mirror from the computed upper tile
+    rr = c;
+    cc = r;
+  }
+  const int64_t off = (int64_t)rr * mp + cc;
+  W[(int64_t)r * mp + c] = kminv[off] - binv[off] - t[rr] * t[cc] - G[off];
+}
+
+void launch_build_w(const double* kminv, const double* binv, const double* t, const double* G, int mp,
+                    double* W, hipStream_t s) {
+  hipLaunchKernelGGL(build_w_kernel, dim3((mp + 255) / 256, mp), dim3(256), 0, s, kminv, binv, t, G, mp,
+                     W);
+  GPR_HIP(hipGetLastError());
+}
+
+// Per column c (thread) over a slab of rows r:
+//   part[slab][0][c]   = sum_r W_rc K_rc                      -> tr(W K_m)     (`Factor, Mat.symm2_trace)
+//   part[slab][1][c]   = sum_r W_rc K_rc |z_r - z_c|^2        -> Log_ell `Dense trace / inv_ell2
+//   part[slab][2+k][c] = sum_r W_rc K_rc (z_kr - z_kc)        -> `Sparse_rows trace / (2*scale)
+// W and K_m are full symmetric here, so the reference's upper-triangle bookkeeping
+// (lib/utils.ml:196-220: 2*sum_{r != c} + diagonal) becomes a plain column sum.
+template <int DT>
+__global__ __launch_bounds__(256) void km_traces_kernel(const double* __restrict__ W,
+                                                        const double* __restrict__ km,
+                                                        const double* __restrict__ Z, int m, int mp,
+                                                        int d, double* __restrict__ part) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= mp) return;
+  const bool live = c < m;
+  double z[DT], g[DT];
+#pragma unroll
+  for (int k = 0; k < DT; ++k) {
+    z[k] = (k < d && live) ? Z[(int64_t)c * d + k] : 0.0;
+    g[k] = 0.0;
+  }
+  double s0 = 0.0, s1 = 0.0;
+  const int r0 = blockIdx.y * 256, r1 = min(m, r0 + 256);
+  if (live) {
+    for (int r = r0; r < r1; ++r) {
+      // upper tiles of km are the valid ones; km is written full by cov_upper, W full by build_w
+      const double wk = W[(int64_t)r * mp + c] * km[(int64_t)r * mp + c];
+      const double* zr = Z + (int64_t)r * d;
+      double dist = 0.0;
+#pragma unroll
+      for (int k = 0; k < DT; ++k) {
+        if (k < d) {
+          const double df = zr[k] - z[k];
+          dist += df * df;
+          g[k] += wk * df;
+        }
+      }
+      s0 += wk;
+      s1 += wk * dist;
+    }
+  }
+  double* p = part + (int64_t)blockIdx.y * (d + 2) * mp;
+  p[c] = s0;
+  p[(int64_t)mp + c] = s1;
+#pragma unroll
+  for (int k = 0; k < DT; ++k)
+    if (k < d) p[(int64_t)(2 + k) * mp + c] = g[k];
+}
+
+void launch_km_traces(const double* W, const double* km, const double* Z, int m, int mp, int d,
+                      double* part, double* /*unused*/, hipStream_t s) {
+  dim3 grid((mp + 255) / 256, (m + 255) / 256);
+  auto go = [&](auto dt) {
+    hipLaunchKernelGGL((km_traces_kernel<decltype(dt)::value>), grid, dim3(256), 0, s, W, km, Z, m, mp,
+                       d, part);
+  };
+  if (d <= 4) go(std::integral_constant<int, 4>{});
+  else if (d <= 8) go(std::integral_constant<int, 8>{});
+  else if (d <= 16) go(std::integral_constant<int, 16>{});
+  else if (d <= 32) go(std::integral_constant<int, 32>{});
+  else go(std::integral_constant<int, 64>{});
+  GPR_HIP(hipGetLastError());
+}
+
+}  // namespace gprhip

@@ -1,0 +1,800 @@
+// C ABI + orchestration of the two-pass streaming FITC evaluation (see include/gprhip.h).
+//
+// Pass 1 (per row chunk):  K = cov(X, Z);  V = K U^-1;  r, s, 1/s;  B_part += K^T diag(1/s) K;
+//                          c += K^T (y/s);  [gradient] A1 = V U^-T (= K K_m^-1), kept in HBM.
+// Exchange 1            :  sum over shards of (B_part, c, sum log s, sum y^2/s, sum r/s).
+// Middle (m x m)        :  R = chol(K_m + jitter + B_part);  t = B^-1 c;  R^-1;  K_m^-1, B^-1.
+// Pass 2 (per row chunk):  Q' = K R^-1;  q_diag, w, v;  S' = Q' R^-T (= K B^-1);
+//                          G_part += A1^T diag(v) A1;  fused gradient accumulators over E = X .* K.
+// Exchange 2            :  sum over shards of (G_part, gradient column accumulators, scalars).
+// Finish                :  W = K_m^-1 - B^-1 - t t^T - G;  traces;  l1, l2, dl/dsigma2, dl/dtheta.
+#include <cmath>
+#include <cstring>
+#include <vector>
+#include <string>
+#include "../../include/gprhip.h"
+#include "common.h"
+#include "kernels.h"
+#include "mfma_gemm.h"
+
+namespace gprhip {
+const std::string& last_error();
+
+__global__ __launch_bounds__(256) void dot_kernel(const double* __restrict__ x,
+                                                  const double* __restrict__ y, int n,
+                                                  double* __restrict__ out) {
+  __shared__ double red[256];
+  double s = 0.0;
+  for (int i = threadIdx.x; i < n; i += 256) s += x[i] * y[i];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[0] = red[0];
+}
+
+__global__ void add_upper_kernel(const double* __restrict__ a, const double* __restrict__ b, int mp,
+                                 double* __restrict__ dst) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  const int r = blockIdx.y;
+  if (c >= mp) return;
+  const int64_t off = (int64_t)r * mp + c;
+  dst[off] = (r / TILE <= c / TILE) ? a[off] + b[off] : 0.0;
+}
+
+}  // namespace gprhip
+
+using namespace gprhip;
+
+namespace {
+
+constexpr double LOG_2PI = 1.8378770664093454835606594728112;  // lib/utils.ml:39-40
+constexpr int NSCAL = 16;
+enum {  // device scalar slots
+  SC_LOGDET_KM = 0,
+  SC_LOGDET_B = 1,
+  SC_UTU = 2,
+};
+// tail of the exchange-1 buffer
+enum { A1_SUMLOGS = 0, A1_ISY2 = 1, A1_ISR = 2, A1_TAIL = 4 };
+// tail of the exchange-2 buffer
+enum { A2_SUMV = 0, A2_SUMIS = 1, A2_ISRES2 = 2, A2_SUMV1 = 3, A2_SUME = 4, A2_SUMED = 5, A2_TAIL = 8 };
+
+struct Timer {
+  std::vector<std::pair<std::string, std::pair<hipEvent_t, hipEvent_t>>> ev;
+  bool on = false;
+};
+
+}  // namespace
+
+struct gprhip_problem {
+  int device = 0, kind = 0;
+  int64_t n = 0;
+  int D = 0, d = 0, m = 0, mp = 0;
+  int64_t chunk = 0;
+  int nchunks = 0;
+  int kslices = 8;
+  hipStream_t stream = nullptr;
+  std::vector<void*> allocs;
+
+  double *X = nullptr, *y = nullptr, *P = nullptr;
+  double *Z = nullptr, *tproj = nullptr;
+  double *km = nullptr, *kj = nullptr, *umat = nullptr, *uinv = nullptr, *kminv = nullptr;
+  double *bmat = nullptr, *rinv = nullptr, *binv = nullptr, *wmat = nullptr, *tmp = nullptr,
+         *dinv = nullptr;
+  double *cvec = nullptr, *bvec = nullptr, *tvec = nullptr, *utvec = nullptr, *scal = nullptr;
+  int* info = nullptr;
+  double *r = nullptr, *is = nullptr, *yis = nullptr, *w = nullptr, *v = nullptr;
+  double *Kc = nullptr, *Vc = nullptr, *Sc = nullptr, *A1 = nullptr;
+  double* slices = nullptr;
+  double *rowpart = nullptr, *gemvpart = nullptr, *colpart = nullptr, *scalpart = nullptr,
+         *kmpart = nullptr, *kmred = nullptr;
+  double *ar1 = nullptr, *ar2 = nullptr;  // internal exchange buffers for single-device eval
+
+  // state of the evaluation in flight
+  gprhip_hypers h{};
+  CovParams cp{};
+  int want_grad = 0;
+  int64_t n_total = 0;
+  int stage = 0;  // 0 idle, 1 pass1 done, 2 pass2 done
+  bool have_inputs = false, have_targets = false, kc_valid = false;
+  std::vector<double> hZ;  // host copy of inducing (padded point-major) for the gradient assembly
+  std::vector<double> hTproj;
+  Timer timer;
+  std::vector<std::string> tnames;
+  std::vector<float> tms;
+
+  template <typename T>
+  T* alloc(int64_t count) {
+    void* ptr = nullptr;
+    GPR_HIP(hipMalloc(&ptr, (size_t)std::max<int64_t>(count, 1) * sizeof(T)));
+    allocs.push_back(ptr);
+    return static_cast<T*>(ptr);
+  }
+  const double* pts() const { return kind == GPRHIP_COV_SE_FAT && h.tproj ? P : X; }
+  int64_t rows_of(int c) const { return std::min<int64_t>(chunk, n - (int64_t)c * chunk); }
+};
+
+namespace {
+
+void tstart(gprhip_problem* p, const char* name) {
+  if (!p->timer.on) return;
+  hipEvent_t a, b;
+  GPR_HIP(hipEventCreate(&a));
+  GPR_HIP(hipEventCreate(&b));
+  GPR_HIP(hipEventRecord(a, p->stream));
+  p->timer.ev.push_back({name, {a, b}});
+}
+void tstop(gprhip_problem* p) {
+  if (!p->timer.on) return;
+  GPR_HIP(hipEventRecord(p->timer.ev.back().second.second, p->stream));
+}
+void tcollect(gprhip_problem* p) {
+  p->tnames.clear();
+  p->tms.clear();
+  for (auto& e : p->timer.ev) {
+    float ms = 0;
+    hipEventElapsedTime(&ms, e.second.first, e.second.second);
+    bool found = false;
+    for (size_t i = 0; i < p->tnames.size(); ++i)
+      if (p->tnames[i] == e.first) {
+        p->tms[i] += ms;
+        found = true;
+      }
+    if (!found) {
+      p->tnames.push_back(e.first);
+      p->tms.push_back(ms);
+    }
+    hipEventDestroy(e.second.first);
+    hipEventDestroy(e.second.second);
+  }
+  p->timer.ev.clear();
+}
+
+// Blocked upper Cholesky A = U^T U in place (dpotrf `U; lib/fitc_gp.ml:56) -- diagonal blocks in
+// LDS, panel solve and trailing update on the MFMA engine.  dinv receives inv(U_jj) per block.
+void potrf_upper(gprhip_problem* p, double* A, int* info) {
+  const int mp = p->mp, nb = mp / TILE;
+  hipStream_t s = p->stream;
+  for (int j = 0; j < nb; ++j) {
+    double* dj = p->dinv + (int64_t)j * TILE * TILE;
+    launch_potrf_diag(A, mp, j, dj, info, s);
+    if (j + 1 < nb) {
+      const int rest = (nb - 1 - j) * TILE;
+      double* panel = A + (int64_t)j * TILE * mp + (int64_t)(j + 1) * TILE;
+      GemmArgs g;  // panel <- inv(U_jj)^T * panel   (in place: a block reads its whole column tile first)
+      g.A = dj; g.lda = TILE; g.B = panel; g.ldb = mp; g.C = panel; g.ldc = mp;
+      g.M = TILE; g.N = rest; g.K = TILE;
+      launch_gemm(OP_TN, g, s);
+      GemmArgs u;  // trailing <- trailing - panel^T panel  (upper tiles)
+      u.A = panel; u.lda = mp; u.B = panel; u.ldb = mp;
+      u.C = A + (int64_t)(j + 1) * TILE * mp + (int64_t)(j + 1) * TILE; u.ldc = mp;
+      u.M = rest; u.N = rest; u.K = TILE; u.alpha = -1.0; u.beta = 1.0; u.upper_only = 1;
+      launch_gemm(OP_TN, u, s);
+    }
+  }
+}
+
+// inv(U) for the upper-triangular factor, column block by column block:
+//   X[0:j, j] = -X[0:j, 0:j] * U[0:j, j] * inv(U_jj)
+void trtri_upper(gprhip_problem* p, const double* U, double* X) {
+  const int mp = p->mp, nb = mp / TILE;
+  hipStream_t s = p->stream;
+  GPR_HIP(hipMemsetAsync(X, 0, (size_t)mp * mp * sizeof(double), s));
+  for (int j = 0; j < nb; ++j) {
+    const double* dj = p->dinv + (int64_t)j * TILE * TILE;
+    launch_copy_block(dj, TILE, X + (int64_t)j * TILE * mp + (int64_t)j * TILE, mp, TILE, TILE, s);
+    if (j > 0) {
+      GemmArgs g;
+      g.A = X; g.lda = mp; g.B = U + (int64_t)j * TILE; g.ldb = mp; g.C = p->tmp; g.ldc = TILE;
+      g.M = j * TILE; g.N = TILE; g.K = j * TILE; g.tri = TRI_KLO_BM;
+      launch_gemm(OP_NN, g, s);
+      GemmArgs h;
+      h.A = p->tmp; h.lda = TILE; h.B = dj; h.ldb = TILE; h.C = X + (int64_t)j * TILE; h.ldc = mp;
+      h.M = j * TILE; h.N = TILE; h.K = TILE; h.alpha = -1.0;
+      launch_gemm(OP_NN, h, s);
+    }
+  }
+}
+
+// C (upper tiles) = X X^T for upper-triangular X: (U^T U)^-1 = U^-1 U^-T   (Utils.ichol, lib/utils.ml:110-113)
+void triu_xxt(gprhip_problem* p, const double* X, double* C) {
+  GemmArgs g;
+  g.A = X; g.lda = p->mp; g.B = X; g.ldb = p->mp; g.C = C; g.ldc = p->mp;
+  g.M = p->mp; g.N = p->mp; g.K = p->mp; g.tri = TRI_KLO_MAX; g.upper_only = 1;
+  launch_gemm(OP_NT, g, p->stream);
+}
+
+void upload_hypers(gprhip_problem* p, const gprhip_hypers* h) {
+  if (!h || !h->inducing) {
+    set_error("gprhip: hypers/inducing pointer is NULL");
+    throw HipFail{ST_BAD_ARG};
+  }
+  if (h->sigma2 < 0.0) {
+    set_error("Model.check_sigma2: sigma2 < 0");  // lib/fitc_gp.ml:148-149
+    throw HipFail{ST_BAD_ARG};
+  }
+  if (p->kind == GPRHIP_COV_SE_ISO && h->tproj) {
+    set_error("gprhip: tproj given for Cov_se_iso");
+    throw HipFail{ST_BAD_ARG};
+  }
+  if (p->kind == GPRHIP_COV_SE_FAT && !h->tproj && p->D != p->d) {
+    set_error("gprhip: Cov_se_fat without tproj needs D == d");
+    throw HipFail{ST_BAD_ARG};
+  }
+  p->h = *h;
+  p->h.inducing = nullptr;  // borrowed; the padded copy lives in hZ
+  CovParams& cp = p->cp;
+  cp.kind = p->kind;
+  cp.log_sf2 = h->log_sf2;
+  cp.sf2 = std::exp(h->log_sf2);
+  if (p->kind == GPRHIP_COV_SE_ISO) {
+    cp.inv_ell2 = std::exp(-2.0 * h->log_ell);  // lib/cov_se_iso.ml:41-44
+    cp.inv_ell2_05 = -0.5 * cp.inv_ell2;
+  } else {
+    cp.inv_ell2 = 1.0;
+    cp.inv_ell2_05 = -0.5;
+  }
+  // inducing: Fortran d x m == point-major [m][d]; pad to mp rows with zeros
+  p->hZ.assign((size_t)p->mp * p->d, 0.0);
+  std::memcpy(p->hZ.data(), h->inducing, (size_t)p->m * p->d * sizeof(double));
+  GPR_HIP(hipMemcpyAsync(p->Z, p->hZ.data(), p->hZ.size() * sizeof(double), hipMemcpyHostToDevice,
+                         p->stream));
+  if (h->tproj) {
+    p->hTproj.assign(h->tproj, h->tproj + (size_t)p->D * p->d);  // borrowed pointer: copy before returning
+    p->h.tproj = p->hTproj.data();
+    GPR_HIP(hipMemcpyAsync(p->tproj, p->hTproj.data(), (size_t)p->D * p->d * sizeof(double),
+                           hipMemcpyHostToDevice, p->stream));
+    launch_project(p->X, p->n, p->D, p->d, p->tproj, p->P, p->stream);
+  }
+}
+
+void cov_chunk(gprhip_problem* p, int c) {
+  const int64_t rows = p->rows_of(c);
+  const int64_t rows_p = round_up(rows, TILE);
+  const double* pts = p->pts() + (int64_t)c * p->chunk * p->d;
+  launch_cov_cross(p->cp, pts, (int)rows, (int)rows_p, p->Z, p->m, p->mp, p->d, p->Kc, p->stream);
+}
+
+void do_pass1(gprhip_problem* p, const gprhip_hypers* h, int want_grad, int64_t n_total, double* ar1) {
+  if (!p->have_inputs || (!p->have_targets && !h->model_only)) {
+    set_error("gprhip: inputs/targets not set");
+    throw HipFail{ST_STATE};
+  }
+  GPR_HIP(hipSetDevice(p->device));
+  hipStream_t s = p->stream;
+  upload_hypers(p, h);
+  p->want_grad = want_grad;
+  p->n_total = n_total;
+  const int mp = p->mp;
+  const int64_t mm = (int64_t)mp * mp;
+  double* ar1_c = ar1 + mm;
+  double* ar1_tail = ar1_c + mp;
+
+  tstart(p, "km_chol");
+  GPR_HIP(hipMemsetAsync(p->info, 0, 2 * sizeof(int), s));
+  GPR_HIP(hipMemsetAsync(p->scal, 0, NSCAL * sizeof(double), s));
+  GPR_HIP(hipMemsetAsync(ar1_c, 0, (size_t)(mp + A1_TAIL) * sizeof(double), s));
+  GPR_HIP(hipMemsetAsync(p->slices, 0, (size_t)p->kslices * mm * sizeof(double), s));
+  launch_cov_upper(p->cp, p->Z, p->m, mp, p->d, h->jitter, p->km, p->kj, s);
+  GPR_HIP(hipMemcpyAsync(p->umat, p->kj, (size_t)mm * sizeof(double), hipMemcpyDeviceToDevice, s));
+  potrf_upper(p, p->umat, p->info);
+  launch_logdet(p->umat, mp, p->m, p->scal + SC_LOGDET_KM, s);
+  trtri_upper(p, p->umat, p->uinv);
+  tstop(p);
+
+  for (int c = 0; c < p->nchunks; ++c) {
+    const int64_t rows = p->rows_of(c);
+    const int rows_p = (int)round_up(rows, TILE);
+    const int64_t base = (int64_t)c * p->chunk;
+    tstart(p, "p1_cov");
+    cov_chunk(p, c);
+    tstop(p);
+    tstart(p, "p1_trmm_V");
+    GemmArgs g;  // V = K U^-1   (dtrsm `R, lib/fitc_gp.ml:226-227)
+    g.A = p->Kc; g.lda = mp; g.B = p->uinv; g.ldb = mp; g.C = p->Vc; g.ldc = mp;
+    g.M = rows_p; g.N = mp; g.K = mp; g.tri = TRI_KHI_BN;
+    launch_gemm(OP_NN, g, s);
+    tstop(p);
+    tstart(p, "p1_rows");
+    Pass1RowArgs ra;
+    ra.V = p->Vc; ra.y = h->model_only ? nullptr : p->y + base; ra.rows = (int)rows; ra.mp = mp;
+    ra.sf2 = p->cp.sf2; ra.sigma2 = h->sigma2;
+    ra.r = p->r + base; ra.is = p->is + base; ra.yis = p->yis + base; ra.partial = p->rowpart;
+    launch_pass1_rows(ra, s);
+    launch_reduce_rows(p->rowpart, pass1_row_blocks(rows_p), 4, ar1_tail, 1, s);
+    tstop(p);
+    tstart(p, "p1_syrk_B");
+    GemmArgs b;  // B_part += K^T diag(is) K   (replaces the stacked QR's R^T R, lib/fitc_gp.ml:170-182)
+    b.A = p->Kc; b.lda = mp; b.B = p->Kc; b.ldb = mp; b.C = p->slices; b.ldc = mp;
+    b.M = mp; b.N = mp; b.K = rows_p; b.beta = 1.0; b.scale_k = p->is + base; b.upper_only = 1;
+    b.kslices = p->kslices; b.slice_stride = mm;
+    launch_gemm(OP_TN, b, s);
+    tstop(p);
+    tstart(p, "p1_gemv_c");
+    launch_gemv_t_partial(p->Kc, rows_p, mp, p->yis + base, p->gemvpart, s);
+    launch_reduce_rows(p->gemvpart, (rows_p + 255) / 256, mp, ar1_c, 1, s);
+    tstop(p);
+    if (want_grad) {
+      if (!p->A1)  // K K_m^-1 for all rows of the shard stays resident between the passes
+        p->A1 = p->alloc<double>((int64_t)p->nchunks * p->chunk * mp);
+      tstart(p, "p1_trmm_A1");
+      GemmArgs a;  // A1 = V U^-T = K K_m^-1   (U_mat, lib/fitc_gp.ml:932-933)
+      a.A = p->Vc; a.lda = mp; a.B = p->uinv; a.ldb = mp; a.C = p->A1 + base * mp; a.ldc = mp;
+      a.M = rows_p; a.N = mp; a.K = mp; a.tri = TRI_KLO_BN;
+      launch_gemm(OP_NT, a, s);
+      tstop(p);
+    }
+  }
+  p->kc_valid = (p->nchunks == 1);
+  launch_sum_slices(nullptr, p->slices, p->kslices, mm, mp, ar1, s);
+  p->stage = 1;
+}
+
+void do_pass2(gprhip_problem* p, const double* ar1, double* ar2) {
+  if (p->stage != 1) {
+    set_error("gprhip: eval_pass2 called before eval_pass1");
+    throw HipFail{ST_STATE};
+  }
+  GPR_HIP(hipSetDevice(p->device));
+  hipStream_t s = p->stream;
+  const int mp = p->mp;
+  const int64_t mm = (int64_t)mp * mp;
+  const double* ar1_c = ar1 + mm;
+  double* ar2_col = ar2 + mm;
+  double* ar2_tail = ar2_col + (int64_t)(p->d + 1) * mp;
+  const bool mo = p->h.model_only != 0;
+
+  tstart(p, "b_chol");
+  hipLaunchKernelGGL(add_upper_kernel, dim3((mp + 255) / 256, mp), dim3(256), 0, s, p->kj, ar1, mp,
+                     p->bmat);
+  potrf_upper(p, p->bmat, p->info + 1);
+  launch_logdet(p->bmat, mp, p->m, p->scal + SC_LOGDET_B, s);
+  trtri_upper(p, p->bmat, p->rinv);
+  // b = R^-T c  (= Q_n^T y~, lib/fitc_gp.ml:285-286);  t = R^-1 b  (trsv, :291 / :1167)
+  launch_triu_matvec(p->rinv, mp, ar1_c, p->bvec, 1, s);
+  launch_triu_matvec(p->rinv, mp, p->bvec, p->tvec, 0, s);
+  launch_triu_matvec(p->umat, mp, p->tvec, p->utvec, 0, s);
+  hipLaunchKernelGGL(dot_kernel, dim3(1), dim3(256), 0, s, p->utvec, p->utvec, mp, p->scal + SC_UTU);
+  tstop(p);
+
+  GPR_HIP(hipMemsetAsync(ar2_col, 0, (size_t)((p->d + 1) * (int64_t)mp + A2_TAIL) * sizeof(double), s));
+  if (p->want_grad) {
+    tstart(p, "inverses");
+    triu_xxt(p, p->uinv, p->kminv);
+    triu_xxt(p, p->rinv, p->binv);
+    GPR_HIP(hipMemsetAsync(p->slices, 0, (size_t)p->kslices * mm * sizeof(double), s));
+    tstop(p);
+  }
+  for (int c = 0; c < p->nchunks; ++c) {
+    const int64_t rows = p->rows_of(c);
+    const int rows_p = (int)round_up(rows, TILE);
+    const int64_t base = (int64_t)c * p->chunk;
+    if (!p->kc_valid) {
+      tstart(p, "p2_cov");
+      cov_chunk(p, c);
+      tstop(p);
+    }
+    Pass2RowArgs ra;
+    ra.y = mo ? nullptr : p->y + base; ra.is = p->is + base; ra.r = p->r + base;
+    ra.rows = (int)rows; ra.mp = mp; ra.variational = p->h.variational;
+    ra.w = p->w + base; ra.v = p->v + base; ra.partial = p->rowpart;
+    if (!p->want_grad) {
+      // evidence only: the residual form of l2 needs K t per row; reuse the row kernel with Q := K, b := t
+      tstart(p, "p2_rows");
+      ra.Q = p->Kc; ra.b = p->tvec;
+      launch_pass2_rows(ra, s);
+      launch_reduce_rows(p->rowpart, pass1_row_blocks(rows_p), 4, ar2_tail, 1, s);
+      tstop(p);
+      continue;
+    }
+    tstart(p, "p2_trmm_Q");
+    GemmArgs q;  // Q' = K R^-1  (Q_n = diag(sqrt is) Q', lib/fitc_gp.ml:176-182)
+    q.A = p->Kc; q.lda = mp; q.B = p->rinv; q.ldb = mp; q.C = p->Vc; q.ldc = mp;
+    q.M = rows_p; q.N = mp; q.K = mp; q.tri = TRI_KHI_BN;
+    launch_gemm(OP_NN, q, s);
+    tstop(p);
+    tstart(p, "p2_rows");
+    ra.Q = p->Vc; ra.b = p->bvec;
+    launch_pass2_rows(ra, s);
+    launch_reduce_rows(p->rowpart, pass1_row_blocks(rows_p), 4, ar2_tail, 1, s);
+    tstop(p);
+    tstart(p, "p2_trmm_S");
+    GemmArgs sg;  // S' = Q' R^-T = K B^-1   (S = diag(is) S', lib/fitc_gp.ml:936-938)
+    sg.A = p->Vc; sg.lda = mp; sg.B = p->rinv; sg.ldb = mp; sg.C = p->Sc; sg.ldc = mp;
+    sg.M = rows_p; sg.N = mp; sg.K = mp; sg.tri = TRI_KLO_BN;
+    launch_gemm(OP_NT, sg, s);
+    tstop(p);
+    tstart(p, "p2_syrk_W");
+    const double* a1 = p->A1 + base * mp;
+    GemmArgs wg;  // G_part += A1^T diag(v) A1   (the two dsyrk of lib/fitc_gp.ml:1198-1203 in one)
+    wg.A = a1; wg.lda = mp; wg.B = a1; wg.ldb = mp; wg.C = p->slices; wg.ldc = mp;
+    wg.M = mp; wg.N = mp; wg.K = rows_p; wg.beta = 1.0; wg.scale_k = p->v + base; wg.upper_only = 1;
+    wg.kslices = p->kslices; wg.slice_stride = mm;
+    launch_gemm(OP_TN, wg, s);
+    tstop(p);
+    tstart(p, "p2_grad");
+    GradArgs ga;
+    ga.K = p->Kc; ga.S = p->Sc; ga.A1 = a1; ga.pts = p->pts() + base * p->d; ga.Z = p->Z;
+    ga.is = p->is + base; ga.v = p->v + base; ga.w = p->w + base; ga.t = p->tvec;
+    ga.rows = (int)rows; ga.rows_p = rows_p; ga.m = p->m; ga.mp = mp; ga.d = p->d;
+    ga.inv_ell2_05 = p->cp.inv_ell2_05; ga.colpart = p->colpart; ga.scalpart = p->scalpart;
+    ga.rowE = nullptr;
+    launch_grad_fused(ga, s);
+    const int nslabs = (int)((rows + grad_slab_rows() - 1) / grad_slab_rows());
+    launch_reduce_rows(p->colpart, nslabs, (p->d + 1) * mp, ar2_col, 1, s);
+    launch_reduce_rows(p->scalpart, nslabs * ((mp + 255) / 256), 2, ar2_tail + A2_SUME, 1, s);
+    tstop(p);
+  }
+  if (p->want_grad)
+    launch_sum_slices(nullptr, p->slices, p->kslices, mm, mp, ar2, s);
+  p->stage = 2;
+}
+
+void do_finish(gprhip_problem* p, const double* ar2, gprhip_result* res, double* grad, double* coeffs) {
+  if (p->stage != 2) {
+    set_error("gprhip: eval_finish called before eval_pass2");
+    throw HipFail{ST_STATE};
+  }
+  GPR_HIP(hipSetDevice(p->device));
+  hipStream_t s = p->stream;
+  const int mp = p->mp, m = p->m, d = p->d;
+  const int64_t mm = (int64_t)mp * mp;
+  const double* ar2_col = ar2 + mm;
+  const double* ar2_tail = ar2_col + (int64_t)(d + 1) * mp;
+  const int nkslab = (m + 255) / 256;
+  if (p->want_grad) {
+    tstart(p, "finish");
+    launch_build_w(p->kminv, p->binv, p->tvec, ar2, mp, p->wmat, s);
+    launch_km_traces(p->wmat, p->km, p->Z, m, mp, d, p->kmpart, nullptr, s);
+    launch_reduce_rows(p->kmpart, nkslab, (d + 2) * mp, p->kmred, 0, s);
+    tstop(p);
+  }
+  std::vector<double> hscal(NSCAL), htail(A2_TAIL), ha1tail(A1_TAIL), ht(mp);
+  std::vector<double> hcol, hkm;
+  int hinfo[2] = {0, 0};
+  GPR_HIP(hipMemcpyAsync(hscal.data(), p->scal, NSCAL * sizeof(double), hipMemcpyDeviceToHost, s));
+  GPR_HIP(hipMemcpyAsync(htail.data(), ar2_tail, A2_TAIL * sizeof(double), hipMemcpyDeviceToHost, s));
+  GPR_HIP(hipMemcpyAsync(ht.data(), p->tvec, mp * sizeof(double), hipMemcpyDeviceToHost, s));
+  GPR_HIP(hipMemcpyAsync(hinfo, p->info, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
+  if (p->want_grad) {
+    hcol.resize((size_t)(d + 1) * mp);
+    hkm.resize((size_t)(d + 2) * mp);
+    GPR_HIP(hipMemcpyAsync(hcol.data(), ar2_col, hcol.size() * sizeof(double), hipMemcpyDeviceToHost, s));
+    GPR_HIP(hipMemcpyAsync(hkm.data(), p->kmred, hkm.size() * sizeof(double), hipMemcpyDeviceToHost, s));
+  }
+  // the exchange-1 tail lives in the caller's (or our) ar1 buffer; it was copied into scal? no:
+  // pass 2 does not need it, so fetch it from the saved pointer
+  GPR_HIP(hipMemcpyAsync(ha1tail.data(), p->ar1 + mm + mp, A1_TAIL * sizeof(double),
+                         hipMemcpyDeviceToHost, s));
+  GPR_HIP(hipStreamSynchronize(s));
+  p->stage = 0;
+  if (p->timer.on) tcollect(p);
+  if (hinfo[0] != 0 || hinfo[1] != 0) {
+    char buf[160];
+    snprintf(buf, sizeof buf,
+             "Lacaml.D.potrf: leading minor of order %d of %s is not positive definite",
+             hinfo[0] ? hinfo[0] : hinfo[1], hinfo[0] ? "K_m + jitter" : "B = K_m + K_mn S^-1 K_nm");
+    set_error(buf);
+    throw HipFail{ST_NOT_POSDEF};
+  }
+  const bool mo = p->h.model_only != 0;
+  const double sum_log_s = ha1tail[A1_SUMLOGS], sum_isr = ha1tail[A1_ISR];
+  // l1: lib/fitc_gp.ml:204-208 ; variational: :262-263
+  double l1 = -0.5 * (hscal[SC_LOGDET_B] - hscal[SC_LOGDET_KM] + sum_log_s + (double)p->n_total * LOG_2PI);
+  if (p->h.variational) l1 += -0.5 * sum_isr;
+  // l2 = -1/2 |y~ - Q Q^T y~|^2 in residual form: |sqrt(is)(y - K t)|^2 + |U t|^2  (DESIGN.md "l2")
+  double l2 = mo ? 0.0 : -0.5 * (htail[A2_ISRES2] + hscal[SC_UTU]);
+  res->l1 = l1;
+  res->l2 = l2;
+  res->l = l1 + l2;
+  res->dl_dsigma2 = 0.0;
+  res->n_hypers = 0;
+  if (coeffs) std::memcpy(coeffs, ht.data(), (size_t)m * sizeof(double));
+  if (!p->want_grad) return;
+  // dl/dsigma2: lib/fitc_gp.ml:1112-1119, :1187-1188
+  double sumv = htail[A2_SUMV];
+  res->dl_dsigma2 = -0.5 * (p->h.variational ? (sumv - htail[A2_SUMIS]) : sumv);
+  // per-hyper evidence derivative, lib/fitc_gp.ml:1005-1021:
+  //   dl = -1/2 (dkn_diag_term - dkm_term) - dknm_term
+  double tr_wk = 0.0, tr_wkd = 0.0;
+  for (int c = 0; c < m; ++c) {
+    tr_wk += hkm[c];
+    tr_wkd += hkm[(size_t)mp + c];
+  }
+  const double sumE = htail[A2_SUME], sumED = htail[A2_SUMED];
+  const double scale = p->cp.inv_ell2;
+  // Log_sf2: `Factor 1. on all three (lib/cov_se_iso.ml:248, :298, :302)
+  const double g_sf2 = -0.5 * (p->cp.sf2 * sumv - tr_wk) - sumE;
+  int64_t pos = 0;
+  if (p->kind == GPRHIP_COV_SE_ISO) {
+    // Log_ell: dkn_diag `Const 0.; dkm `Dense K.*D/ell^2 (diag 0); dknm `Dense (lib/cov_se_iso.ml:249-260, :303-314)
+    grad[pos++] = 0.5 * scale * tr_wkd - scale * sumED;
+    grad[pos++] = g_sf2;
+  } else {
+    grad[pos++] = g_sf2;
+  }
+  // Inducing_hyper {ind; dim}: dkm `Sparse_rows -> 2*scale*sum_{r!=c} W_rc K_rc (z_kr - z_kc)
+  // (lib/utils.ml:196-220); dknm `Sparse_cols -> scale*sum_r (x_kr - z_kc) E_rc
+  for (int c = 0; c < m; ++c) {
+    for (int k = 0; k < d; ++k) {
+      const double zk = p->hZ[(size_t)c * d + k];
+      const double dkm_half = scale * hkm[(size_t)(2 + k) * mp + c];
+      const double dknm = scale * (hcol[(size_t)(k + 1) * mp + c] - zk * hcol[c]);
+      grad[pos++] = dkm_half - dknm;
+    }
+  }
+  res->n_hypers = pos;
+}
+
+template <typename F>
+int guarded(F&& f) {
+  try {
+    f();
+    return GPRHIP_OK;
+  } catch (const HipFail& e) {
+    return e.status;
+  } catch (const std::bad_alloc&) {
+    set_error("gprhip: host allocation failed");
+    return GPRHIP_EOOM;
+  } catch (...) {
+    set_error("gprhip: unexpected C++ exception");
+    return GPRHIP_EHIP;
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* gprhip_last_error(void) { return last_error().c_str(); }
+const char* gprhip_version(void) { return "gprhip 0.1 (gfx950)"; }
+
+int gprhip_device_count(int* count) {
+  return guarded([&] {
+    int c = 0;
+    hipError_t e = hipGetDeviceCount(&c);
+    if (e != hipSuccess) c = 0;
+    *count = c;
+  });
+}
+
+int gprhip_problem_create(int device, int cov_kind, int64_t n, int D, int d, int m, int64_t chunk_rows,
+                          gprhip_problem** out) {
+  return guarded([&] {
+    if (!out || n < 1 || D < 1 || d < 1 || m < 1 ||
+        (cov_kind != GPRHIP_COV_SE_ISO && cov_kind != GPRHIP_COV_SE_FAT) ||
+        (cov_kind == GPRHIP_COV_SE_ISO && d != D) || d > 64) {
+      set_error("gprhip_problem_create: invalid arguments (need n,D,d,m >= 1, d <= 64, d == D for Cov_se_iso)");
+      throw HipFail{ST_BAD_ARG};
+    }
+    GPR_HIP(hipSetDevice(device));
+    gemm_init();
+    auto* p = new gprhip_problem();
+    *out = p;
+    p->device = device; p->kind = cov_kind; p->n = n; p->D = D; p->d = d; p->m = m;
+    p->mp = (int)round_up(m, TILE);
+    int64_t chunk = chunk_rows > 0 ? chunk_rows : 32768;
+    if (const char* e = getenv("GPRHIP_CHUNK_ROWS")) chunk = atoll(e);
+    chunk = round_up(std::min<int64_t>(chunk, round_up(n, TILE)), TILE);
+    p->chunk = chunk;
+    p->nchunks = (int)((n + chunk - 1) / chunk);
+    if (const char* e = getenv("GPRHIP_KSLICES")) p->kslices = std::max(1, atoi(e));
+    if (const char* e = getenv("GPRHIP_TIMING")) p->timer.on = atoi(e) != 0;
+    GPR_HIP(hipStreamCreate(&p->stream));
+    const int mp = p->mp;
+    const int64_t mm = (int64_t)mp * mp;
+    const int64_t npad = (int64_t)p->nchunks * chunk;
+    p->X = p->alloc<double>(n * D);
+    p->y = p->alloc<double>(npad);
+    if (cov_kind == GPRHIP_COV_SE_FAT) {
+      p->P = p->alloc<double>(n * d);
+      p->tproj = p->alloc<double>((int64_t)D * d);
+    }
+    p->Z = p->alloc<double>((int64_t)mp * d);
+    p->km = p->alloc<double>(mm); p->kj = p->alloc<double>(mm); p->umat = p->alloc<double>(mm);
+    p->uinv = p->alloc<double>(mm); p->kminv = p->alloc<double>(mm); p->bmat = p->alloc<double>(mm);
+    p->rinv = p->alloc<double>(mm); p->binv = p->alloc<double>(mm); p->wmat = p->alloc<double>(mm);
+    p->tmp = p->alloc<double>((int64_t)mp * TILE);
+    p->dinv = p->alloc<double>((int64_t)(mp / TILE) * TILE * TILE);
+    p->cvec = p->alloc<double>(mp); p->bvec = p->alloc<double>(mp); p->tvec = p->alloc<double>(mp);
+    p->utvec = p->alloc<double>(mp); p->scal = p->alloc<double>(NSCAL);
+    p->info = p->alloc<int>(2);
+    p->r = p->alloc<double>(npad); p->is = p->alloc<double>(npad); p->yis = p->alloc<double>(npad);
+    p->w = p->alloc<double>(npad); p->v = p->alloc<double>(npad);
+    p->Kc = p->alloc<double>(chunk * mp); p->Vc = p->alloc<double>(chunk * mp);
+    p->Sc = p->alloc<double>(chunk * mp);
+    p->slices = p->alloc<double>((int64_t)p->kslices * mm);
+    p->rowpart = p->alloc<double>((int64_t)pass1_row_blocks((int)chunk) * 4);
+    p->gemvpart = p->alloc<double>(((chunk + 255) / 256) * mp);
+    const int64_t nslab = (chunk + grad_slab_rows() - 1) / grad_slab_rows();
+    p->colpart = p->alloc<double>(nslab * (d + 1) * mp);
+    p->scalpart = p->alloc<double>(nslab * ((mp + 255) / 256) * 2);
+    p->kmpart = p->alloc<double>((int64_t)((m + 255) / 256) * (d + 2) * mp);
+    p->kmred = p->alloc<double>((int64_t)(d + 2) * mp);
+    p->ar1 = p->alloc<double>(mm + mp + A1_TAIL);
+    p->ar2 = p->alloc<double>(mm + (int64_t)(d + 1) * mp + A2_TAIL);
+    GPR_HIP(hipMemsetAsync(p->y, 0, (size_t)npad * sizeof(double), p->stream));
+    GPR_HIP(hipStreamSynchronize(p->stream));
+  });
+}
+
+void gprhip_problem_destroy(gprhip_problem* p) {
+  if (!p) return;
+  hipSetDevice(p->device);
+  if (p->stream) {
+    hipStreamSynchronize(p->stream);
+    hipStreamDestroy(p->stream);
+  }
+  for (void* a : p->allocs) hipFree(a);
+  delete p;
+}
+
+int gprhip_set_inputs(gprhip_problem* p, const double* inputs, int64_t ld) {
+  return guarded([&] {
+    if (!p || !inputs || ld < p->D) {
+      set_error("gprhip_set_inputs: invalid arguments");
+      throw HipFail{ST_BAD_ARG};
+    }
+    GPR_HIP(hipSetDevice(p->device));
+    GPR_HIP(hipMemcpy2DAsync(p->X, (size_t)p->D * sizeof(double), inputs, (size_t)ld * sizeof(double),
+                             (size_t)p->D * sizeof(double), (size_t)p->n, hipMemcpyHostToDevice,
+                             p->stream));
+    GPR_HIP(hipStreamSynchronize(p->stream));
+    p->have_inputs = true;
+  });
+}
+
+int gprhip_set_targets(gprhip_problem* p, const double* targets) {
+  return guarded([&] {
+    if (!p || !targets) {
+      set_error("gprhip_set_targets: invalid arguments");
+      throw HipFail{ST_BAD_ARG};
+    }
+    GPR_HIP(hipSetDevice(p->device));
+    GPR_HIP(hipMemcpyAsync(p->y, targets, (size_t)p->n * sizeof(double), hipMemcpyHostToDevice, p->stream));
+    GPR_HIP(hipStreamSynchronize(p->stream));
+    p->have_targets = true;
+  });
+}
+
+int gprhip_set_inputs_device(gprhip_problem* p, const double* d_inputs) {
+  return guarded([&] {
+    if (!p || !d_inputs) {
+      set_error("gprhip_set_inputs_device: invalid arguments");
+      throw HipFail{ST_BAD_ARG};
+    }
+    GPR_HIP(hipSetDevice(p->device));
+    GPR_HIP(hipMemcpyAsync(p->X, d_inputs, (size_t)p->n * p->D * sizeof(double), hipMemcpyDeviceToDevice,
+                           p->stream));
+    GPR_HIP(hipStreamSynchronize(p->stream));
+    p->have_inputs = true;
+  });
+}
+
+int gprhip_set_targets_device(gprhip_problem* p, const double* d_targets) {
+  return guarded([&] {
+    if (!p || !d_targets) {
+      set_error("gprhip_set_targets_device: invalid arguments");
+      throw HipFail{ST_BAD_ARG};
+    }
+    GPR_HIP(hipSetDevice(p->device));
+    GPR_HIP(hipMemcpyAsync(p->y, d_targets, (size_t)p->n * sizeof(double), hipMemcpyDeviceToDevice,
+                           p->stream));
+    GPR_HIP(hipStreamSynchronize(p->stream));
+    p->have_targets = true;
+  });
+}
+
+int64_t gprhip_n_hypers(const gprhip_problem* p, int has_tproj) {
+  if (!p) return 0;
+  if (p->kind == GPRHIP_COV_SE_ISO) return 2 + (int64_t)p->d * p->m;
+  return 1 + (int64_t)p->d * p->m + (has_tproj ? (int64_t)p->D * p->d : 0);
+}
+
+int64_t gprhip_ar1_len(const gprhip_problem* p) { return (int64_t)p->mp * p->mp + p->mp + A1_TAIL; }
+int64_t gprhip_ar2_len(const gprhip_problem* p) {
+  return (int64_t)p->mp * p->mp + (int64_t)(p->d + 1) * p->mp + A2_TAIL;
+}
+
+int gprhip_eval_pass1(gprhip_problem* p, const gprhip_hypers* h, int want_grad, int64_t n_total,
+                      double* d_ar1) {
+  return guarded([&] {
+    if (!p || !d_ar1) {
+      set_error("gprhip_eval_pass1: NULL argument");
+      throw HipFail{ST_BAD_ARG};
+    }
+    do_pass1(p, h, want_grad, n_total, d_ar1);
+  });
+}
+
+int gprhip_eval_pass2(gprhip_problem* p, const double* d_ar1, double* d_ar2) {
+  return guarded([&] {
+    if (!p || !d_ar1 || !d_ar2) {
+      set_error("gprhip_eval_pass2: NULL argument");
+      throw HipFail{ST_BAD_ARG};
+    }
+    // keep the reduced exchange-1 buffer where finish() reads its scalar tail
+    if (d_ar1 != p->ar1)
+      GPR_HIP(hipMemcpyAsync(p->ar1, d_ar1, (size_t)gprhip_ar1_len(p) * sizeof(double),
+                             hipMemcpyDeviceToDevice, p->stream));
+    do_pass2(p, p->ar1, d_ar2);
+  });
+}
+
+int gprhip_eval_finish(gprhip_problem* p, const double* d_ar2, gprhip_result* res, double* grad,
+                       double* coeffs) {
+  return guarded([&] {
+    if (!p || !d_ar2 || !res || (p->want_grad && !grad)) {
+      set_error("gprhip_eval_finish: NULL argument");
+      throw HipFail{ST_BAD_ARG};
+    }
+    do_finish(p, d_ar2, res, grad, coeffs);
+  });
+}
+
+int gprhip_eval(gprhip_problem* p, const gprhip_hypers* h, int want_grad, gprhip_result* res,
+                double* grad, double* coeffs) {
+  return guarded([&] {
+    if (!p || !res || (want_grad && !grad)) {
+      set_error("gprhip_eval: NULL argument");
+      throw HipFail{ST_BAD_ARG};
+    }
+    do_pass1(p, h, want_grad, p->n, p->ar1);
+    do_pass2(p, p->ar1, p->ar2);
+    do_finish(p, p->ar2, res, grad, coeffs);
+  });
+}
+
+int gprhip_sync(gprhip_problem* p) {
+  return guarded([&] {
+    GPR_HIP(hipSetDevice(p->device));
+    GPR_HIP(hipStreamSynchronize(p->stream));
+  });
+}
+
+void* gprhip_stream(gprhip_problem* p) { return p ? (void*)p->stream : nullptr; }
+
+int gprhip_debug_fetch(gprhip_problem* p, const char* name, double* out, int64_t len) {
+  return guarded([&] {
+    const double* src = nullptr;
+    int64_t avail = 0;
+    std::string nm = name ? name : "";
+    // per-row vectors are stored chunk by chunk with padding; only nchunks == 1 keeps them contiguous
+    if (nm == "r") { src = p->r; avail = p->n; }
+    else if (nm == "is") { src = p->is; avail = p->n; }
+    else if (nm == "v") { src = p->v; avail = p->n; }
+    else if (nm == "w") { src = p->w; avail = p->n; }
+    else if (nm == "t") { src = p->tvec; avail = p->m; }
+    else {
+      set_error("gprhip_debug_fetch: unknown name");
+      throw HipFail{ST_BAD_ARG};
+    }
+    if (len > avail) len = avail;
+    GPR_HIP(hipSetDevice(p->device));
+    GPR_HIP(hipStreamSynchronize(p->stream));
+    if (avail == p->m || p->nchunks == 1) {
+      GPR_HIP(hipMemcpy(out, src, (size_t)len * sizeof(double), hipMemcpyDeviceToHost));
+    } else {
+      for (int c = 0; c < p->nchunks; ++c) {
+        int64_t lo = (int64_t)c * p->chunk;
+        if (lo >= len) break;
+        int64_t cnt = std::min<int64_t>(p->rows_of(c), len - lo);
+        GPR_HIP(hipMemcpy(out + lo, src + lo, (size_t)cnt * sizeof(double), hipMemcpyDeviceToHost));
+      }
+    }
+  });
+}
+
+int gprhip_last_timings(gprhip_problem* p, const char** names, float* ms, int cap) {
+  int n = (int)std::min<size_t>(p->tnames.size(), (size_t)cap);
+  for (int i = 0; i < n; ++i) {
+    names[i] = p->tnames[i].c_str();
+    ms[i] = p->tms[i];
+  }
+  return n;
+}
+
+}  // extern "C"

@@ -1,0 +1,118 @@
+// Device-kernel launchers of the FITC path other than the MFMA engine.
+// Layout conventions (all fp64, device memory):
+//   points   : "point-major" [n][dim]   (== the reference's Fortran dim x n Bigarray, lib/interfaces.ml:190-195)
+//   inducing : [mp][d], rows >= m are padding
+//   n x m matrices (K_nm and everything derived from it): row-major [rows_padded][mp],
+//              one training point per row ("K_mn column-major" in BASELINE.json's words)
+//   m x m matrices: row-major [mp][mp]; symmetric ones are valid in the upper triangle
+//              (tile-granular: every 128x128 tile with row tile <= column tile is fully written)
+#pragma once
+#include "common.h"
+
+namespace gprhip {
+
+struct CovParams {
+  int kind;             // 0 = Cov_se_iso, 1 = Cov_se_fat (projection-only sub-case)
+  double log_sf2, sf2;  // lib/cov_se_iso.ml:41-44 / lib/cov_se_fat.ml:62-75
+  double inv_ell2;      // iso: exp(-2 log_ell); fat: 1
+  double inv_ell2_05;   // iso: -0.5*inv_ell2;   fat: -0.5
+};
+
+// K_m (lib/cov_se_iso.ml:56-87, lib/cov_se_fat.ml:85-100): km = covariance (padding rows/cols 0),
+// kj = km + jitter*I on the real diagonal and exactly 1 on the padded diagonal.
+void launch_cov_upper(const CovParams& cp, const double* Z, int m, int mp, int d, double jitter,
+                      double* km, double* kj, hipStream_t s);
+
+// K_nm rows [0, rows) of a chunk (lib/cov_se_iso.ml:128-159, lib/cov_se_fat.ml:224-240);
+// rows in [rows, rows_p) and columns in [m, mp) are written as 0.
+void launch_cov_cross(const CovParams& cp, const double* pts, int rows, int rows_p, const double* Z,
+                      int m, int mp, int d, double* K, hipStream_t s);
+
+// Cov_se_fat.Eval.Inputs.project (lib/cov_se_fat.ml:215-218): P[n][d] = X[n][D] * tproj[D][d]
+// (tproj given as the reference's Fortran D x d matrix, i.e. element (big,small) at tproj[small*D+big]).
+void launch_project(const double* X, int64_t n, int D, int d, const double* tproj, double* P,
+                    hipStream_t s);
+
+// ---- blocked Cholesky / triangular inverse pieces (chol.hip)
+// Factor the 128x128 diagonal block j of the row-major mp x mp matrix A in place (upper, A = U^T U),
+// zero its strict lower part, and write inv(U_jj) (upper, lower zero) to dinv (128x128 row-major).
+// On a non-positive pivot, *info (if still 0) is set to the 1-based global index.
+void launch_potrf_diag(double* A, int mp, int j, double* dinv, int* info, hipStream_t s);
+void launch_zero_strict_lower(double* A, int mp, hipStream_t s);
+void launch_copy_block(const double* src, int64_t lds, double* dst, int64_t ldd, int rows, int cols,
+                       hipStream_t s);
+// out[0] = 2 * sum_{i<m} log A[i][i]   (lib/utils.ml:95-101)
+void launch_logdet(const double* A, int mp, int m, double* out, hipStream_t s);
+
+// ---- small dense vector ops on m-vectors (single block)
+// y = op(A) x for an upper-triangular row-major mp x mp A; trans=0: y_i = sum_{k>=i} A[i][k] x_k,
+// trans=1: y_i = sum_{k<=i} A[k][i] x_k.
+void launch_triu_matvec(const double* A, int mp, const double* x, double* y, int trans, hipStream_t s);
+
+// ---- row kernels (rowops.hip)
+struct Pass1RowArgs {
+  const double* V;       // [rows_p][mp]
+  const double* y;       // [rows] targets of this chunk (may be null: model-only)
+  int rows, mp;
+  double sf2, sigma2;
+  double* r;             // out [rows]
+  double* is;            // out [rows_p] (padding rows get 0)
+  double* yis;           // out [rows_p]  is*y (padding 0)
+  double* partial;       // out [nblocks][4]: sum log s, sum is*y^2, sum is*r, unused
+};
+int pass1_row_blocks(int rows);
+void launch_pass1_rows(const Pass1RowArgs& a, hipStream_t s);
+
+struct Pass2RowArgs {
+  const double* Q;       // [rows_p][mp]  K_chunk * Rinv
+  const double* b;       // [mp]          Rinv^T c  (= Q_n^T y~ of the reference)
+  const double* y;       // [rows] or null
+  const double* is;      // [rows_p]
+  const double* r;       // [rows]
+  int rows, mp, variational;
+  double* w;             // out [rows_p]  (padding 0)
+  double* v;             // out [rows_p]  (padding 0)
+  double* partial;       // out [nblocks][4]: sum v, sum is, sum w*(y-Kt) (= sum is*res^2), sum v1
+};
+void launch_pass2_rows(const Pass2RowArgs& a, hipStream_t s);
+
+// partial[slab][col] = sum_{rows of slab} K[row][col] * x[row]; slab = 256 rows
+void launch_gemv_t_partial(const double* K, int rows_p, int mp, const double* x, double* partial,
+                           hipStream_t s);
+// out[col] (+)= sum_slab partial[slab][col]
+void launch_reduce_rows(const double* partial, int nslabs, int width, double* out, int accumulate,
+                        hipStream_t s);
+
+struct GradArgs {
+  const double* K;       // [rows_p][mp]
+  const double* S;       // [rows_p][mp]  K * Binv
+  const double* A1;      // [rows_p][mp]  K * Kminv
+  const double* pts;     // [rows][d]  inputs (iso) or projections (fat) of the chunk
+  const double* Z;       // [mp][d]
+  const double* is;      // [rows_p]
+  const double* v;       // [rows_p]
+  const double* w;       // [rows_p]
+  const double* t;       // [mp]
+  int rows, rows_p, m, mp, d;
+  double inv_ell2_05;    // distance scale of the kernel (for sqr_diff recovery is not used; D recomputed)
+  double* colpart;       // out [nslabs][(d+1)][mp]: row 0 = column sums of E, rows 1..d = sum_r x_kr E_rc
+  double* scalpart;      // out [nslabs][nbx][2]: sum E, sum E*sqr_diff
+  double* rowE;          // optional out [rows][1+d]: rowsum E, (E Z)[r][k]  (Cov_se_fat Proj gradient), or null
+};
+int grad_slab_rows();
+void launch_grad_fused(const GradArgs& a, hipStream_t s);
+
+// ---- m x m finalisation (finalize.hip)
+// dst (upper tiles) = base + sum_z slices[z]
+void launch_sum_slices(const double* base, const double* slices, int nslices, int64_t stride, int mp,
+                       double* dst, hipStream_t s);
+// W (upper tiles) = Kminv - Binv - t t^T - G
+void launch_build_w(const double* kminv, const double* binv, const double* t, const double* G, int mp,
+                    double* W, hipStream_t s);
+// Trace terms of W against K_m and its derivatives (lib/fitc_gp.ml:956-973, lib/utils.ml:196-220),
+// as per-column partial sums over slabs of 256 rows: part[slab][q][c], q = 0: sum_r W_rc K_rc,
+// q = 1: sum_r W_rc K_rc |z_r - z_c|^2, q = 2+k: sum_r W_rc K_rc (z_kr - z_kc).  W, km full symmetric.
+void launch_km_traces(const double* W, const double* km, const double* Z, int m, int mp, int d,
+                      double* part, double* unused, hipStream_t s);
+
+}  // namespace gprhip

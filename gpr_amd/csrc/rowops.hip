@@ -1,0 +1,275 @@
+// Row-wise (per training point) kernels of the two streaming passes -- all HBM-bound.
+// Wavefront reductions give diag(Q_nn)-type quantities; every cross-block sum goes through
+// a partial buffer that is reduced in a fixed order (bit-reproducible run to run).
+#include "kernels.h"
+
+namespace gprhip {
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+constexpr int ROWS_PER_BLOCK = 16;  // 4 wavefronts x 4 rows
+
+int pass1_row_blocks(int rows_p) { return (rows_p + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK; }
+
+// r = k_diag - rowsum(V.^2)            lib/fitc_gp.ml:222-223 (Mat.syrk_diag)
+// s = r + sigma2, is = 1/s, sum log s   lib/fitc_gp.ml:155-166
+__global__ __launch_bounds__(256) void pass1_rows_kernel(Pass1RowArgs a, int rows_p) {
+  __shared__ double red[4][4];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  double p_log = 0.0, p_y2 = 0.0, p_isr = 0.0;
+  for (int q = 0; q < 4; ++q) {
+    const int row = blockIdx.x * ROWS_PER_BLOCK + wv * 4 + q;
+    if (row >= rows_p) break;
+    const double* v = a.V + (int64_t)row * a.mp;
+    double s2 = 0.0;
+    for (int c = lane * 2; c < a.mp; c += 128) {
+      double2 x = *reinterpret_cast<const double2*>(v + c);
+      s2 += x.x * x.x + x.y * x.y;
+    }
+    s2 = wave_sum(s2);
+    if (lane == 0) {
+      if (row < a.rows) {
+        const double r = a.sf2 - s2;
+        const double s = r + a.sigma2;
+        const double is = 1.0 / s;
+        const double y = a.y ? a.y[row] : 0.0;
+        a.r[row] = r;
+        a.is[row] = is;
+        a.yis[row] = is * y;
+        p_log += log(s);
+        p_y2 += is * y * y;
+        p_isr += is * r;
+      } else {
+        a.r[row] = 0.0;
+        a.is[row] = 0.0;
+        a.yis[row] = 0.0;
+      }
+    }
+  }
+  if (lane == 0) {
+    red[wv][0] = p_log;
+    red[wv][1] = p_y2;
+    red[wv][2] = p_isr;
+  }
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    const int k = threadIdx.x;
+    a.partial[(int64_t)blockIdx.x * 4 + k] = (red[0][k] + red[1][k]) + (red[2][k] + red[3][k]);
+  }
+  if (threadIdx.x == 3) a.partial[(int64_t)blockIdx.x * 4 + 3] = 0.0;
+}
+
+void launch_pass1_rows(const Pass1RowArgs& a, hipStream_t s) {
+  const int rows_p = (int)round_up(a.rows, TILE);
+  hipLaunchKernelGGL(pass1_rows_kernel, dim3(pass1_row_blocks(rows_p)), dim3(256), 0, s, a, rows_p);
+  GPR_HIP(hipGetLastError());
+}
+
+// q_diag, u, w, v of lib/fitc_gp.ml:1048, :1092-1108, :1158-1181 from Q' = K R^-1 (so that
+// Q_n = diag(sqrt is) Q'):  q_diag = is*|Q'_i|^2,  u/sqrt(is) = y - Q' b  (b = Q_n^T y~),
+// w = is*(y - Q' b),  v1 = is*(1-q) [variational: is*(2 - is*r - q)],  v = v1 - w^2.
+__global__ __launch_bounds__(256) void pass2_rows_kernel(Pass2RowArgs a, int rows_p) {
+  __shared__ double red[4][4];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  double p_v = 0.0, p_is = 0.0, p_res = 0.0, p_v1 = 0.0;
+  for (int q = 0; q < 4; ++q) {
+    const int row = blockIdx.x * ROWS_PER_BLOCK + wv * 4 + q;
+    if (row >= rows_p) break;
+    const double* qr = a.Q + (int64_t)row * a.mp;
+    double s2 = 0.0, sb = 0.0;
+    for (int c = lane * 2; c < a.mp; c += 128) {
+      double2 x = *reinterpret_cast<const double2*>(qr + c);
+      double2 bb = *reinterpret_cast<const double2*>(a.b + c);
+      s2 += x.x * x.x + x.y * x.y;
+      sb += x.x * bb.x + x.y * bb.y;
+    }
+    s2 = wave_sum(s2);
+    sb = wave_sum(sb);
+    if (lane == 0) {
+      if (row < a.rows) {
+        const double is = a.is[row];
+        const double qd = is * s2;
+        const double y = a.y ? a.y[row] : 0.0;
+        const double res = a.y ? (y - sb) : 0.0;
+        const double w = is * res;
+        double v1 = a.variational ? is * (2.0 - is * a.r[row] - qd) : is * (1.0 - qd);
+        const double v = v1 - w * w;
+        a.w[row] = w;
+        a.v[row] = v;
+        p_v += v;
+        p_is += is;
+        p_res += w * res;
+        p_v1 += v1;
+      } else {
+        a.w[row] = 0.0;
+        a.v[row] = 0.0;
+      }
+    }
+  }
+  if (lane == 0) {
+    red[wv][0] = p_v;
+    red[wv][1] = p_is;
+    red[wv][2] = p_res;
+    red[wv][3] = p_v1;
+  }
+  __syncthreads();
+  if (threadIdx.x < 4) {
+    const int k = threadIdx.x;
+    a.partial[(int64_t)blockIdx.x * 4 + k] = (red[0][k] + red[1][k]) + (red[2][k] + red[3][k]);
+  }
+}
+
+void launch_pass2_rows(const Pass2RowArgs& a, hipStream_t s) {
+  const int rows_p = (int)round_up(a.rows, TILE);
+  hipLaunchKernelGGL(pass2_rows_kernel, dim3(pass1_row_blocks(rows_p)), dim3(256), 0, s, a, rows_p);
+  GPR_HIP(hipGetLastError());
+}
+
+// partial[slab][col] = sum_{r in slab} K[r][col] * x[r]
+__global__ __launch_bounds__(256) void gemv_t_partial_kernel(const double* __restrict__ K, int rows_p,
+                                                             int mp, const double* __restrict__ x,
+                                                             double* __restrict__ partial) {
+  const int col = blockIdx.x * 256 + threadIdx.x;
+  if (col >= mp) return;
+  const int r0 = blockIdx.y * 256;
+  const int r1 = min(rows_p, r0 + 256);
+  double acc = 0.0;
+  for (int r = r0; r < r1; ++r) acc += K[(int64_t)r * mp + col] * x[r];
+  partial[(int64_t)blockIdx.y * mp + col] = acc;
+}
+
+void launch_gemv_t_partial(const double* K, int rows_p, int mp, const double* x, double* partial,
+                           hipStream_t s) {
+  dim3 grid((mp + 255) / 256, (rows_p + 255) / 256);
+  hipLaunchKernelGGL(gemv_t_partial_kernel, grid, dim3(256), 0, s, K, rows_p, mp, x, partial);
+  GPR_HIP(hipGetLastError());
+}
+
+// out[col] (+)= sum_slab partial[slab][col].  A block covers COLS columns with 256/COLS slab lanes
+// per column; each lane strides over the slabs, then the lanes are combined in a fixed order.
+template <int COLS>
+__global__ __launch_bounds__(256) void reduce_rows_kernel(const double* __restrict__ partial, int nslabs,
+                                                          int width, double* __restrict__ out,
+                                                          int accumulate) {
+  constexpr int LANES = 256 / COLS;
+  __shared__ double red[LANES][COLS];
+  const int tx = threadIdx.x % COLS, ty = threadIdx.x / COLS;
+  const int col = blockIdx.x * COLS + tx;
+  double acc = 0.0;
+  if (col < width) {
+#pragma unroll 8
+    for (int sl = ty; sl < nslabs; sl += LANES) acc += partial[(int64_t)sl * width + col];
+  }
+  red[ty][tx] = acc;
+  __syncthreads();
+  if (ty == 0 && col < width) {
+    double tot = accumulate ? out[col] : 0.0;
+    for (int l = 0; l < LANES; ++l) tot += red[l][tx];
+    out[col] = tot;
+  }
+}
+
+void launch_reduce_rows(const double* partial, int nslabs, int width, double* out, int accumulate,
+                        hipStream_t s) {
+  if (width <= 8) {
+    hipLaunchKernelGGL(reduce_rows_kernel<8>, dim3((width + 7) / 8), dim3(256), 0, s, partial, nslabs,
+                       width, out, accumulate);
+  } else {
+    hipLaunchKernelGGL(reduce_rows_kernel<64>, dim3((width + 63) / 64), dim3(256), 0, s, partial,
+                       nslabs, width, out, accumulate);
+  }
+  GPR_HIP(hipGetLastError());
+}
+
+// ---------------------------------------------------------------------------------------------
+// Fused gradient pass: never materialises X or any derivative matrix.
+//   X   = diag(is) K Binv - diag(v) K Kminv - w t^T          lib/fitc_gp.ml:1204-1206
+//   E   = X .* K_nm
+//   `Factor 1.  (Log_sf2)       : tr(X^T K)            = sum E                 lib/fitc_gp.ml:991
+//   `Dense      (Log_ell)       : tr(X^T (K.*D)) ell^-2 = ell^-2 sum E.*D      lib/cov_se_iso.ml:303-314
+//   `Sparse_cols (Inducing c,k) : scale * sum_r (x_kr - z_kc) E_rc             lib/cov_se_iso.ml:315-327
+// Thread <-> inducing column; rows stream through; per-thread accumulators in registers.
+constexpr int GRAD_SLAB = 256;
+int grad_slab_rows() { return GRAD_SLAB; }
+
+template <int DT>
+__global__ __launch_bounds__(256) void grad_fused_kernel(GradArgs a) {
+  __shared__ double red[4][2];
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  const int jj = min(j, a.mp - 1);
+  const bool live = (j < a.m);
+  double z[DT], gx[DT];
+#pragma unroll
+  for (int k = 0; k < DT; ++k) {
+    z[k] = (k < a.d && live) ? a.Z[(int64_t)jj * a.d + k] : 0.0;
+    gx[k] = 0.0;
+  }
+  const double tj = live ? a.t[jj] : 0.0;
+  double cs = 0.0, sE = 0.0, sED = 0.0;
+  const int r0 = blockIdx.y * GRAD_SLAB;
+  const int r1 = min(a.rows, r0 + GRAD_SLAB);
+  for (int r = r0; r < r1; ++r) {
+    const double is = a.is[r], v = a.v[r], w = a.w[r];
+    const double* x = a.pts + (int64_t)r * a.d;
+    const int64_t off = (int64_t)r * a.mp + jj;
+    const double kk = a.K[off];
+    const double xs = is * a.S[off] - v * a.A1[off] - w * tj;
+    const double e = live ? xs * kk : 0.0;
+    double dist = 0.0;
+#pragma unroll
+    for (int k = 0; k < DT; ++k) {
+      if (k < a.d) {
+        const double xk = x[k];
+        const double df = xk - z[k];
+        dist += df * df;
+        gx[k] += xk * e;
+      }
+    }
+    cs += e;
+    sE += e;
+    sED += e * dist;
+  }
+  if (j < a.mp) {
+    double* cp = a.colpart + (int64_t)blockIdx.y * (a.d + 1) * a.mp;
+    cp[j] = cs;
+#pragma unroll
+    for (int k = 0; k < DT; ++k)
+      if (k < a.d) cp[(int64_t)(k + 1) * a.mp + j] = gx[k];
+  }
+  sE = wave_sum(sE);
+  sED = wave_sum(sED);
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  if (lane == 0) {
+    red[wv][0] = sE;
+    red[wv][1] = sED;
+  }
+  __syncthreads();
+  if (threadIdx.x < 2) {
+    const int k = threadIdx.x;
+    a.scalpart[((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 2 + k] =
+        (red[0][k] + red[1][k]) + (red[2][k] + red[3][k]);
+  }
+}
+
+void launch_grad_fused(const GradArgs& a, hipStream_t s) {
+  dim3 grid((a.mp + 255) / 256, (a.rows + GRAD_SLAB - 1) / GRAD_SLAB);
+  auto go = [&](auto dt) {
+    hipLaunchKernelGGL((grad_fused_kernel<decltype(dt)::value>), grid, dim3(256), 0, s, a);
+  };
+  if (a.d <= 4) go(std::integral_constant<int, 4>{});
+  else if (a.d <= 8) go(std::integral_constant<int, 8>{});
+  else if (a.d <= 16) go(std::integral_constant<int, 16>{});
+  else if (a.d <= 32) go(std::integral_constant<int, 32>{});
+  else if (a.d <= 64) go(std::integral_constant<int, 64>{});
+  else {
+    set_error("gprhip: input dimension d > 64 is not supported by the gradient kernel");
+    throw HipFail{ST_BAD_ARG};
+  }
+  GPR_HIP(hipGetLastError());
+}
+
+}  // namespace gprhip

@@ -1,0 +1,157 @@
+"""Device-resident FITC problem: thin object wrapper over the gprhip C ABI.
+
+Holds the training inputs/targets of one shard in HBM and runs evaluations of the FITC log
+evidence + gradient for changing hyper-parameters (what the reference's optimiser callback
+multim_dcommon does per call, lib/fitc_gp.ml:1612-1636).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Optional
+
+import numpy as np
+
+from . import _lib
+from ._lib import COV_SE_FAT, COV_SE_ISO, Hypers, Result
+
+CHOLESKY_JITTER = 1e-6  # Utils.cholesky_jitter, lib/utils.ml:35
+
+
+@dataclass
+class Evaluation:
+    l1: float                 # Model.calc_log_evidence
+    l2: float
+    l: float                  # Trained.calc_log_evidence
+    dl_dsigma2: Optional[float]
+    grad: Optional[np.ndarray]    # reference Hyper.get_all order
+    coeffs: np.ndarray        # Trained.calc_mean_coeffs
+
+
+def _f64_ptr(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+class Problem:
+    def __init__(self, cov_kind, n, D, d, m, device=0, chunk_rows=0):
+        self._lib = _lib.load()
+        self._h = C.c_void_p()
+        self.cov_kind, self.n, self.D, self.d, self.m = cov_kind, int(n), int(D), int(d), int(m)
+        self.device = device
+        _lib.check(self._lib.gprhip_problem_create(device, cov_kind, self.n, self.D, self.d, self.m,
+                                                   int(chunk_rows), C.byref(self._h)))
+
+    def close(self):
+        if self._h:
+            self._lib.gprhip_problem_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- data
+    def set_inputs(self, inputs):
+        """inputs: D x n (reference layout, one point per column); numpy, any order."""
+        x = np.asfortranarray(inputs, dtype=np.float64)
+        if x.shape != (self.D, self.n):
+            raise ValueError("set_inputs: expected shape (%d, %d), got %s" % (self.D, self.n, x.shape))
+        _lib.check(self._lib.gprhip_set_inputs(self._h, _f64_ptr(x), self.D))
+
+    def set_targets(self, targets):
+        y = np.ascontiguousarray(targets, dtype=np.float64)
+        if y.shape != (self.n,):
+            # Trained.calc: Vec.dim targets <> n  (lib/fitc_gp.ml:283-284)
+            raise ValueError("Trained.calc: Vec.dim targets (%d) <> n (%d)" % (y.shape[0], self.n))
+        _lib.check(self._lib.gprhip_set_targets(self._h, _f64_ptr(y)))
+
+    def set_inputs_device(self, ptr):
+        """ptr: device address of a contiguous point-major [n][D] fp64 array (e.g. tensor.data_ptr())."""
+        _lib.check(self._lib.gprhip_set_inputs_device(self._h, C.c_void_p(ptr)))
+
+    def set_targets_device(self, ptr):
+        _lib.check(self._lib.gprhip_set_targets_device(self._h, C.c_void_p(ptr)))
+
+    # ---- evaluation
+    def n_hypers(self, has_tproj=False):
+        return int(self._lib.gprhip_n_hypers(self._h, int(has_tproj)))
+
+    def _hypers(self, log_ell, log_sf2, sigma2, inducing, tproj, variational, model_only, jitter):
+        z = np.asfortranarray(inducing, dtype=np.float64)
+        if z.shape != (self.d, self.m):
+            raise ValueError("inducing: expected shape (%d, %d), got %s" % (self.d, self.m, z.shape))
+        h = Hypers()
+        h.log_ell, h.log_sf2, h.sigma2 = float(log_ell), float(log_sf2), float(sigma2)
+        h.inducing = _f64_ptr(z)
+        keep = [z]
+        if tproj is not None:
+            tp = np.asfortranarray(tproj, dtype=np.float64)
+            if tp.shape != (self.D, self.d):
+                raise ValueError("tproj: expected shape (%d, %d), got %s" % (self.D, self.d, tp.shape))
+            h.tproj = _f64_ptr(tp)
+            keep.append(tp)
+        h.variational, h.model_only, h.jitter = int(variational), int(model_only), float(jitter)
+        return h, keep
+
+    def eval(self, *, log_sf2, sigma2, inducing, log_ell=0.0, tproj=None, variational=False,
+             model_only=False, want_grad=True, jitter=CHOLESKY_JITTER):
+        h, keep = self._hypers(log_ell, log_sf2, sigma2, inducing, tproj, variational, model_only, jitter)
+        res = Result()
+        nh = self.n_hypers(tproj is not None)
+        grad = np.empty(nh if want_grad else 1, dtype=np.float64)
+        coeffs = np.empty(self.m, dtype=np.float64)
+        _lib.check(self._lib.gprhip_eval(self._h, C.byref(h), int(want_grad), C.byref(res),
+                                         _f64_ptr(grad), _f64_ptr(coeffs)))
+        del keep
+        return Evaluation(res.l1, res.l2, res.l, res.dl_dsigma2 if want_grad else None,
+                          grad[:res.n_hypers] if want_grad else None, coeffs)
+
+    # ---- staged evaluation (row-sharded across devices; see gpr_amd/dist.py)
+    def ar1_len(self):
+        return int(self._lib.gprhip_ar1_len(self._h))
+
+    def ar2_len(self):
+        return int(self._lib.gprhip_ar2_len(self._h))
+
+    def eval_pass1(self, ar1_ptr, n_total, *, log_sf2, sigma2, inducing, log_ell=0.0, tproj=None,
+                   variational=False, model_only=False, want_grad=True, jitter=CHOLESKY_JITTER):
+        h, keep = self._hypers(log_ell, log_sf2, sigma2, inducing, tproj, variational, model_only, jitter)
+        self._want_grad = bool(want_grad)
+        self._has_tproj = tproj is not None
+        _lib.check(self._lib.gprhip_eval_pass1(self._h, C.byref(h), int(want_grad), int(n_total),
+                                               C.c_void_p(ar1_ptr)))
+        del keep  # the library copies borrowed host buffers before returning
+
+    def eval_pass2(self, ar1_ptr, ar2_ptr):
+        _lib.check(self._lib.gprhip_eval_pass2(self._h, C.c_void_p(ar1_ptr), C.c_void_p(ar2_ptr)))
+
+    def eval_finish(self, ar2_ptr):
+        res = Result()
+        nh = self.n_hypers(self._has_tproj)
+        grad = np.empty(nh if self._want_grad else 1, dtype=np.float64)
+        coeffs = np.empty(self.m, dtype=np.float64)
+        _lib.check(self._lib.gprhip_eval_finish(self._h, C.c_void_p(ar2_ptr), C.byref(res),
+                                                _f64_ptr(grad), _f64_ptr(coeffs)))
+        return Evaluation(res.l1, res.l2, res.l, res.dl_dsigma2 if self._want_grad else None,
+                          grad[:res.n_hypers] if self._want_grad else None, coeffs)
+
+    def sync(self):
+        _lib.check(self._lib.gprhip_sync(self._h))
+
+    def stream(self):
+        return self._lib.gprhip_stream(self._h)
+
+    # ---- diagnostics
+    def debug_fetch(self, name):
+        length = self.m if name == "t" else self.n
+        out = np.empty(length, dtype=np.float64)
+        _lib.check(self._lib.gprhip_debug_fetch(self._h, name.encode(), _f64_ptr(out), length))
+        return out
+
+    def last_timings(self):
+        names = (C.c_char_p * 32)()
+        ms = (C.c_float * 32)()
+        k = self._lib.gprhip_last_timings(self._h, names, ms, 32)
+        return {names[i].decode(): float(ms[i]) for i in range(k)}

@@ -1,0 +1,140 @@
+/* gprhip -- C ABI of the MI355X-native FITC/SPGP core (libgprhip.so).
+ *
+ * Drop-in boundary for one path of mmottl/gpr: one evaluation of the FITC log evidence and its
+ * full hyper-parameter gradient, i.e. what Gpr.Fitc_gp.Make_deriv(Cov_se_iso.Deriv).FITC /
+ * (Cov_se_fat.Deriv) compute in
+ *     Deriv.Inducing.calc -> Deriv.Inputs.calc -> Deriv.Model.calc -> Deriv.Trained.calc ->
+ *     Trained.calc_log_evidence_sigma2 -> Trained.prepare_hyper -> Trained.calc_log_evidence (per hyper)
+ * (reference lib/fitc_gp.ml:881-888, :902-911, :1051-1078, :1158-1207, :1005-1021; driven by
+ * multim_dcommon lib/fitc_gp.ml:1612-1636).  The reference has no native stubs of its own for this
+ * path (it reaches C only through Lacaml); these entry points are what an OCaml stub layer, or the
+ * ctypes host layer in gpr_amd/, binds.  See INTEGRATION.md for the OCaml `external` side.
+ *
+ * Conventions
+ *   - All matrices cross the boundary as raw double pointers in the reference's own layout:
+ *     Fortran (column-major) Bigarrays -- inputs D x n (one point per column), inducing d x m,
+ *     tproj D x d (lib/interfaces.ml:190-195, bin/ocaml_gpr.ml:196-202).
+ *   - Host pointers are borrowed for the duration of the call only.
+ *   - Every function returns 0 on success or a GPRHIP_E* code; gprhip_last_error() gives the
+ *     message (thread-local).  No C++ exception crosses the boundary.
+ *   - A context/problem must not be used from two host threads at once.
+ */
+#ifndef GPRHIP_H
+#define GPRHIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum {
+  GPRHIP_OK = 0,
+  GPRHIP_EBADARG = 1,    /* reference: Failure / Invalid_argument on argument checks            */
+  GPRHIP_ENOTPOSDEF = 2, /* reference: Lacaml Failure on potrf info > 0                          */
+  GPRHIP_EHIP = 3,       /* HIP runtime error                                                    */
+  GPRHIP_EOOM = 4,       /* device out of memory                                                 */
+  GPRHIP_ESTATE = 5      /* call sequence violated (e.g. pass2 before pass1)                     */
+};
+
+enum { GPRHIP_COV_SE_ISO = 0, GPRHIP_COV_SE_FAT = 1 }; /* lib/cov_se_iso.ml, lib/cov_se_fat.ml */
+
+typedef struct gprhip_problem gprhip_problem;
+
+/* Number of visible HIP devices (does not initialise a device). */
+int gprhip_device_count(int* count);
+
+/* Create the device-resident state for one shard of a FITC problem on HIP device `device`:
+ *   n  training points held by this shard, D input dimension, d kernel-space dimension
+ *   (d == D for Cov_se_iso; Cov_se_fat: d = Params.d, the tproj target dimension), m inducing points.
+ *   chunk_rows: rows of K_nm processed per streaming step (0 = library default).
+ * Replaces: the Bigarray allocations spread over Eval_inputs / Eval_model (lib/fitc_gp.ml:105-229). */
+int gprhip_problem_create(int device, int cov_kind, int64_t n, int D, int d, int m, int64_t chunk_rows,
+                          gprhip_problem** out);
+void gprhip_problem_destroy(gprhip_problem* p);
+
+/* Training inputs (Fortran D x n, leading dimension ld >= D) and targets (n): copied to the device.
+ * Replaces: Spec.Inputs.t / targets arguments of Deriv.Inputs.calc and Deriv.Trained.calc. */
+int gprhip_set_inputs(gprhip_problem* p, const double* inputs, int64_t ld);
+int gprhip_set_targets(gprhip_problem* p, const double* targets);
+/* Same, from device pointers (inputs already resident in HBM; point-major [n][D], contiguous). */
+int gprhip_set_inputs_device(gprhip_problem* p, const double* d_inputs);
+int gprhip_set_targets_device(gprhip_problem* p, const double* d_targets);
+
+/* Hyper-parameters of one evaluation.
+ *   log_ell    : Cov_se_iso.Params.log_ell (ignored for Cov_se_fat)          lib/cov_se_iso.ml:23-25
+ *   log_sf2    : Params.log_sf2
+ *   sigma2     : noise variance (>= 0, else GPRHIP_EBADARG: lib/fitc_gp.ml:148-149)
+ *   inducing   : Fortran d x m inducing points (Spec.Inducing.t)
+ *   tproj      : Fortran D x d projection (Cov_se_fat.Params.tproj) or NULL
+ *   variational: 0 = Make_FITC_deriv (Standard), 1 = Make_variational_FITC_deriv  lib/fitc_gp.ml:262-263
+ *   model_only : 1 = evidence/gradient of the model without targets (Deriv.Model.*), 0 = Trained.*
+ *   jitter     : Utils.cholesky_jitter (lib/utils.ml:35); pass 1e-6 for the reference behaviour */
+typedef struct {
+  double log_ell;
+  double log_sf2;
+  double sigma2;
+  const double* inducing;
+  const double* tproj;
+  int variational;
+  int model_only;
+  double jitter;
+} gprhip_hypers;
+
+/* Results.  Gradient order is the reference's Hyper.get_all order:
+ *   Cov_se_iso: [Log_ell; Log_sf2; Inducing_hyper{ind=1,dim=1..d}; {ind=2,..}; ...]   lib/cov_se_iso.ml:188-202
+ *   Cov_se_fat: [Log_sf2; Inducing_hyper (ind-major); Proj{big_dim,small_dim} (big-major)] lib/cov_se_fat.ml:290-342
+ * l1 = Model.calc_log_evidence, l = Trained.calc_log_evidence, dl_dsigma2 = calc_log_evidence_sigma2. */
+typedef struct {
+  double l1;
+  double l2;
+  double l;
+  double dl_dsigma2;
+  int64_t n_hypers;
+} gprhip_result;
+
+int64_t gprhip_n_hypers(const gprhip_problem* p, int has_tproj);
+
+/* One complete evaluation on one device (shard == whole problem).
+ *   want_grad = 0: log evidence only (multim_f, lib/fitc_gp.ml:1601-1610)
+ *   want_grad = 1: + dl_dsigma2 and grad[n_hypers] (multim_dcommon, lib/fitc_gp.ml:1612-1636)
+ *   coeffs (m, may be NULL): Trained.calc_mean_coeffs (lib/fitc_gp.ml:294). */
+int gprhip_eval(gprhip_problem* p, const gprhip_hypers* h, int want_grad, gprhip_result* res,
+                double* grad, double* coeffs);
+
+/* Staged form for row-sharded evaluation across devices (one process per device).  Between the
+ * stages the caller sums the exchange buffers over all shards (RCCL all-reduce on the same HIP
+ * stream or after a stream sync -- the buffers are plain device memory owned by the caller):
+ *     gprhip_eval_pass1(p, h, want_grad, ar1)      ar1: gprhip_ar1_len(p) doubles
+ *     all-reduce(sum, ar1)
+ *     gprhip_eval_pass2(p, ar1, ar2)               ar2: gprhip_ar2_len(p) doubles
+ *     all-reduce(sum, ar2)
+ *     gprhip_eval_finish(p, ar2, res, grad, coeffs)
+ * n used in the n*log(2*pi) term is n_total given here (sum over shards). */
+int64_t gprhip_ar1_len(const gprhip_problem* p);
+int64_t gprhip_ar2_len(const gprhip_problem* p);
+int gprhip_eval_pass1(gprhip_problem* p, const gprhip_hypers* h, int want_grad, int64_t n_total,
+                      double* d_ar1);
+int gprhip_eval_pass2(gprhip_problem* p, const double* d_ar1, double* d_ar2);
+int gprhip_eval_finish(gprhip_problem* p, const double* d_ar2, gprhip_result* res, double* grad,
+                       double* coeffs);
+/* Block the host until all work queued by the stage calls has finished. */
+int gprhip_sync(gprhip_problem* p);
+/* The HIP stream (hipStream_t) the problem enqueues on, for callers that order other work after it. */
+void* gprhip_stream(gprhip_problem* p);
+
+/* Intermediates of the last evaluation, for parity tests (copied to host; sizes in doubles):
+ *   "r" n, "is" n, "v" n, "w" n, "t" m.  Returns GPRHIP_EBADARG for an unknown name. */
+int gprhip_debug_fetch(gprhip_problem* p, const char* name, double* out, int64_t len);
+
+/* Per-stage timing of the last gprhip_eval (milliseconds, HIP events): fills up to `cap` entries of
+ * names/ms; returns the count. */
+int gprhip_last_timings(gprhip_problem* p, const char** names, float* ms, int cap);
+
+const char* gprhip_last_error(void);
+const char* gprhip_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GPRHIP_H */
