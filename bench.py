@@ -1,0 +1,172 @@
+#!/usr/bin/env python3
+"""FITC nLML + hyper-gradient throughput on MI355X (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one complete evaluation (log evidence l1+l2, dl/dsigma2 and dl/dtheta for all
+2 + d*m hypers) of cov_se_iso FITC at n=1,000,000, m=2048, d=8, fp64 (BASELINE.json configs[1]),
+with fresh theta and inducing points every step (as under an optimiser) and the training inputs
+already resident in HBM.  With N > 1 the n training points are row-sharded over the ranks
+(strong scaling of the same n) with two RCCL all-reduces per step.
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+PEAK_FP64_MFMA_TFLOPS = 78.6   # MI355X fp64 matrix peak (256 CU x 2.4 GHz x 128 flop/clk/CU)
+
+
+def synth(seed, n, m, d):
+    """BASELINE.md section 2 generator."""
+    rng = np.random.default_rng(seed)
+    X = rng.normal(size=(d, n))
+    y = np.sin(X.sum(0)) + 0.1 * rng.normal(size=n)
+    Z = X[:, rng.permutation(n)[:m]] + 0.01 * rng.normal(size=(d, m))
+    return np.asfortranarray(X), y, np.asfortranarray(Z)
+
+
+def algorithmic_flops(n, m, d):
+    """F = n(6 m^2 + 4 m d) + 2 m^3."""
+    return n * (6.0 * m * m + 4.0 * m * d) + 2.0 * m ** 3
+
+
+def cpu_baseline(n_full, m, d, seed):
+    """The CPU oracle (numpy/scipy-LAPACK port of the reference's operation sequence) timed on this
+    host's cores on a bounded row sample of the same workload; cost is linear in n."""
+    from oracle import fitc_oracle as O
+    n_cpu = int(os.environ.get("BENCH_CPU_ROWS", "12288"))
+    X, y, Z = synth(seed, n_cpu, m, d)
+    k = O.SeIsoKernel(0.5 * np.log(d), 0.0)
+    t0 = time.time()
+    out = O.evaluate_fast(k, Z, X, y, 0.1)
+    dt = time.time() - t0
+    assert np.isfinite(out["l"])
+    return {"value": n_cpu / dt, "unit": "training-points/s", "cores": os.cpu_count(), "kind": "port",
+            "sample": "oracle.evaluate_fast (reference LAPACK sequence: potrf, trsm, geqrf+orgqr, potri x2, "
+                      "trsm x2, syrk x2, traces) on n=%d rows of the same m=%d d=%d workload, %.1f s, "
+                      "scipy OpenBLAS threads" % (n_cpu, m, d, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--n", type=int, default=1_000_000)
+    ap.add_argument("--m", type=int, default=2048)
+    ap.add_argument("--d", type=int, default=8)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    os.environ.setdefault("GPRHIP_TIMING", "1")  # per-kernel HIP events on the library's own stream
+    import torch
+    import torch.distributed as dist
+    import gpr_amd
+    from gpr_amd.dist import ShardedProblem, shard_rows
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)"
+                         % (args.gpus, world))
+    if gpr_amd.device_count() < 1:
+        raise SystemExit("bench.py: no HIP device; the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    n, m, d, seed = args.n, args.m, args.d, 2
+    X, y, Z0 = synth(seed, n, m, d)
+    lo, hi = shard_rows(n, rank, world)
+    sp = ShardedProblem(gpr_amd.COV_SE_ISO, n, d, d, m, rank=rank, world=world, device=local_rank)
+    sp.set_inputs(X[:, lo:hi])
+    sp.set_targets(y[lo:hi])
+    del X, y
+    rng = np.random.default_rng(1234)  # same stream on every rank: identical theta everywhere
+    le0 = 0.5 * np.log(d)
+
+    def step():
+        Z = Z0 + 1e-3 * rng.normal(size=Z0.shape)
+        return sp.eval(log_ell=le0 + 1e-3 * rng.normal(), log_sf2=1e-3 * rng.normal(),
+                       sigma2=0.1 * np.exp(1e-3 * rng.normal()), inducing=Z)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    tim = {}
+    for _ in range(args.steps):
+        ev = step()
+        for k_, v_ in sp.local.last_timings().items():
+            tim.setdefault(k_, []).append(v_)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    assert np.isfinite(ev.l) and np.all(np.isfinite(ev.grad))
+
+    if rank == 0:
+        ms_per_step = dt / args.steps * 1e3
+        value = n * args.steps / dt
+        F = algorithmic_flops(n, m, d)
+        # dominant kernel: gemm_kernel<OP_TN> (the two SYRK-shaped accumulations over training points,
+        # one launch per row chunk and pass); algorithmic flops per launch = chunk_rows * m^2
+        chunk = min(int(os.environ.get("GPRHIP_CHUNK_ROWS", "32768")), hi - lo)
+        n_local = hi - lo
+        nchunks = (n_local + chunk - 1) // chunk
+        syrk_ms = (np.mean(tim.get("p1_syrk_B", [0.0])) + np.mean(tim.get("p2_syrk_W", [0.0])))
+        launches = 2 * nchunks
+        flops_per_launch = (n_local / nchunks) * m * m
+        achieved = flops_per_launch / (syrk_ms / launches * 1e-3) * 1e-12 if syrk_ms > 0 else None
+        engine_ms = sum(np.mean(tim.get(k_, [0.0])) for k_ in
+                        ("p1_syrk_B", "p2_syrk_W", "p1_trmm_V", "p1_trmm_A1", "p2_trmm_Q", "p2_trmm_S"))
+        line = {
+            "metric": "FITC nLML+grad training-points/sec at n=1M m=2048 d=8",
+            "value": value, "unit": "training-points/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "cov_se_iso FITC nLML + full hyper-gradient, n=%d m=%d d=%d fp64 "
+                                   "(BASELINE.json configs[1]); n row-sharded over %d GPU(s)" % (n, m, d, world),
+                       "n": n, "m": m, "d": d, "n_hypers": int(ev.grad.shape[0]) + 1,
+                       "chunk_rows": chunk},
+            "roofline": {"bound": "mfma", "kernel": "gprhip::gemm_kernel<OP_TN> (SYRK over training points)",
+                         "achieved": achieved, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": (achieved / PEAK_FP64_MFMA_TFLOPS) if achieved else None,
+                         "traffic": None,
+                         "avg_launch_ms": syrk_ms / launches if launches else None,
+                         "flops_per_launch": flops_per_launch},
+            "roofline_job": {"algorithmic_flops_per_step": F, "achieved": F / (dt / args.steps) * 1e-12 / world,
+                             "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s per GPU",
+                             "frac": F / (dt / args.steps) * 1e-12 / world / PEAK_FP64_MFMA_TFLOPS,
+                             "mfma_engine_ms_per_step": engine_ms},
+            "stage_ms": {k_: float(np.mean(v_)) for k_, v_ in sorted(tim.items())},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(n, m, d, seed)
+        print(json.dumps(line))
+    sp.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,138 @@
+"""Host-side mirror of Gpr.Cov_se_fat (reference lib/cov_se_fat.ml, lib/cov_se_fat.mli),
+projection-only sub-case: `tproj` optional, heteroskedastic noise and multiscales must be None
+(SURVEY.md section 8(f) rank 3 -- the next rows to widen into).
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+from typing import NamedTuple, Optional, Union
+
+import numpy as np
+
+from ._lib import COV_SE_FAT
+
+COV_KIND = COV_SE_FAT
+
+
+@dataclass(frozen=True, eq=False)
+class Params:
+    """Cov_se_fat.Params.params (lib/cov_se_fat.ml:27-49)."""
+    d: int
+    log_sf2: float
+    tproj: Optional[np.ndarray] = None                 # big_dim x d
+    log_hetero_skedasticity: Optional[np.ndarray] = None
+    log_multiscales_m05: Optional[np.ndarray] = None
+
+    @staticmethod
+    def create(d, log_sf2, tproj=None, log_hetero_skedasticity=None, log_multiscales_m05=None):
+        if tproj is not None:
+            tproj = np.asfortranarray(tproj, dtype=np.float64)
+            if tproj.shape[1] != d:  # lib/cov_se_fat.ml:38-48
+                raise ValueError("Cov_se_fat.Params.create: tproj projection (%d) disagrees with "
+                                 "target dimension d (%d)" % (tproj.shape[1], d))
+        if log_hetero_skedasticity is not None or log_multiscales_m05 is not None:
+            raise NotImplementedError(
+                "gpr_amd.cov_se_fat: heteroskedastic noise / multiscales are not on the device path yet")
+        return Params(int(d), float(log_sf2), tproj, None, None)
+
+
+@dataclass(frozen=True, eq=False)
+class Kernel:
+    """Cov_se_fat.Eval.Kernel.t (lib/cov_se_fat.ml:55-75)."""
+    params: Params
+    sf2: float
+
+    @staticmethod
+    def create(params: Params) -> "Kernel":
+        return Kernel(params, math.exp(params.log_sf2))
+
+    def get_params(self) -> Params:
+        return self.params
+
+
+class Inducing_hyper(NamedTuple):
+    ind: int
+    dim: int
+
+
+class Proj_hyper(NamedTuple):
+    """`Proj {big_dim; small_dim}` (lib/cov_se_fat.ml:263-265), 1-based."""
+    big_dim: int
+    small_dim: int
+
+
+Hyper = Union[str, Inducing_hyper, Proj_hyper]
+LOG_SF2 = "Log_sf2"
+
+
+def kernel_space_dim(kernel: Kernel, inputs) -> int:
+    return kernel.params.d
+
+
+def tproj_of(kernel: Kernel):
+    return kernel.params.tproj
+
+
+class HyperModule:
+    """Cov_se_fat.Deriv.Hyper (lib/cov_se_fat.ml:287-407): [Log_sf2; inducing (ind-major); Proj (big-major)]."""
+
+    @staticmethod
+    def get_all(kernel: Kernel, inducing, _inputs=None):
+        d = kernel.params.d
+        m = inducing.shape[1]
+        hypers = [LOG_SF2]
+        for ind in range(1, m + 1):
+            for dim in range(1, d + 1):
+                hypers.append(Inducing_hyper(ind, dim))
+        tproj = kernel.params.tproj
+        if tproj is not None:
+            for big in range(1, tproj.shape[0] + 1):
+                for small in range(1, d + 1):
+                    hypers.append(Proj_hyper(big, small))
+        return hypers
+
+    @staticmethod
+    def get_value(kernel: Kernel, inducing, _inputs, hyper):
+        if hyper == LOG_SF2:
+            return kernel.params.log_sf2
+        if isinstance(hyper, Proj_hyper):
+            if kernel.params.tproj is None:  # lib/cov_se_fat.ml:344-347
+                raise RuntimeError("Deriv.Hyper.option_get_value: tproj not supported")
+            return float(kernel.params.tproj[hyper.big_dim - 1, hyper.small_dim - 1])
+        return float(inducing[hyper.dim - 1, hyper.ind - 1])
+
+    @staticmethod
+    def set_values(kernel: Kernel, inducing, inputs, hypers, values):
+        log_sf2 = kernel.params.log_sf2
+        tproj = None
+        new_inducing = None
+        for h, v in zip(hypers, values):
+            if h == LOG_SF2:
+                log_sf2 = float(v)
+            elif isinstance(h, Proj_hyper):
+                if tproj is None:
+                    if kernel.params.tproj is None:
+                        raise RuntimeError("Deriv.Hyper.option_get_value: tproj not supported")
+                    tproj = np.array(kernel.params.tproj, dtype=np.float64, order="F", copy=True)
+                tproj[h.big_dim - 1, h.small_dim - 1] = v
+            else:
+                if new_inducing is None:
+                    new_inducing = np.array(inducing, dtype=np.float64, order="F", copy=True)
+                new_inducing[h.dim - 1, h.ind - 1] = v
+        params = Params(kernel.params.d, log_sf2, kernel.params.tproj if tproj is None else tproj)
+        return Kernel.create(params), (inducing if new_inducing is None else new_inducing), inputs
+
+    @staticmethod
+    def index_of(kernel: Kernel, inducing, hyper) -> int:
+        d = kernel.params.d
+        m = inducing.shape[1]
+        if hyper == LOG_SF2:
+            return 0
+        if isinstance(hyper, Proj_hyper):
+            return 1 + d * m + (hyper.big_dim - 1) * d + (hyper.small_dim - 1)
+        return 1 + (hyper.ind - 1) * d + (hyper.dim - 1)
+
+
+def eval_args(kernel: Kernel):
+    return dict(log_ell=0.0, log_sf2=kernel.params.log_sf2, tproj=kernel.params.tproj)

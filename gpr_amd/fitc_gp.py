@@ -1,0 +1,228 @@
+"""Host-side mirror of Gpr.Fitc_gp.Make_deriv (reference lib/fitc_gp.mli:83-135, lib/interfaces.ml
+Sigs.Deriv :848-1154) for the FITC evidence + gradient path, backed by the HIP library.
+
+    GP = fitc_gp.Make_deriv(cov_se_iso)          # module GP = Fitc_gp.Make_deriv (Cov_se_iso.Deriv)
+    FITC = GP.FITC                               # test/save_data.ml:24-27
+    inducing = FITC.Deriv.Inducing.calc(kernel, inducing_points)
+    inputs   = FITC.Deriv.Inputs.calc(inducing, training_inputs)
+    model    = FITC.Deriv.Model.calc(inputs, sigma2=0.1)
+    trained  = FITC.Deriv.Trained.calc(model, targets=y)
+    l        = FITC.Eval.Trained.calc_log_evidence(FITC.Deriv.Trained.calc_eval(trained))
+    hyper_t  = FITC.Deriv.Trained.prepare_hyper(trained)
+    dl       = FITC.Deriv.Trained.calc_log_evidence(hyper_t, hyper)
+
+`Inputs.t`, `Model.t`, `Trained.t`, `hyper_t` are abstract in the reference signature
+(lib/interfaces.ml:433, :459, :514, :895-899, :944-948); here they are small Python objects
+holding a handle to the device-resident problem.  The reference computes its matrices eagerly
+stage by stage; the device path is a two-pass streaming evaluation, so these objects are lazy and
+the whole evaluation runs when the first number (log evidence, gradient entry) is requested.
+Only scalars, m-vectors and the gradient ever cross back to the host.
+
+Not on this path: prediction, sampling, stats, the GSL/SGD/SMD optimisers,
+FIC covariances.  `FIC` / `Variational_FIC` are provided as aliases because their *evidence* is
+the FITC one (they differ only in predictive covariances, lib/fitc_gp.ml:565-624).
+"""
+from __future__ import annotations
+
+from types import SimpleNamespace
+
+import numpy as np
+
+from .problem import CHOLESKY_JITTER, Problem
+
+
+class _Inducing:
+    def __init__(self, kernel, points):
+        self.kernel = kernel
+        self.points = np.asfortranarray(points, dtype=np.float64)
+
+
+class _Inputs:
+    def __init__(self, inducing, points, problem):
+        self.inducing = inducing
+        self.points = points
+        self.problem = problem
+
+
+class _Model:
+    def __init__(self, inputs, sigma2, variational):
+        if sigma2 < 0.0:  # Model.check_sigma2, lib/fitc_gp.ml:148-149
+            raise ValueError("Model.check_sigma2: sigma2 < 0")
+        self.inputs, self.sigma2, self.variational = inputs, float(sigma2), variational
+        self._ev = {}
+
+    def evaluation(self, want_grad):
+        if True in self._ev:  # the gradient evaluation also carries the evidence
+            return self._ev[True]
+        key = bool(want_grad)
+        if key not in self._ev:
+            self._ev[key] = _run(self, None, key)
+        return self._ev[key]
+
+
+class _Trained:
+    def __init__(self, model, targets, want_grad):
+        self.model = model
+        self.targets = np.ascontiguousarray(targets, dtype=np.float64)
+        n = model.inputs.problem.n
+        if self.targets.shape != (n,):  # lib/fitc_gp.ml:283-284
+            raise ValueError("Trained.calc: Vec.dim targets (%d) <> n (%d)" % (self.targets.shape[0], n))
+        self.want_grad = want_grad
+        self._ev = None
+
+    def evaluation(self):
+        if self._ev is None:
+            self._ev = _run(self.model, self.targets, self.want_grad)
+        return self._ev
+
+
+class _HyperT:
+    def __init__(self, evaluation, kernel, inducing_points, spec):
+        self.evaluation, self.kernel, self.inducing_points, self.spec = evaluation, kernel, inducing_points, spec
+
+
+def _run(model, targets, want_grad):
+    inputs = model.inputs
+    prob = inputs.problem
+    spec = prob._spec
+    kernel = inputs.inducing.kernel
+    if targets is not None:  # n doubles: cheap next to one evaluation, and never stale
+        prob.set_targets(targets)
+    return prob.eval(sigma2=model.sigma2, inducing=inputs.inducing.points, variational=model.variational,
+                     model_only=targets is None, want_grad=want_grad, jitter=prob._jitter,
+                     **spec.eval_args(kernel))
+
+
+def _make_variant(spec, variational, functor):
+    def inducing_calc(kernel, points):
+        return _Inducing(kernel, points)
+
+    def inputs_calc(inducing, points, device=0, chunk_rows=0):
+        points = np.asarray(points)
+        d = spec.kernel_space_dim(inducing.kernel, points)
+        m = inducing.points.shape[1]
+        if inducing.points.shape[0] != d:
+            raise ValueError("Inputs.calc: inducing points have dimension %d, kernel space has %d"
+                             % (inducing.points.shape[0], d))
+        key = (id(points), points.shape, m, d, device)
+        prob = functor._problems.get(key)
+        if prob is None:
+            D, n = points.shape
+            prob = Problem(spec.COV_KIND, n, D, d, m, device=device, chunk_rows=chunk_rows)
+            prob.set_inputs(points)
+            prob._spec, prob._jitter = spec, functor.jitter
+            prob._points_ref = points  # keep the id() stable
+            if len(functor._problems) >= 4:  # resident copies are large; keep a handful
+                functor._problems.pop(next(iter(functor._problems))).close()
+            functor._problems[key] = prob
+        return _Inputs(inducing, points, prob)
+
+    def model_calc(inputs, sigma2):
+        return _Model(inputs, sigma2, variational)
+
+    def model_update_sigma2(model, sigma2):
+        return _Model(model.inputs, sigma2, variational)
+
+    def hyper_lookup(hyper_t, hyper):
+        idx = spec.HyperModule.index_of(hyper_t.kernel, hyper_t.inducing_points, hyper)
+        return float(hyper_t.evaluation.grad[idx])
+
+    Eval = SimpleNamespace(
+        Inducing=SimpleNamespace(calc=inducing_calc, get_points=lambda i: i.points,
+                                 get_kernel=lambda i: i.kernel),
+        Inputs=SimpleNamespace(calc=lambda points, inducing, **kw: inputs_calc(inducing, points, **kw),
+                               get_points=lambda i: i.points),
+        Model=SimpleNamespace(
+            calc=model_calc, update_sigma2=model_update_sigma2,
+            calc_log_evidence=lambda model: model.evaluation(False).l1,   # lib/fitc_gp.ml:238
+            get_sigma2=lambda model: model.sigma2, get_inputs=lambda model: model.inputs,
+            get_inducing=lambda model: model.inputs.inducing,
+            get_kernel=lambda model: model.inputs.inducing.kernel),
+        Trained=SimpleNamespace(
+            calc=lambda model, targets: _Trained(model, targets, False),   # multim_f, :1601-1610
+            calc_log_evidence=lambda trained: trained.evaluation().l,      # :295
+            calc_mean_coeffs=lambda trained: trained.evaluation().coeffs,  # :294
+            get_model=lambda trained: trained.model, get_targets=lambda trained: trained.targets),
+    )
+
+    def prepare_hyper_model(model):
+        return _HyperT(model.evaluation(True), model.inputs.inducing.kernel, model.inputs.inducing.points, spec)
+
+    def prepare_hyper_trained(trained):
+        inducing = trained.model.inputs.inducing
+        return _HyperT(trained.evaluation(), inducing.kernel, inducing.points, spec)
+
+    def self_test(kernel, inducing_points, points, sigma2, targets, hyper, eps=1e-8, tol=1e-2):
+        """Deriv.Test.self_test (lib/fitc_gp.ml:1398-1462): forward finite difference of the model and
+        trained log evidence against the analytic derivative; raises like the reference's failwithf."""
+        def evals(k, z, s2):
+            ind = inducing_calc(k, z)
+            inp = inputs_calc(ind, points)
+            mod = model_calc(inp, s2)
+            return mod, _Trained(mod, targets, True)
+
+        mod1, tr1 = evals(kernel, inducing_points, sigma2)
+        if hyper == "Sigma2":
+            mod2, tr2 = evals(kernel, inducing_points, sigma2 + eps)
+            checks = [("sigma2(model)", mod1.evaluation(True).l1, mod2.evaluation(False).l1,
+                       mod1.evaluation(True).dl_dsigma2),
+                      ("sigma2(trained)", tr1.evaluation().l, tr2.evaluation().l, tr1.evaluation().dl_dsigma2)]
+        else:
+            value = spec.HyperModule.get_value(kernel, inducing_points, points, hyper)
+            k2, z2, _ = spec.HyperModule.set_values(kernel, inducing_points, points, [hyper], [value + eps])
+            mod2, tr2 = evals(k2, z2, sigma2)
+            checks = [("hyper(model)", mod1.evaluation(True).l1, mod2.evaluation(False).l1,
+                       hyper_lookup(prepare_hyper_model(mod1), hyper)),
+                      ("hyper(trained)", tr1.evaluation().l, tr2.evaluation().l,
+                       hyper_lookup(prepare_hyper_trained(tr1), hyper))]
+        for name, before, after, deriv in checks:
+            finite_el = (after - before) / eps
+            if not (abs(finite_el - deriv) <= tol):  # is_bad_deriv, :1219-1221 (NaN-safe)
+                raise AssertionError(
+                    "Gpr.Fitc_gp.Make_deriv.Test.self_test: finite difference (%f) and derivative (%f) "
+                    "differ by more than %f on %s" % (finite_el, deriv, tol, name))
+
+    def calc_gradient(learn_sigma2, sigma2, hypers, trained):
+        """Optim.calc_gradient (lib/fitc_gp.ml:1674-1694)."""
+        ev = trained.evaluation()
+        ht = prepare_hyper_trained(trained)
+        g = [hyper_lookup(ht, h) for h in hypers]
+        if learn_sigma2:
+            g = [ev.dl_dsigma2 * sigma2] + g
+        return np.array(g)
+
+    Deriv = SimpleNamespace(
+        Spec=spec,
+        Inducing=SimpleNamespace(calc=inducing_calc, calc_eval=lambda i: i),
+        Inputs=SimpleNamespace(calc=inputs_calc, calc_eval=lambda i: i),
+        Model=SimpleNamespace(
+            calc=model_calc, update_sigma2=model_update_sigma2, calc_eval=lambda m: m,
+            calc_log_evidence_sigma2=lambda model: model.evaluation(True).dl_dsigma2,  # :1121-1122
+            prepare_hyper=prepare_hyper_model, calc_log_evidence=hyper_lookup),
+        Trained=SimpleNamespace(
+            calc=lambda model, targets: _Trained(model, targets, True),                 # :1158-1181
+            calc_eval=lambda t: t,
+            calc_log_evidence_sigma2=lambda trained: trained.evaluation().dl_dsigma2,   # :1187-1188
+            prepare_hyper=prepare_hyper_trained, calc_log_evidence=hyper_lookup),
+        Test=SimpleNamespace(self_test=self_test),
+        Optim=SimpleNamespace(calc_gradient=calc_gradient),
+    )
+    return SimpleNamespace(Eval=Eval, Deriv=Deriv)
+
+
+class Make_deriv:
+    """Fitc_gp.Make_deriv (lib/fitc_gp.mli:120-135).  `spec` is gpr_amd.cov_se_iso or gpr_amd.cov_se_fat."""
+
+    def __init__(self, spec, jitter=CHOLESKY_JITTER):
+        self.spec = spec
+        self.jitter = jitter  # read once at functor application, like lib/fitc_gp.ml:33
+        self._problems = {}
+        self.FITC = _make_variant(spec, False, self)
+        self.Variational_FITC = _make_variant(spec, True, self)
+        self.FIC = self.FITC
+        self.Variational_FIC = self.Variational_FITC
+
+    def close(self):
+        for p in self._problems.values():
+            p.close()
+        self._problems.clear()

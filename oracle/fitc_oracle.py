@@ -74,11 +74,11 @@ def _sqr_diff_cross(inputs, inducing):
     accumulated over i in increasing order (same rounding as the scalar loop)."""
     d, n = inputs.shape
     m = inducing.shape[1]
-    res = np.zeros((n, m), order="F")
+    res_t = np.zeros((m, n))  # C-order (m, n) == Fortran (n, m): contiguous along r like the reference
     for i in range(d):
-        diff = inputs[i, :][:, None] - inducing[i, :][None, :]
-        res += diff * diff
-    return res
+        diff = inputs[i, :][None, :] - inducing[i, :][:, None]
+        res_t += diff * diff
+    return res_t.T
 
 
 def se_iso_calc_sqr_diff_upper(inducing):
@@ -336,10 +336,12 @@ def model_calc_internal(inducing, knm, sigma2, kn_diag, v_mat, r_vec):
     q_mat = np.zeros((n + m, m), order="F")
     q_mat[:n, :] = knm * sqrt_is_vec[:, None]  # lacpy + scal_rows
     q_mat[n:, :] = np.triu(inducing["chol_km"])
-    qr, tau, _, info = lapack.dgeqrf(q_mat)
+    lwork = int(lapack.dgeqrf_lwork(n + m, m)[0])  # blocked Householder QR (workspace query)
+    qr, tau, _, info = lapack.dgeqrf(q_mat, lwork=lwork)
     assert info == 0
     r_mat = np.triu(qr[:m, :m]).copy(order="F")
-    q_full, _, info = lapack.dorgqr(qr, tau)
+    q_full, work, info = lapack.dorgqr(qr, tau, lwork=-1)  # workspace query
+    q_full, _, info = lapack.dorgqr(qr, tau, lwork=int(work[0]))
     assert info == 0
     q_full = _F(q_full)
     log_det_r = 0.0

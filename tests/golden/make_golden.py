@@ -1,0 +1,92 @@
+"""Regenerates tests/golden/*.npz from the CPU oracle (oracle/fitc_oracle.py).
+
+The reference (OCaml) cannot be run in the build image and ships no golden vectors, so these
+fixtures are outputs of the oracle's reference-sequence evaluation (`evaluate`: per-hyper traces,
+QR-based model) on seeded inputs.  They pin (a) the oracle against accidental change and (b) the
+HIP path on the GPU box, where the oracle's own runtime deps (numpy/scipy) are also present.
+
+    python tests/golden/make_golden.py
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from oracle import fitc_oracle as O  # noqa: E402
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def synth(seed, n, m, d):
+    """BASELINE.md section 2 generator (numpy PCG64)."""
+    rng = np.random.default_rng(seed)
+    X = rng.normal(size=(d, n))
+    y = np.sin(X.sum(0)) + 0.1 * rng.normal(size=n)
+    Z = X[:, rng.permutation(n)[:m]] + 0.01 * rng.normal(size=(d, m))
+    return np.asfortranarray(X), y, np.asfortranarray(Z)
+
+
+def gen_data_1d(seed, n, m):
+    """test/gen_data.ml:23-44 recipe: f(x) = sin(3x)/x + |x-3|/(x^2+1), noise sigma 0.7, x ~ U(-5,5)."""
+    rng = np.random.default_rng(seed)
+    x = rng.uniform(-5.0, 5.0, size=n)
+    y = np.sin(3 * x) / x + np.abs(x - 3) / (x * x + 1) + 0.7 * rng.normal(size=n)
+    Z = x[rng.permutation(n)[:m]][None, :].copy()
+    return np.asfortranarray(x[None, :]), y, np.asfortranarray(Z)
+
+
+def save(name, k, X, y, Z, sigma2, variational, extra):
+    out = O.evaluate(k, Z, X, y, sigma2, variational=variational, keep=True)
+    np.savez_compressed(
+        os.path.join(HERE, name + ".npz"), X=X, y=y, Z=Z, sigma2=sigma2, variational=variational,
+        l1=out["l1"], l2=out["l2"], l=out["l"], dl_dsigma2=out["dl_dsigma2"], grad=out["grad"],
+        coeffs=out["coeffs"], model_dl_dsigma2=out["model_dl_dsigma2"], model_grad=out["model_grad"],
+        r_vec=out["model"]["r_vec"], is_vec=out["model"]["is_vec"], v_vec=out["trained"]["v_vec"],
+        w_vec=out["trained"]["w_vec"], **extra)
+    print(name, "l=%.12g" % out["l"], "n_hypers=%d" % len(out["grad"]))
+
+
+def main():
+    # C1 shape of BASELINE.json (n=2000 m=50 d=3), seed 1, standard + variational
+    X, y, Z = synth(1, 2000, 50, 3)
+    le = 0.5 * np.log(3)
+    for var in (False, True):
+        save("iso_c1" + ("_var" if var else ""), O.SeIsoKernel(le, 0.0), X, y, Z, 0.1, var,
+             dict(kind="iso", log_ell=le, log_sf2=0.0))
+    # test_derivatives.ml shape: n=10, m=5, D=3
+    X, y, Z = synth(7, 10, 5, 3)
+    save("iso_tiny", O.SeIsoKernel(0.1, -0.2), X, y, Z, 1.0, False, dict(kind="iso", log_ell=0.1, log_sf2=-0.2))
+    # ragged sizes (not multiples of any tile), d=8
+    X, y, Z = synth(11, 777, 131, 8)
+    le = 0.5 * np.log(8)
+    save("iso_ragged", O.SeIsoKernel(le, 0.3), X, y, Z, 0.05, False, dict(kind="iso", log_ell=le, log_sf2=0.3))
+    # save_data.ml recipe (1-D function), n=1000, m=10
+    X, y, Z = gen_data_1d(3, 1000, 10)
+    save("iso_gen_data", O.SeIsoKernel(0.0, 0.0), X, y, Z, 0.49, False, dict(kind="iso", log_ell=0.0, log_sf2=0.0))
+    # Cov_se_fat with a general projection (D=5 -> d=3) and the ARD special case (diagonal tproj)
+    rng = np.random.default_rng(21)
+    Xb = np.asfortranarray(rng.normal(size=(5, 400)))
+    yb = np.sin(Xb.sum(0)) + 0.1 * rng.normal(size=400)
+    P = np.asfortranarray(0.5 * rng.normal(size=(5, 3)))
+    kf = O.SeFatKernel(3, 0.2, P)
+    Zf = np.asfortranarray(O.se_fat_project(kf, Xb[:, rng.permutation(400)[:20]]) + 0.01 * rng.normal(size=(3, 20)))
+    for var in (False, True):
+        save("fat_proj" + ("_var" if var else ""), kf, Xb, yb, Zf, 0.1, var,
+             dict(kind="fat", d=3, log_sf2=0.2, tproj=P))
+    ell = rng.uniform(-0.5, 0.5, size=4)
+    Pd = np.asfortranarray(np.diag(np.exp(-ell)))
+    Xa = np.asfortranarray(rng.normal(size=(4, 300)))
+    ya = np.sin(Xa.sum(0)) + 0.1 * rng.normal(size=300)
+    ka = O.SeFatKernel(4, 0.0, Pd)
+    Za = np.asfortranarray(O.se_fat_project(ka, Xa[:, :16]) + 0.01 * rng.normal(size=(4, 16)))
+    save("fat_ard", ka, Xa, ya, Za, 0.1, False, dict(kind="fat", d=4, log_sf2=0.0, tproj=Pd))
+    # Cov_se_fat without projection
+    kn = O.SeFatKernel(4, -0.1, None)
+    save("fat_noproj", kn, Xa, ya, np.asfortranarray(Xa[:, :16] + 0.01), 0.2, False,
+         dict(kind="fat", d=4, log_sf2=-0.1))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,134 @@
+"""CPU test double with the staged interface of gpr_amd.Problem (eval_pass1 / eval_pass2 /
+eval_finish on caller-owned exchange buffers).
+
+TEST INFRASTRUCTURE ONLY: lets the world_size-2 gloo tests exercise the row-sharding and
+all-reduce logic of gpr_amd.dist without a GPU.  It restates in numpy the *build's* two-pass
+formulation (SYRK + potrf(B) instead of the reference's stacked QR) on top of
+the oracle's covariance functions, so it doubles as an independent check of that algebra against
+the reference-sequence oracle.
+"""
+import ctypes
+
+import numpy as np
+import scipy.linalg as sl
+
+from oracle import fitc_oracle as O
+from gpr_amd.problem import Evaluation
+
+
+def _view(ptr, length):
+    return np.ctypeslib.as_array((ctypes.c_double * length).from_address(ptr))
+
+
+class StagedDouble:
+    def __init__(self, kernel_factory, n, D, d, m):
+        """kernel_factory(log_ell, log_sf2, tproj) -> oracle kernel object."""
+        self.kernel_factory, self.n, self.D, self.d, self.m = kernel_factory, n, D, d, m
+
+    def ar1_len(self):
+        return self.m * self.m + self.m + 4
+
+    def ar2_len(self):
+        return self.m * self.m + (self.d + 1) * self.m + 8
+
+    def set_inputs(self, x):
+        self.X = np.asfortranarray(x, dtype=np.float64)
+
+    def set_targets(self, y):
+        self.y = np.asarray(y, dtype=np.float64)
+
+    def sync(self):
+        pass
+
+    def eval_pass1(self, ar1_ptr, n_total, *, log_sf2, sigma2, inducing, log_ell=0.0, tproj=None,
+                   variational=False, model_only=False, want_grad=True, jitter=1e-6):
+        m = self.m
+        self.k = self.kernel_factory(log_ell, log_sf2, tproj)
+        self.Z = np.asfortranarray(inducing)
+        self.sigma2, self.variational, self.model_only = sigma2, variational, model_only
+        self.want_grad, self.n_total, self.jitter = want_grad, n_total, jitter
+        km, self.su = O.spec_calc_shared_upper(self.k, self.Z)
+        self.km = np.triu(km) + np.triu(km, 1).T
+        self.kj = self.km + jitter * np.eye(m)
+        self.U = np.linalg.cholesky(self.kj).T
+        self.Ui = sl.solve_triangular(self.U, np.eye(m))
+        self.K, self.sc = O.spec_calc_shared_cross(self.k, self.X, self.Z)
+        V = self.K @ self.Ui
+        self.r = self.k.sf2 - np.sum(V * V, axis=1)
+        s = self.r + sigma2
+        self.is_ = 1.0 / s
+        self.A1 = V @ self.Ui.T
+        yy = np.zeros(self.n) if model_only else self.y
+        ar1 = _view(ar1_ptr, self.ar1_len())
+        ar1[:m * m] = ((self.K * self.is_[:, None]).T @ self.K).reshape(-1)
+        ar1[m * m:m * m + m] = self.K.T @ (self.is_ * yy)
+        ar1[m * m + m:] = [np.sum(np.log(s)), np.sum(self.is_ * yy * yy), np.sum(self.is_ * self.r), 0.0]
+
+    def eval_pass2(self, ar1_ptr, ar2_ptr):
+        m, d = self.m, self.d
+        ar1 = _view(ar1_ptr, self.ar1_len())
+        self.tail1 = ar1[m * m + m:].copy()
+        B = self.kj + ar1[:m * m].reshape(m, m)
+        c = ar1[m * m:m * m + m]
+        self.R = np.linalg.cholesky(B).T
+        Ri = sl.solve_triangular(self.R, np.eye(m))
+        b = Ri.T @ c
+        self.t = Ri @ b
+        self.kminv, self.binv = self.Ui @ self.Ui.T, Ri @ Ri.T
+        Q = self.K @ Ri
+        q = self.is_ * np.sum(Q * Q, axis=1)
+        yy = np.zeros(self.n) if self.model_only else self.y
+        res = 0.0 * yy if self.model_only else yy - Q @ b
+        w = self.is_ * res
+        v1 = self.is_ * (2.0 - self.is_ * self.r - q) if self.variational else self.is_ * (1.0 - q)
+        v = v1 - w * w
+        S = Q @ Ri.T
+        Xm = self.is_[:, None] * S - v[:, None] * self.A1 - np.outer(w, self.t)
+        E = Xm * self.K
+        pts = self.sc["inputs"] if isinstance(self.k, O.SeIsoKernel) else self.sc["projections"]
+        sq = np.zeros_like(E)
+        for i in range(d):
+            df = pts[i, :][:, None] - self.Z[i, :][None, :]
+            sq += df * df
+        ar2 = _view(ar2_ptr, self.ar2_len())
+        ar2[:m * m] = ((self.A1 * v[:, None]).T @ self.A1).reshape(-1)
+        col = np.vstack([E.sum(0)[None, :], pts @ E])
+        ar2[m * m:m * m + (d + 1) * m] = col.reshape(-1)
+        ar2[m * m + (d + 1) * m:] = [v.sum(), self.is_.sum(), np.sum(w * res), v1.sum(), E.sum(),
+                                     np.sum(E * sq), 0.0, 0.0]
+
+    def eval_finish(self, ar2_ptr):
+        m, d = self.m, self.d
+        ar2 = _view(ar2_ptr, self.ar2_len())
+        G = ar2[:m * m].reshape(m, m)
+        col = ar2[m * m:m * m + (d + 1) * m].reshape(d + 1, m)
+        tail = ar2[m * m + (d + 1) * m:]
+        logdet_b = 2 * np.sum(np.log(np.diag(self.R)))
+        logdet_km = 2 * np.sum(np.log(np.diag(self.U)))
+        l1 = -0.5 * (logdet_b - logdet_km + self.tail1[0] + self.n_total * O.LOG_2PI)
+        if self.variational:
+            l1 += -0.5 * self.tail1[2]
+        ut = self.U @ self.t
+        l2 = 0.0 if self.model_only else -0.5 * (tail[2] + ut @ ut)
+        if not self.want_grad:
+            return Evaluation(l1, l2, l1 + l2, None, None, self.t.copy())
+        W = self.kminv - self.binv - np.outer(self.t, self.t) - G
+        dls2 = -0.5 * (tail[0] - tail[1] if self.variational else tail[0])
+        iso = isinstance(self.k, O.SeIsoKernel)
+        scale = self.k.inv_ell2 if iso else 1.0
+        wk = W * self.km
+        g_sf2 = -0.5 * (self.k.sf2 * tail[0] - wk.sum()) - tail[4]
+        zq = np.zeros((m, m))
+        for i in range(d):
+            df = self.Z[i, :][:, None] - self.Z[i, :][None, :]
+            zq += df * df
+        gi = np.empty((m, d))
+        for k_ in range(d):
+            zp = np.sum(wk * (self.Z[k_, :][:, None] - self.Z[k_, :][None, :]), axis=0)
+            gi[:, k_] = scale * zp - scale * (col[k_ + 1] - self.Z[k_, :] * col[0])
+        if iso:
+            g_ell = 0.5 * scale * np.sum(wk * zq) - scale * tail[5]
+            grad = np.concatenate([[g_ell, g_sf2], gi.reshape(-1)])
+        else:
+            grad = np.concatenate([[g_sf2], gi.reshape(-1)])
+        return Evaluation(l1, l2, l1 + l2, dls2, grad, self.t.copy())

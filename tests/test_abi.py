@@ -1,0 +1,53 @@
+"""The C-ABI library loads without a GPU and exports every symbol include/gprhip.h declares."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "gprhip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(gprhip_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_declares_expected_entry_points():
+    syms = declared_symbols()
+    for must in ("gprhip_problem_create", "gprhip_eval", "gprhip_eval_pass1", "gprhip_eval_pass2",
+                 "gprhip_eval_finish", "gprhip_last_error"):
+        assert must in syms
+
+
+def test_library_exports_every_declared_symbol():
+    from gpr_amd import _lib
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for name in declared_symbols():
+        assert hasattr(lib, name), "libgprhip.so does not export %s" % name
+
+
+def test_binding_table_matches_header():
+    from gpr_amd import _lib
+    assert sorted(_lib.SIGNATURES) == declared_symbols()
+
+
+def test_no_device_fails_loudly(gpu_available):
+    """There is no CPU fallback: creating a problem without a GPU raises."""
+    import gpr_amd
+    if gpu_available:
+        pytest.skip("a GPU is present")
+    with pytest.raises(gpr_amd.GprHipError):
+        gpr_amd.Problem(gpr_amd.COV_SE_ISO, 10, 2, 2, 3)
+
+
+def test_product_never_imports_oracle():
+    """oracle/ is test infrastructure: nothing under gpr_amd/ may import or execute it."""
+    pkg = os.path.join(ROOT, "gpr_amd")
+    pat = re.compile(r"(^|\n)\s*(from|import)\s+oracle\b|fitc_oracle|staged_double")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".cpp", ".h")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not pat.search(src), "%s references the oracle" % os.path.join(dirpath, f)

@@ -1,0 +1,228 @@
+"""Parity of the HIP path (through the C ABI) with the CPU oracle and the golden fixtures.
+
+Stated fp64 tolerances.  The device path forms B = K_m + K_mn S^-1 K_nm and
+factors it by Cholesky (the north-star formulation) where the reference runs a Householder QR of
+the stacked matrix, so agreement is limited by cond(B)*eps rather than by eps:
+"""
+import numpy as np
+import pytest
+
+import gpr_amd
+from gpr_amd import cov_se_fat, cov_se_iso, fitc_gp
+from oracle import fitc_oracle as O
+from tests.util import golden_names, load_golden, oracle_kernel, relinf, synth
+
+pytestmark = pytest.mark.gpu
+
+TOL_L = 5e-8        # |l - l_ref| <= TOL_L * |l_ref|   (also l1)
+TOL_DS2 = 2e-6      # dl/dsigma2, relative
+TOL_GRAD = 2e-5     # gradient, max-abs error relative to max-abs entry
+TOL_COEFF = 2e-5    # mean coefficients t, same norm
+TOL_ROW = 1e-9      # per-row intermediates r, 1/s (before any m x m solve with B)
+
+
+def _problem_for(g, chunk_rows=0):
+    X, Z = g["X"], g["Z"]
+    D, n = X.shape
+    d, m = Z.shape
+    kind = gpr_amd.COV_SE_ISO if g["kind"] == "iso" else gpr_amd.COV_SE_FAT
+    p = gpr_amd.Problem(kind, n, D, d, m, chunk_rows=chunk_rows)
+    p.set_inputs(X)
+    p.set_targets(g["y"])
+    return p
+
+
+def _eval_golden(p, g, **kw):
+    args = dict(log_sf2=float(g["log_sf2"]), sigma2=float(g["sigma2"]), inducing=g["Z"],
+                variational=bool(g["variational"]))
+    if g["kind"] == "iso":
+        args["log_ell"] = float(g["log_ell"])
+    elif "tproj" in g:
+        args["tproj"] = g["tproj"]
+    args.update(kw)
+    return p.eval(**args)
+
+
+ISO_GOLDEN = [n for n in golden_names() if n.startswith("iso")]
+
+
+@pytest.mark.parametrize("name", ISO_GOLDEN)
+def test_golden_iso(name):
+    g = load_golden(name)
+    p = _problem_for(g)
+    ev = _eval_golden(p, g)
+    assert abs(ev.l1 - g["l1"]) <= TOL_L * abs(g["l1"])
+    assert abs(ev.l - g["l"]) <= TOL_L * abs(g["l"])
+    assert abs(ev.dl_dsigma2 - g["dl_dsigma2"]) <= TOL_DS2 * abs(g["dl_dsigma2"])
+    assert ev.grad.shape == g["grad"].shape
+    assert relinf(ev.grad, g["grad"]) <= TOL_GRAD
+    assert relinf(ev.coeffs, g["coeffs"]) <= TOL_COEFF
+    assert relinf(p.debug_fetch("r"), g["r_vec"]) <= TOL_ROW
+    assert relinf(p.debug_fetch("is"), g["is_vec"]) <= TOL_ROW
+    assert relinf(p.debug_fetch("v"), g["v_vec"]) <= TOL_GRAD
+    assert relinf(p.debug_fetch("w"), g["w_vec"]) <= TOL_GRAD
+    # evidence-only entry point (multim_f) agrees with the gradient one
+    ev0 = _eval_golden(p, g, want_grad=False)
+    assert abs(ev0.l - ev.l) <= 1e-12 * abs(ev.l)
+    # model-only gradient (Deriv.Model.prepare_hyper / calc_log_evidence)
+    evm = _eval_golden(p, g, model_only=True)
+    assert abs(evm.l - g["l1"]) <= TOL_L * abs(g["l1"])
+    assert abs(evm.dl_dsigma2 - g["model_dl_dsigma2"]) <= TOL_DS2 * abs(g["model_dl_dsigma2"])
+    assert relinf(evm.grad, g["model_grad"]) <= TOL_GRAD
+    p.close()
+
+
+def test_chunking_does_not_change_results():
+    g = load_golden("iso_ragged")
+    p1, p2 = _problem_for(g), _problem_for(g, chunk_rows=256)
+    a, b = _eval_golden(p1, g), _eval_golden(p2, g)
+    assert abs(a.l - b.l) <= 1e-11 * abs(a.l)
+    assert relinf(a.grad, b.grad) <= 1e-9
+    p1.close()
+    p2.close()
+
+
+def test_mid_size_against_oracle():
+    n, m, d = 20000, 256, 8
+    X, y, Z = synth(2, n, m, d)
+    le = 0.5 * np.log(d)
+    ref = O.evaluate_fast(O.SeIsoKernel(le, 0.0), Z, X, y, 0.1)
+    p = gpr_amd.Problem(gpr_amd.COV_SE_ISO, n, d, d, m, chunk_rows=4096)
+    p.set_inputs(X)
+    p.set_targets(y)
+    ev = p.eval(log_ell=le, log_sf2=0.0, sigma2=0.1, inducing=Z)
+    assert abs(ev.l - ref["l"]) <= TOL_L * abs(ref["l"])
+    assert abs(ev.dl_dsigma2 - ref["dl_dsigma2"]) <= TOL_DS2 * abs(ref["dl_dsigma2"])
+    assert relinf(ev.grad, ref["grad"]) <= TOL_GRAD
+    p.close()
+
+
+def test_functor_mirror_and_reference_self_test_recipe():
+    """test/test_derivatives.ml's recipe through the mirrored module surface: finite differences at
+    the reference's eps=1e-8 / tol=1e-2 for sigma2 and every hyper (n=10, m=5, D=3)."""
+    rng = np.random.default_rng(4)
+    X = np.asfortranarray(rng.uniform(size=(3, 10)))
+    y = rng.uniform(size=10)
+    Z = np.asfortranarray(X[:, :5].copy())
+    GP = fitc_gp.Make_deriv(cov_se_iso)
+    FITC = GP.FITC
+    kernel = cov_se_iso.Kernel.create(cov_se_iso.create_default_kernel_params())
+    hypers = FITC.Deriv.Spec.HyperModule.get_all(kernel, Z, X)
+    FITC.Deriv.Test.self_test(kernel, Z, X, sigma2=1.0, targets=y, hyper="Sigma2")
+    for h in hypers:
+        FITC.Deriv.Test.self_test(kernel, Z, X, sigma2=1.0, targets=y, hyper=h)
+    # staged calls of the signature, against the oracle
+    inducing = FITC.Deriv.Inducing.calc(kernel, Z)
+    inputs = FITC.Deriv.Inputs.calc(inducing, X)
+    model = FITC.Deriv.Model.calc(inputs, sigma2=1.0)
+    trained = FITC.Deriv.Trained.calc(model, targets=y)
+    ref = O.evaluate(O.SeIsoKernel(0.0, 0.0), Z, X, y, 1.0)
+    assert abs(FITC.Eval.Trained.calc_log_evidence(FITC.Deriv.Trained.calc_eval(trained)) - ref["l"]) < 1e-9
+    assert abs(FITC.Eval.Model.calc_log_evidence(FITC.Deriv.Model.calc_eval(model)) - ref["l1"]) < 1e-9
+    assert abs(FITC.Deriv.Trained.calc_log_evidence_sigma2(trained) - ref["dl_dsigma2"]) < 1e-8
+    ht = FITC.Deriv.Trained.prepare_hyper(trained)
+    got = np.array([FITC.Deriv.Trained.calc_log_evidence(ht, h) for h in hypers])
+    assert relinf(got, ref["grad"]) < 1e-7
+    hm = FITC.Deriv.Model.prepare_hyper(model)
+    gotm = np.array([FITC.Deriv.Model.calc_log_evidence(hm, h) for h in hypers])
+    assert relinf(gotm, ref["model_grad"]) < 1e-7
+    assert relinf(FITC.Eval.Trained.calc_mean_coeffs(trained), ref["coeffs"]) < 1e-7
+    g = FITC.Deriv.Optim.calc_gradient(True, 1.0, hypers, trained)
+    assert abs(g[0] - ref["dl_dsigma2"] * 1.0) < 1e-8 and relinf(g[1:], ref["grad"]) < 1e-7
+    # variational functor
+    V = GP.Variational_FITC
+    vt = V.Deriv.Trained.calc(V.Deriv.Model.calc(V.Deriv.Inputs.calc(V.Deriv.Inducing.calc(kernel, Z), X), 1.0), y)
+    refv = O.evaluate(O.SeIsoKernel(0.0, 0.0), Z, X, y, 1.0, variational=True)
+    assert abs(V.Eval.Trained.calc_log_evidence(vt) - refv["l"]) < 1e-9
+    GP.close()
+
+
+def test_two_shards_on_one_device_equal_the_whole():
+    """The staged entry points: two row shards whose exchange buffers are summed == one problem."""
+    import torch
+    n, m, d = 3001, 140, 4
+    X, y, Z = synth(12, n, m, d)
+    hyp = dict(log_ell=0.6, log_sf2=0.1, sigma2=0.2, inducing=Z)
+    whole = gpr_amd.Problem(gpr_amd.COV_SE_ISO, n, d, d, m)
+    whole.set_inputs(X)
+    whole.set_targets(y)
+    ref = whole.eval(**hyp)
+    cut = 1234
+    shards = []
+    for lo, hi in ((0, cut), (cut, n)):
+        p = gpr_amd.Problem(gpr_amd.COV_SE_ISO, hi - lo, d, d, m, chunk_rows=512)
+        p.set_inputs(X[:, lo:hi])
+        p.set_targets(y[lo:hi])
+        shards.append(p)
+    dev = torch.device("cuda", 0)
+    ar1 = [torch.zeros(p.ar1_len(), dtype=torch.float64, device=dev) for p in shards]
+    ar2 = [torch.zeros(p.ar2_len(), dtype=torch.float64, device=dev) for p in shards]
+    for p, a in zip(shards, ar1):
+        p.eval_pass1(a.data_ptr(), n, **hyp)
+        p.sync()
+    tot1 = ar1[0] + ar1[1]
+    torch.cuda.synchronize()
+    for p, a in zip(shards, ar2):
+        p.eval_pass2(tot1.data_ptr(), a.data_ptr())
+        p.sync()
+    tot2 = ar2[0] + ar2[1]
+    torch.cuda.synchronize()
+    evs = [p.eval_finish(tot2.data_ptr()) for p in shards]
+    for ev in evs:
+        assert abs(ev.l - ref.l) <= 1e-11 * abs(ref.l)
+        assert abs(ev.dl_dsigma2 - ref.dl_dsigma2) <= 1e-9 * abs(ref.dl_dsigma2)
+        assert relinf(ev.grad, ref.grad) <= 1e-8
+    for p in shards + [whole]:
+        p.close()
+
+
+def test_error_behaviour():
+    X, y, Z = synth(0, 50, 4, 2)
+    p = gpr_amd.Problem(gpr_amd.COV_SE_ISO, 50, 2, 2, 4)
+    p.set_inputs(X)
+    p.set_targets(y)
+    with pytest.raises(gpr_amd.GprHipError, match="sigma2 < 0"):          # lib/fitc_gp.ml:148-149
+        p.eval(log_ell=0.0, log_sf2=0.0, sigma2=-1.0, inducing=Z)
+    Zdup = np.asfortranarray(np.repeat(Z[:, :1], 4, axis=1))
+    with pytest.raises(gpr_amd.NotPositiveDefinite):                        # Lacaml potrf Failure
+        p.eval(log_ell=0.0, log_sf2=0.0, sigma2=0.1, inducing=Zdup, jitter=0.0)
+    # with the reference's jitter the same inducing set factorises (lib/utils.ml:35)
+    ev = p.eval(log_ell=0.0, log_sf2=0.0, sigma2=0.1, inducing=Zdup)
+    assert np.isfinite(ev.l)
+    with pytest.raises(ValueError, match="targets"):                         # lib/fitc_gp.ml:283-284
+        p.set_targets(y[:-1])
+    p.close()
+    with pytest.raises(gpr_amd.GprHipError):
+        gpr_amd.Problem(gpr_amd.COV_SE_ISO, 0, 2, 2, 4)
+
+
+def test_headline_size_properties():
+    """BASELINE.json C2 shape (n=1M, m=2048, d=8): size-independent properties -- run-to-run bitwise
+    determinism, evidence-only == gradient-mode evidence, directional derivative vs a central
+    difference of device evaluations."""
+    n, m, d = 1_000_000, 2048, 8
+    X, y, Z = synth(2, n, m, d)
+    le = 0.5 * np.log(d)
+    p = gpr_amd.Problem(gpr_amd.COV_SE_ISO, n, d, d, m)
+    p.set_inputs(X)
+    p.set_targets(y)
+    hyp = dict(log_ell=le, log_sf2=0.0, sigma2=0.1, inducing=Z)
+    a = p.eval(**hyp)
+    b = p.eval(**hyp)
+    assert a.l == b.l and np.array_equal(a.grad, b.grad)
+    assert np.isfinite(a.l) and np.all(np.isfinite(a.grad))
+    l0 = p.eval(want_grad=False, **hyp).l
+    assert abs(l0 - a.l) <= 1e-12 * abs(a.l)
+    rng = np.random.default_rng(0)
+    dz = rng.normal(size=Z.shape)
+    dz /= np.linalg.norm(dz)
+    dle, dls, ds2 = 0.3, -0.2, 0.05
+    eps = 1e-4
+    plus = p.eval(want_grad=False, log_ell=le + eps * dle, log_sf2=eps * dls, sigma2=0.1 + eps * ds2,
+                  inducing=Z + eps * dz).l
+    minus = p.eval(want_grad=False, log_ell=le - eps * dle, log_sf2=-eps * dls, sigma2=0.1 - eps * ds2,
+                   inducing=Z - eps * dz).l
+    fd = (plus - minus) / (2 * eps)
+    analytic = a.grad[0] * dle + a.grad[1] * dls + a.dl_dsigma2 * ds2 + float(a.grad[2:] @ dz.T.reshape(-1))
+    assert abs(fd - analytic) <= 1e-5 * max(abs(analytic), abs(a.l) * 1e-6)
+    p.close()

@@ -1,0 +1,138 @@
+"""Host-side logic that needs no GPU: hyper-parameter enumeration / get / set of the two covariance
+specs, row sharding, and the world_size-2 all-reduce path of gpr_amd.dist over gloo with the CPU
+staged double standing in for the device."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from gpr_amd import cov_se_fat, cov_se_iso
+from gpr_amd.dist import ShardedProblem, shard_rows
+from oracle import fitc_oracle as O
+from tests.staged_double import StagedDouble
+from tests.util import relinf, synth
+
+
+def test_iso_hyper_enumeration_matches_reference_order():
+    k = cov_se_iso.Kernel.create(cov_se_iso.Params(0.3, -0.2))
+    Z = np.asfortranarray(np.arange(6.0).reshape(2, 3))
+    hs = cov_se_iso.HyperModule.get_all(k, Z)
+    assert hs[:2] == ["Log_ell", "Log_sf2"]
+    assert hs[2:] == [cov_se_iso.Inducing_hyper(i, d) for i in (1, 2, 3) for d in (1, 2)]
+    assert [cov_se_iso.HyperModule.index_of(k, Z, h) for h in hs] == list(range(len(hs)))
+    assert cov_se_iso.HyperModule.get_value(k, Z, None, hs[0]) == 0.3
+    assert cov_se_iso.HyperModule.get_value(k, Z, None, cov_se_iso.Inducing_hyper(3, 2)) == Z[1, 2]
+    oracle_order = O.se_iso_hypers(2, 3)
+    assert [(h if isinstance(h, str) else ("inducing", h.ind, h.dim)) for h in hs][2:] == oracle_order[2:]
+
+
+def test_iso_set_values_copies_inducing_lazily():
+    k = cov_se_iso.Kernel.create(cov_se_iso.Params(0.0, 0.0))
+    Z = np.asfortranarray(np.zeros((2, 3)))
+    k2, Z2, _ = cov_se_iso.HyperModule.set_values(k, Z, None, ["Log_sf2"], [1.5])
+    assert Z2 is Z and k2.params.log_sf2 == 1.5 and abs(k2.sf2 - np.exp(1.5)) < 1e-15
+    k3, Z3, _ = cov_se_iso.HyperModule.set_values(k, Z, None, [cov_se_iso.Inducing_hyper(2, 1)], [7.0])
+    assert Z3 is not Z and Z3[0, 1] == 7.0 and Z[0, 1] == 0.0
+    assert abs(k.inv_ell2_05 + 0.5) < 1e-15
+
+
+def test_fat_hypers_and_param_checks():
+    with pytest.raises(ValueError, match="disagrees with target dimension"):
+        cov_se_fat.Params.create(3, 0.0, tproj=np.ones((5, 2)))
+    with pytest.raises(NotImplementedError):
+        cov_se_fat.Params.create(3, 0.0, log_hetero_skedasticity=np.zeros(4))
+    P = np.ones((3, 2))
+    k = cov_se_fat.Kernel.create(cov_se_fat.Params.create(2, 0.1, P))
+    Z = np.zeros((2, 2), order="F")
+    hs = cov_se_fat.HyperModule.get_all(k, Z)
+    assert hs[0] == "Log_sf2" and len(hs) == 1 + 4 + 6
+    assert hs[5:] == [cov_se_fat.Proj_hyper(b, s) for b in (1, 2, 3) for s in (1, 2)]
+    assert [cov_se_fat.HyperModule.index_of(k, Z, h) for h in hs] == list(range(len(hs)))
+    k2, _, _ = cov_se_fat.HyperModule.set_values(k, Z, None, [cov_se_fat.Proj_hyper(3, 2)], [9.0])
+    assert k2.params.tproj[2, 1] == 9.0 and k.params.tproj[2, 1] == 1.0
+
+
+def test_shard_rows_partitions_exactly():
+    for n, w in ((1_000_000, 8), (10, 3), (7, 7), (1001, 4)):
+        spans = [shard_rows(n, r, w) for r in range(w)]
+        assert spans[0][0] == 0 and spans[-1][1] == n
+        assert all(spans[i][1] == spans[i + 1][0] for i in range(w - 1))
+        sizes = [hi - lo for lo, hi in spans]
+        assert max(sizes) - min(sizes) <= 1
+
+
+def _factory(log_ell, log_sf2, tproj):
+    return O.SeIsoKernel(log_ell, log_sf2)
+
+
+@pytest.mark.parametrize("variational", [False, True])
+def test_staged_double_matches_reference_sequence_oracle(variational):
+    """The build's two-pass formulation (numpy restatement) against the reference-sequence oracle."""
+    X, y, Z = synth(6, 400, 20, 3)
+    le = 0.5 * np.log(3)
+    ref = O.evaluate_fast(O.SeIsoKernel(le, 0.1), Z, X, y, 0.1, variational=variational)
+    sd = StagedDouble(_factory, 400, 3, 3, 20)
+    sp = ShardedProblem(0, 400, 3, 3, 20, rank=0, world=1, backend=sd)
+    sp.set_inputs(X)
+    sp.set_targets(y)
+    ev = sp.eval(log_ell=le, log_sf2=0.1, sigma2=0.1, inducing=Z, variational=variational)
+    assert abs(ev.l - ref["l"]) < 1e-9 * abs(ref["l"])
+    assert abs(ev.dl_dsigma2 - ref["dl_dsigma2"]) < 1e-7 * abs(ref["dl_dsigma2"])
+    assert relinf(ev.grad, ref["grad"]) < 1e-6
+    assert relinf(ev.coeffs, ref["coeffs"]) < 1e-6
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        n, m, d = 501, 16, 3
+        X, y, Z = synth(8, n, m, d)
+        lo, hi = shard_rows(n, rank, world)
+        sd = StagedDouble(_factory, hi - lo, d, d, m)
+        sp = ShardedProblem(0, n, d, d, m, backend=sd)
+        sp.set_inputs(X[:, lo:hi])
+        sp.set_targets(y[lo:hi])
+        ev = sp.eval(log_ell=0.4, log_sf2=0.0, sigma2=0.1, inducing=Z)
+        ev0 = sp.eval(log_ell=0.4, log_sf2=0.0, sigma2=0.1, inducing=Z, want_grad=False)
+        q.put((rank, ev.l, ev.dl_dsigma2, ev.grad, ev0.l))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_world_size_2_sharded_eval_over_gloo():
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    n, m, d = 501, 16, 3
+    X, y, Z = synth(8, n, m, d)
+    ref = O.evaluate_fast(O.SeIsoKernel(0.4, 0.0), Z, X, y, 0.1)
+    for rank, l, dls2, grad, l0 in results:
+        assert abs(l - ref["l"]) < 1e-9 * abs(ref["l"])
+        assert abs(l0 - ref["l"]) < 1e-9 * abs(ref["l"])
+        assert abs(dls2 - ref["dl_dsigma2"]) < 1e-7 * abs(ref["dl_dsigma2"])
+        assert relinf(grad, ref["grad"]) < 1e-6
+    # every rank returns the same numbers (replicated m x m work on identical reduced buffers)
+    assert results[0][1] == results[1][1]
+    assert np.array_equal(results[0][3], results[1][3])

@@ -1,0 +1,197 @@
+"""Pins the CPU oracle (oracle/fitc_oracle.py).  The reference ships no golden vectors and cannot
+be run here (no OCaml toolchain), so the oracle is pinned by independent known answers:
+dense textbook FITC, finite differences, a 40-digit mpmath evaluation, the formulas of the
+reference's Octave cross-check (test/oct.m), and the reference's own gradient self-test recipe."""
+import numpy as np
+import pytest
+
+from oracle import fitc_oracle as O
+from tests.util import golden_names, load_golden, oracle_kernel, relinf, synth
+
+
+@pytest.mark.parametrize("variational", [False, True])
+def test_qr_path_equals_dense_textbook_fitc(variational):
+    X, y, Z = synth(0, 200, 12, 3)
+    k = O.SeIsoKernel(0.5 * np.log(3), 0.0)
+    out = O.evaluate(k, Z, X, y, 0.1, variational=variational, want_grad=False)
+    dense = O.dense_fitc_log_evidence(k, Z, X, y, 0.1, variational=variational)
+    assert abs(out["l"] - dense) <= 1e-11 * abs(dense)
+
+
+def _central_fd(f, x0, eps=1e-5):
+    return (f(x0 + eps) - f(x0 - eps)) / (2 * eps)
+
+
+@pytest.mark.parametrize("variational", [False, True])
+def test_iso_gradient_against_central_differences(variational):
+    X, y, Z = synth(3, 150, 8, 3)
+    le, ls, s2 = 0.3, -0.1, 0.2
+    k = O.SeIsoKernel(le, ls)
+    out = O.evaluate(k, Z, X, y, s2, variational=variational)
+    L = lambda le_, ls_, Z_, s2_: O.dense_fitc_log_evidence(O.SeIsoKernel(le_, ls_), Z_, X, y, s2_, variational)
+    assert abs(_central_fd(lambda v: L(v, ls, Z, s2), le) - out["grad"][0]) < 1e-5 * max(1, abs(out["grad"][0]))
+    assert abs(_central_fd(lambda v: L(le, v, Z, s2), ls) - out["grad"][1]) < 1e-5 * max(1, abs(out["grad"][1]))
+    assert abs(_central_fd(lambda v: L(le, ls, Z, v), s2) - out["dl_dsigma2"]) < 1e-5 * max(1, abs(out["dl_dsigma2"]))
+    for ind, dim in ((1, 1), (4, 2), (8, 3)):
+        def f(v):
+            Zp = Z.copy()
+            Zp[dim - 1, ind - 1] = v
+            return L(le, ls, Zp, s2)
+        g = out["grad"][2 + (ind - 1) * 3 + dim - 1]
+        assert abs(_central_fd(f, Z[dim - 1, ind - 1]) - g) < 1e-5 * max(1, abs(g))
+
+
+def test_fat_gradient_against_central_differences():
+    rng = np.random.default_rng(5)
+    D, d, n, m = 5, 3, 120, 7
+    X = np.asfortranarray(rng.normal(size=(D, n)))
+    y = np.sin(X.sum(0)) + 0.1 * rng.normal(size=n)
+    P = 0.5 * rng.normal(size=(D, d))
+    k = O.SeFatKernel(d, 0.2, P)
+    Z = np.asfortranarray(O.se_fat_project(k, X[:, :m]) + 0.01)
+    out = O.evaluate(k, Z, X, y, 0.1)
+    hypers = out["hypers"]
+    L = lambda ls_, P_, Z_: O.dense_fitc_log_evidence(O.SeFatKernel(d, ls_, P_), Z_, X, y, 0.1)
+    assert abs(_central_fd(lambda v: L(v, P, Z), 0.2) - out["grad"][0]) < 1e-5 * max(1, abs(out["grad"][0]))
+    for big, small in ((1, 1), (3, 2), (5, 3)):
+        def f(v):
+            Pp = P.copy()
+            Pp[big - 1, small - 1] = v
+            return L(0.2, Pp, Z)
+        g = out["grad"][hypers.index(("proj", big, small))]
+        assert abs(_central_fd(f, P[big - 1, small - 1]) - g) < 1e-5 * max(1, abs(g))
+    def fz(v):
+        Zp = Z.copy()
+        Zp[1, 2] = v
+        return L(0.2, P, Zp)
+    g = out["grad"][hypers.index(("inducing", 3, 2))]
+    assert abs(_central_fd(fz, Z[1, 2]) - g) < 1e-5 * max(1, abs(g))
+
+
+def test_model_only_gradient_is_l1_derivative():
+    X, y, Z = synth(9, 100, 6, 2)
+    k = O.SeIsoKernel(0.2, 0.1)
+    out = O.evaluate(k, Z, X, y, 0.3)
+    l1 = lambda le: O.evaluate(O.SeIsoKernel(le, 0.1), Z, X, y, 0.3, want_grad=False)["l1"]
+    assert abs(_central_fd(l1, 0.2) - out["model_grad"][0]) < 1e-5 * max(1, abs(out["model_grad"][0]))
+    l1s = lambda s2: O.evaluate(k, Z, X, y, s2, want_grad=False)["l1"]
+    assert abs(_central_fd(l1s, 0.3) - out["model_dl_dsigma2"]) < 1e-5 * max(1, abs(out["model_dl_dsigma2"]))
+
+
+def test_against_mpmath_40_digits():
+    mp = pytest.importorskip("mpmath")
+    mp.mp.dps = 40
+    X, y, Z = synth(2, 40, 6, 2)
+    k = O.SeIsoKernel(0.4, 0.0)
+    s2 = 0.05
+    n, m = 40, 6
+    km, _ = O.spec_calc_shared_upper(k, Z)
+    km = np.triu(km) + np.triu(km, 1).T
+    knm, _ = O.spec_calc_shared_cross(k, X, Z)
+    Km = mp.matrix(km.tolist()) + mp.mpf(O.CHOLESKY_JITTER) * mp.eye(m)
+    Knm = mp.matrix(knm.tolist())
+    A1 = Knm * (Km ** -1)
+    s = [mp.mpf(k.sf2) - sum(A1[i, j] * Knm[i, j] for j in range(m)) + mp.mpf(s2) for i in range(n)]
+    B = Km.copy()
+    for i in range(n):
+        for a in range(m):
+            for b in range(m):
+                B[a, b] += Knm[i, a] * Knm[i, b] / s[i]
+    c = mp.matrix([sum(Knm[i, a] * mp.mpf(float(y[i])) / s[i] for i in range(n)) for a in range(m)])
+    t = mp.lu_solve(B, c)
+    l1 = -mp.mpf(0.5) * (mp.log(mp.det(B)) - mp.log(mp.det(Km)) + sum(mp.log(si) for si in s) + n * mp.log(2 * mp.pi))
+    l2 = -mp.mpf(0.5) * (sum(mp.mpf(float(y[i])) ** 2 / s[i] for i in range(n)) - sum(c[a] * t[a] for a in range(m)))
+    out = O.evaluate(k, Z, X, y, s2, want_grad=False)
+    assert abs(out["l1"] - float(l1)) < 1e-10 * abs(float(l1))
+    assert abs(out["l2"] - float(l2)) < 1e-10 * abs(float(l2))
+    assert np.max(np.abs(out["coeffs"] - np.array([float(v) for v in t]))) < 1e-8 * np.max(np.abs(out["coeffs"]))
+
+
+def test_oct_m_identities():
+    """test/oct.m:88-180 -- l = l1 + l2; dl = dl1 + dl2 with W1/X1 (model part) and W2/X2 (target part);
+    dls = dls1 + dls2; variational vl1 = l1 - 0.5 is'r."""
+    X, y, Z = synth(4, 90, 7, 2)
+    k = O.SeIsoKernel(0.1, 0.2)
+    out = O.evaluate(k, Z, X, y, 0.4, keep=True)
+    model, cm, tr = out["model"], out["cm"], out["trained"]
+    n = model["n"]
+    Q = model["q_mat"][:n]
+    y_ = np.sqrt(model["is_vec"]) * y
+    u = y_ - Q @ (Q.T @ y_)
+    assert abs(out["l2"] - (-0.5 * float(u @ y_))) < 1e-12 * abs(out["l2"])       # oct.m:119-122
+    U, S = O.calc_us_mat(model)
+    Tm = O._upper_to_full(cm["t_mat"])
+    v1 = model["is_vec"] * (1 - np.sum(Q * Q, axis=1))                              # oct.m:133
+    w = np.sqrt(model["is_vec"]) * u                                                # oct.m:140
+    v2 = w * w
+    t = S.T @ y                                                                     # oct.m:118
+    assert np.allclose(t, out["coeffs"], rtol=1e-9, atol=1e-12)
+    W1 = Tm - (U * v1[:, None]).T @ U
+    W2 = np.outer(t, t) - (U * v2[:, None]).T @ U
+    X1 = S - U * v1[:, None]
+    X2 = np.outer(w, t) - U * v2[:, None]
+    ht = out["hyper_t"]
+    assert np.allclose(np.triu(W1 - W2), np.triu(ht["w_mat"]), rtol=1e-9, atol=1e-10)  # W = W1 - W2
+    assert np.allclose(X1 - X2, ht["x_mat"], rtol=1e-9, atol=1e-10)                    # X = X1 - X2
+    assert abs(out["dl_dsigma2"] - (-0.5 * v1.sum() + 0.5 * v2.sum())) < 1e-10       # oct.m:149-151
+    assert abs(out["model_dl_dsigma2"] - (-0.5 * v1.sum())) < 1e-10
+    var = O.evaluate(k, Z, X, y, 0.4, variational=True, want_grad=False)
+    assert abs(var["l1"] - (out["l1"] - 0.5 * float(model["is_vec"] @ model["r_vec"]))) < 1e-10  # oct.m:159
+
+
+def test_reference_self_test_recipe():
+    """lib/fitc_gp.ml:1398-1462 at the reference's eps=1e-8 / tol=1e-2, on test_derivatives.ml's shape."""
+    rng = np.random.default_rng(1)
+    X = np.asfortranarray(rng.uniform(size=(3, 10)))
+    y = rng.uniform(size=10)
+    Z = np.asfortranarray(X[:, :5] + 0.0)
+    k = O.SeIsoKernel(0.0, 0.0)
+    out = O.evaluate(k, Z, X, y, 1.0)
+    eps, tol = 1e-8, 1e-2
+    base = out["l"]
+    l_s2 = O.evaluate(k, Z, X, y, 1.0 + eps, want_grad=False)["l"]
+    assert abs((l_s2 - base) / eps - out["dl_dsigma2"]) <= tol
+    for i, h in enumerate(out["hypers"]):
+        if h[0] == "log_ell":
+            k2, Z2 = O.SeIsoKernel(eps, 0.0), Z
+        elif h[0] == "log_sf2":
+            k2, Z2 = O.SeIsoKernel(0.0, eps), Z
+        else:
+            k2, Z2 = k, Z.copy()
+            Z2[h[2] - 1, h[1] - 1] += eps
+        l2 = O.evaluate(k2, Z2, X, y, 1.0, want_grad=False)["l"]
+        assert abs((l2 - base) / eps - out["grad"][i]) <= tol, h
+
+
+@pytest.mark.parametrize("name", golden_names())
+def test_golden_fixtures_reproduce(name):
+    g = load_golden(name)
+    k = oracle_kernel(g)
+    out = O.evaluate(k, g["Z"], g["X"], g["y"], float(g["sigma2"]), variational=bool(g["variational"]))
+    for key in ("l1", "l2", "l", "dl_dsigma2"):
+        assert abs(out[key] - float(g[key])) <= 1e-9 * max(1.0, abs(float(g[key]))), key
+    assert relinf(out["grad"], g["grad"]) < 1e-8
+    assert relinf(out["coeffs"], g["coeffs"]) < 1e-8
+    fast = O.evaluate_fast(k, g["Z"], g["X"], g["y"], float(g["sigma2"]), variational=bool(g["variational"]))
+    assert relinf(fast["grad"], g["grad"]) < 1e-9
+
+
+def test_hyper_order():
+    assert O.se_iso_hypers(2, 2) == [("log_ell",), ("log_sf2",), ("inducing", 1, 1), ("inducing", 1, 2),
+                                     ("inducing", 2, 1), ("inducing", 2, 2)]      # lib/cov_se_iso.ml:188-202
+    k = O.SeFatKernel(2, 0.0, np.ones((3, 2)))
+    hs = O.se_fat_hypers(k, 1)
+    assert hs[:3] == [("log_sf2",), ("inducing", 1, 1), ("inducing", 1, 2)]
+    assert hs[3:] == [("proj", b, s) for b in (1, 2, 3) for s in (1, 2)]           # lib/cov_se_fat.ml:318-326
+
+
+def test_error_behaviour():
+    X, y, Z = synth(0, 20, 3, 2)
+    k = O.SeIsoKernel(0.0, 0.0)
+    with pytest.raises(ValueError, match="sigma2 < 0"):      # lib/fitc_gp.ml:148-149
+        O.evaluate(k, Z, X, y, -1.0)
+    with pytest.raises(ValueError, match="targets"):         # lib/fitc_gp.ml:283-284
+        O.evaluate(k, Z, X, y[:-1], 0.1)
+    Zdup = np.asfortranarray(np.repeat(Z[:, :1], 3, axis=1))
+    # duplicate inducing points are only saved by the jitter (lib/utils.ml:35): still factorises
+    O.evaluate(k, Zdup, X, y, 0.1, want_grad=False)
