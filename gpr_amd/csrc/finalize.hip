@@ -27,10 +27,10 @@ void launch_sum_slices(const double* base, const double* slices, int nslices, in
   GPR_HIP(hipGetLastError());
 }
 
-// W = T - t t^T - U^T diag(v) U with T = Kminv - Binv   (lib/fitc_gp.ml:1196-1203, :1040-1041),
-// written as a full symmetric matrix (upper tiles are the computed ones; the rest is mirrored).
-__global__ __launch_bounds__(256) void build_w_kernel(const double* __restrict__ kminv,
-                                                      const double* __restrict__ binv,
+// Whitened W:  W = T - t t^T - U_mat^T diag(v) U_mat  (lib/fitc_gp.ml:1196-1203, T = K_m^-1 - B^-1 :1040-1041)
+// equals U^-1 W~ U^-T with  W~ = I - B~^-1 - t~ t~^T - V^T diag(v) V,  B~ = I + V^T diag(is) V, t~ = U t.
+// Written as a full symmetric matrix (upper tiles are the computed ones; the rest is mirrored).
+__global__ __launch_bounds__(256) void build_w_kernel(const double* __restrict__ binv,
                                                       const double* __restrict__ t,
                                                       const double* __restrict__ G, int mp,
                                                       double* __restrict__ W) {
@@ -43,13 +43,12 @@ __global__ __launch_bounds__(256) void build_w_kernel(const double* __restrict__
     cc = r;
   }
   const int64_t off = (int64_t)rr * mp + cc;
-  W[(int64_t)r * mp + c] = kminv[off] - binv[off] - t[rr] * t[cc] - G[off];
+  W[(int64_t)r * mp + c] = (r == c ? 1.0 : 0.0) - binv[off] - t[rr] * t[cc] - G[off];
 }
 
-void launch_build_w(const double* kminv, const double* binv, const double* t, const double* G, int mp,
-                    double* W, hipStream_t s) {
-  hipLaunchKernelGGL(build_w_kernel, dim3((mp + 255) / 256, mp), dim3(256), 0, s, kminv, binv, t, G, mp,
-                     W);
+void launch_build_w(const double* binv, const double* t, const double* G, int mp, double* W,
+                    hipStream_t s) {
+  hipLaunchKernelGGL(build_w_kernel, dim3((mp + 255) / 256, mp), dim3(256), 0, s, binv, t, G, mp, W);
   GPR_HIP(hipGetLastError());
 }
 

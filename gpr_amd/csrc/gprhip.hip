@@ -1,13 +1,18 @@
 // C ABI + orchestration of the two-pass streaming FITC evaluation (see include/gprhip.h).
 //
-// Pass 1 (per row chunk):  K = cov(X, Z);  V = K U^-1;  r, s, 1/s;  B_part += K^T diag(1/s) K;
-//                          c += K^T (y/s);  [gradient] A1 = V U^-T (= K K_m^-1), kept in HBM.
-// Exchange 1            :  sum over shards of (B_part, c, sum log s, sum y^2/s, sum r/s).
-// Middle (m x m)        :  R = chol(K_m + jitter + B_part);  t = B^-1 c;  R^-1;  K_m^-1, B^-1.
-// Pass 2 (per row chunk):  Q' = K R^-1;  q_diag, w, v;  S' = Q' R^-T (= K B^-1);
-//                          G_part += A1^T diag(v) A1;  fused gradient accumulators over E = X .* K.
-// Exchange 2            :  sum over shards of (G_part, gradient column accumulators, scalars).
-// Finish                :  W = K_m^-1 - B^-1 - t t^T - G;  traces;  l1, l2, dl/dsigma2, dl/dtheta.
+// Whitened formulation (V = K_nm U^-1 with U = chol(K_m + jitter)): every quantity of the reference's
+// stacked-QR path is obtained from  B~ = I + V^T diag(1/s) V = R~^T R~  -- no K_m^-1 / B^-1 cancellation,
+// QR-grade accuracy from SYRK + potrf.
+// Pass 1 (per row chunk):  K = cov(X, Z);  V = K U^-1 (kept in HBM for pass 2);  r, s, 1/s;
+//                          B~_part += V^T diag(1/s) V;  c~ += V^T (y/s).
+// Exchange 1            :  sum over shards of (B~_part, c~, sum log s, sum y^2/s, sum r/s).
+// Middle (m x m)        :  R~ = chol(I + B~_part);  b = R~^-T c~;  t~ = R~^-1 b;  t = U^-1 t~;  R~^-1.
+//                          l1, l2 are complete here: evidence-only evaluations stop after this.
+// Pass 2 (per row chunk):  Q' = V R~^-1;  q_diag, w, v;  X~ = diag(1/s) Q' R~^-T - diag(v) V - w t~^T
+//                          (fused GEMM epilogue);  X = X~ U^-T;  G~_part += V^T diag(v) V;
+//                          fused gradient accumulators over E = X .* K_nm.
+// Exchange 2            :  sum over shards of (G~_part, gradient column accumulators, scalars).
+// Finish                :  W = U^-1 (I - B~^-1 - t~ t~^T - G~) U^-T;  traces;  dl/dsigma2, dl/dtheta.
 #include <cmath>
 #include <cstring>
 #include <vector>
@@ -35,32 +40,33 @@ __global__ __launch_bounds__(256) void dot_kernel(const double* __restrict__ x,
   if (threadIdx.x == 0) out[0] = red[0];
 }
 
-__global__ void add_upper_kernel(const double* __restrict__ a, const double* __restrict__ b, int mp,
-                                 double* __restrict__ dst) {
+// dst = I + a on upper tiles, 0 elsewhere
+__global__ void add_identity_upper_kernel(const double* __restrict__ a, int mp, double* __restrict__ dst) {
   const int c = blockIdx.x * 256 + threadIdx.x;
   const int r = blockIdx.y;
   if (c >= mp) return;
   const int64_t off = (int64_t)r * mp + c;
-  dst[off] = (r / TILE <= c / TILE) ? a[off] + b[off] : 0.0;
+  dst[off] = (r / TILE <= c / TILE) ? a[off] + (r == c ? 1.0 : 0.0) : 0.0;
 }
 
 }  // namespace gprhip
 
 using namespace gprhip;
 
+extern "C" int64_t gprhip_ar2_len(const gprhip_problem* p);
+
 namespace {
 
 constexpr double LOG_2PI = 1.8378770664093454835606594728112;  // lib/utils.ml:39-40
 constexpr int NSCAL = 16;
 enum {  // device scalar slots
-  SC_LOGDET_KM = 0,
-  SC_LOGDET_B = 1,
-  SC_UTU = 2,
+  SC_LOGDET_B = 0,  // log |B~| = log |B| - log |K_m + jitter|
+  SC_BB = 1,        // |b|^2 = |Q_n^T y~|^2
 };
 // tail of the exchange-1 buffer
 enum { A1_SUMLOGS = 0, A1_ISY2 = 1, A1_ISR = 2, A1_TAIL = 4 };
 // tail of the exchange-2 buffer
-enum { A2_SUMV = 0, A2_SUMIS = 1, A2_ISRES2 = 2, A2_SUMV1 = 3, A2_SUME = 4, A2_SUMED = 5, A2_TAIL = 8 };
+enum { A2_SUMV = 0, A2_SUMIS = 1, A2_WRES = 2, A2_SUMV1 = 3, A2_SUME = 4, A2_SUMED = 5, A2_TAIL = 8 };
 
 struct Timer {
   std::vector<std::pair<std::string, std::pair<hipEvent_t, hipEvent_t>>> ev;
@@ -75,19 +81,19 @@ struct gprhip_problem {
   int D = 0, d = 0, m = 0, mp = 0;
   int64_t chunk = 0;
   int nchunks = 0;
-  int kslices = 8;
+  int kslices = 32;  // upper bound on the split-K factor (partial-sum buffers allocated)
   hipStream_t stream = nullptr;
   std::vector<void*> allocs;
 
   double *X = nullptr, *y = nullptr, *P = nullptr;
   double *Z = nullptr, *tproj = nullptr;
-  double *km = nullptr, *kj = nullptr, *umat = nullptr, *uinv = nullptr, *kminv = nullptr;
-  double *bmat = nullptr, *rinv = nullptr, *binv = nullptr, *wmat = nullptr, *tmp = nullptr,
-         *dinv = nullptr;
-  double *cvec = nullptr, *bvec = nullptr, *tvec = nullptr, *utvec = nullptr, *scal = nullptr;
+  double *km = nullptr, *kj = nullptr, *umat = nullptr, *uinv = nullptr;
+  double *bmat = nullptr, *rinv = nullptr, *binv = nullptr, *wtil = nullptr, *wmat = nullptr,
+         *tmp = nullptr, *dinv = nullptr;
+  double *bvec = nullptr, *ttil = nullptr, *tvec = nullptr, *scal = nullptr;
   int* info = nullptr;
   double *r = nullptr, *is = nullptr, *yis = nullptr, *w = nullptr, *v = nullptr;
-  double *Kc = nullptr, *Vc = nullptr, *Sc = nullptr, *A1 = nullptr;
+  double *bufA = nullptr, *bufB = nullptr, *Vstore = nullptr;
   double* slices = nullptr;
   double *rowpart = nullptr, *gemvpart = nullptr, *colpart = nullptr, *scalpart = nullptr,
          *kmpart = nullptr, *kmred = nullptr;
@@ -99,7 +105,7 @@ struct gprhip_problem {
   int want_grad = 0;
   int64_t n_total = 0;
   int stage = 0;  // 0 idle, 1 pass1 done, 2 pass2 done
-  bool have_inputs = false, have_targets = false, kc_valid = false;
+  bool have_inputs = false, have_targets = false;
   std::vector<double> hZ;  // host copy of inducing (padded point-major) for the gradient assembly
   std::vector<double> hTproj;
   Timer timer;
@@ -251,11 +257,30 @@ void upload_hypers(gprhip_problem* p, const gprhip_hypers* h) {
   }
 }
 
-void cov_chunk(gprhip_problem* p, int c) {
+// Split-K factor of the SYRK-shaped accumulations: the (upper tiles) x (slices) blocks should fill
+// a whole number of residency rounds (256 CUs x 2 resident blocks) so no round runs part-empty.
+int pick_kslices(int mp, int rows_p, int max_slices) {
+  const int nt = mp / TILE, tiles = nt * (nt + 1) / 2;
+  const int slots = 512;
+  const int kmax = std::max(1, std::min(max_slices, rows_p / (BK * 8)));
+  int best = 1;
+  double best_eff = 0.0;
+  for (int ks = 1; ks <= kmax; ++ks) {
+    const int blocks = tiles * ks;
+    const double eff = (double)blocks / ((double)((blocks + slots - 1) / slots) * slots);
+    if (eff > best_eff + 1e-9) {
+      best_eff = eff;
+      best = ks;
+    }
+  }
+  return best;
+}
+
+void cov_chunk(gprhip_problem* p, int c, double* K) {
   const int64_t rows = p->rows_of(c);
   const int64_t rows_p = round_up(rows, TILE);
   const double* pts = p->pts() + (int64_t)c * p->chunk * p->d;
-  launch_cov_cross(p->cp, pts, (int)rows, (int)rows_p, p->Z, p->m, p->mp, p->d, p->Kc, p->stream);
+  launch_cov_cross(p->cp, pts, (int)rows, (int)rows_p, p->Z, p->m, p->mp, p->d, K, p->stream);
 }
 
 void do_pass1(gprhip_problem* p, const gprhip_hypers* h, int want_grad, int64_t n_total, double* ar1) {
@@ -272,6 +297,8 @@ void do_pass1(gprhip_problem* p, const gprhip_hypers* h, int want_grad, int64_t 
   const int64_t mm = (int64_t)mp * mp;
   double* ar1_c = ar1 + mm;
   double* ar1_tail = ar1_c + mp;
+  if (want_grad && !p->Vstore)  // V = K U^-1 for all rows of the shard stays resident between the passes
+    p->Vstore = p->alloc<double>((int64_t)p->nchunks * p->chunk * mp);
 
   tstart(p, "km_chol");
   GPR_HIP(hipMemsetAsync(p->info, 0, 2 * sizeof(int), s));
@@ -280,8 +307,7 @@ void do_pass1(gprhip_problem* p, const gprhip_hypers* h, int want_grad, int64_t 
   GPR_HIP(hipMemsetAsync(p->slices, 0, (size_t)p->kslices * mm * sizeof(double), s));
   launch_cov_upper(p->cp, p->Z, p->m, mp, p->d, h->jitter, p->km, p->kj, s);
   GPR_HIP(hipMemcpyAsync(p->umat, p->kj, (size_t)mm * sizeof(double), hipMemcpyDeviceToDevice, s));
-  potrf_upper(p, p->umat, p->info);
-  launch_logdet(p->umat, mp, p->m, p->scal + SC_LOGDET_KM, s);
+  potrf_upper(p, p->umat, p->info);  // U = chol(K_m + jitter), lib/fitc_gp.ml:53-57
   trtri_upper(p, p->umat, p->uinv);
   tstop(p);
 
@@ -289,46 +315,36 @@ void do_pass1(gprhip_problem* p, const gprhip_hypers* h, int want_grad, int64_t 
     const int64_t rows = p->rows_of(c);
     const int rows_p = (int)round_up(rows, TILE);
     const int64_t base = (int64_t)c * p->chunk;
+    double* V = want_grad ? p->Vstore + base * mp : p->bufB;
     tstart(p, "p1_cov");
-    cov_chunk(p, c);
+    cov_chunk(p, c, p->bufA);
     tstop(p);
     tstart(p, "p1_trmm_V");
     GemmArgs g;  // V = K U^-1   (dtrsm `R, lib/fitc_gp.ml:226-227)
-    g.A = p->Kc; g.lda = mp; g.B = p->uinv; g.ldb = mp; g.C = p->Vc; g.ldc = mp;
+    g.A = p->bufA; g.lda = mp; g.B = p->uinv; g.ldb = mp; g.C = V; g.ldc = mp;
     g.M = rows_p; g.N = mp; g.K = mp; g.tri = TRI_KHI_BN;
     launch_gemm(OP_NN, g, s);
     tstop(p);
     tstart(p, "p1_rows");
     Pass1RowArgs ra;
-    ra.V = p->Vc; ra.y = h->model_only ? nullptr : p->y + base; ra.rows = (int)rows; ra.mp = mp;
+    ra.V = V; ra.y = h->model_only ? nullptr : p->y + base; ra.rows = (int)rows; ra.mp = mp;
     ra.sf2 = p->cp.sf2; ra.sigma2 = h->sigma2;
     ra.r = p->r + base; ra.is = p->is + base; ra.yis = p->yis + base; ra.partial = p->rowpart;
     launch_pass1_rows(ra, s);
     launch_reduce_rows(p->rowpart, pass1_row_blocks(rows_p), 4, ar1_tail, 1, s);
     tstop(p);
     tstart(p, "p1_syrk_B");
-    GemmArgs b;  // B_part += K^T diag(is) K   (replaces the stacked QR's R^T R, lib/fitc_gp.ml:170-182)
-    b.A = p->Kc; b.lda = mp; b.B = p->Kc; b.ldb = mp; b.C = p->slices; b.ldc = mp;
+    GemmArgs b;  // B~_part += V^T diag(is) V   (R~^T R~ replaces the stacked QR's R, lib/fitc_gp.ml:170-182)
+    b.A = V; b.lda = mp; b.B = V; b.ldb = mp; b.C = p->slices; b.ldc = mp;
     b.M = mp; b.N = mp; b.K = rows_p; b.beta = 1.0; b.scale_k = p->is + base; b.upper_only = 1;
-    b.kslices = p->kslices; b.slice_stride = mm;
+    b.kslices = pick_kslices(mp, rows_p, p->kslices); b.slice_stride = mm;
     launch_gemm(OP_TN, b, s);
     tstop(p);
     tstart(p, "p1_gemv_c");
-    launch_gemv_t_partial(p->Kc, rows_p, mp, p->yis + base, p->gemvpart, s);
+    launch_gemv_t_partial(V, rows_p, mp, p->yis + base, p->gemvpart, s);
     launch_reduce_rows(p->gemvpart, (rows_p + 255) / 256, mp, ar1_c, 1, s);
     tstop(p);
-    if (want_grad) {
-      if (!p->A1)  // K K_m^-1 for all rows of the shard stays resident between the passes
-        p->A1 = p->alloc<double>((int64_t)p->nchunks * p->chunk * mp);
-      tstart(p, "p1_trmm_A1");
-      GemmArgs a;  // A1 = V U^-T = K K_m^-1   (U_mat, lib/fitc_gp.ml:932-933)
-      a.A = p->Vc; a.lda = mp; a.B = p->uinv; a.ldb = mp; a.C = p->A1 + base * mp; a.ldc = mp;
-      a.M = rows_p; a.N = mp; a.K = mp; a.tri = TRI_KLO_BN;
-      launch_gemm(OP_NT, a, s);
-      tstop(p);
-    }
   }
-  p->kc_valid = (p->nchunks == 1);
   launch_sum_slices(nullptr, p->slices, p->kslices, mm, mp, ar1, s);
   p->stage = 1;
 }
@@ -348,88 +364,80 @@ void do_pass2(gprhip_problem* p, const double* ar1, double* ar2) {
   const bool mo = p->h.model_only != 0;
 
   tstart(p, "b_chol");
-  hipLaunchKernelGGL(add_upper_kernel, dim3((mp + 255) / 256, mp), dim3(256), 0, s, p->kj, ar1, mp,
+  // B~ = I + sum of shard parts; R~ = chol(B~): R = R~ U is the reference's r_mat (lib/fitc_gp.ml:181)
+  hipLaunchKernelGGL(add_identity_upper_kernel, dim3((mp + 255) / 256, mp), dim3(256), 0, s, ar1, mp,
                      p->bmat);
   potrf_upper(p, p->bmat, p->info + 1);
-  launch_logdet(p->bmat, mp, p->m, p->scal + SC_LOGDET_B, s);
+  launch_logdet(p->bmat, mp, mp, p->scal + SC_LOGDET_B, s);
   trtri_upper(p, p->bmat, p->rinv);
-  // b = R^-T c  (= Q_n^T y~, lib/fitc_gp.ml:285-286);  t = R^-1 b  (trsv, :291 / :1167)
+  // b = R~^-T c~ (= Q_n^T y~, lib/fitc_gp.ml:285-286);  t~ = R~^-1 b;  t = U^-1 t~ (trsv, :291 / :1167)
   launch_triu_matvec(p->rinv, mp, ar1_c, p->bvec, 1, s);
-  launch_triu_matvec(p->rinv, mp, p->bvec, p->tvec, 0, s);
-  launch_triu_matvec(p->umat, mp, p->tvec, p->utvec, 0, s);
-  hipLaunchKernelGGL(dot_kernel, dim3(1), dim3(256), 0, s, p->utvec, p->utvec, mp, p->scal + SC_UTU);
+  launch_triu_matvec(p->rinv, mp, p->bvec, p->ttil, 0, s);
+  launch_triu_matvec(p->uinv, mp, p->ttil, p->tvec, 0, s);
+  hipLaunchKernelGGL(dot_kernel, dim3(1), dim3(256), 0, s, p->bvec, p->bvec, mp, p->scal + SC_BB);
   tstop(p);
 
-  GPR_HIP(hipMemsetAsync(ar2_col, 0, (size_t)((p->d + 1) * (int64_t)mp + A2_TAIL) * sizeof(double), s));
+  GPR_HIP(hipMemsetAsync(ar2, 0, (size_t)gprhip_ar2_len(p) * sizeof(double), s));
   if (p->want_grad) {
     tstart(p, "inverses");
-    triu_xxt(p, p->uinv, p->kminv);
-    triu_xxt(p, p->rinv, p->binv);
+    triu_xxt(p, p->rinv, p->binv);  // B~^-1 (upper tiles)
     GPR_HIP(hipMemsetAsync(p->slices, 0, (size_t)p->kslices * mm * sizeof(double), s));
     tstop(p);
-  }
-  for (int c = 0; c < p->nchunks; ++c) {
-    const int64_t rows = p->rows_of(c);
-    const int rows_p = (int)round_up(rows, TILE);
-    const int64_t base = (int64_t)c * p->chunk;
-    if (!p->kc_valid) {
-      tstart(p, "p2_cov");
-      cov_chunk(p, c);
+    for (int c = 0; c < p->nchunks; ++c) {
+      const int64_t rows = p->rows_of(c);
+      const int rows_p = (int)round_up(rows, TILE);
+      const int64_t base = (int64_t)c * p->chunk;
+      const double* V = p->Vstore + base * mp;
+      tstart(p, "p2_trmm_Q");
+      GemmArgs q;  // Q' = V R~^-1 = K R^-1  (Q_n = diag(sqrt is) Q', lib/fitc_gp.ml:176-182)
+      q.A = V; q.lda = mp; q.B = p->rinv; q.ldb = mp; q.C = p->bufA; q.ldc = mp;
+      q.M = rows_p; q.N = mp; q.K = mp; q.tri = TRI_KHI_BN;
+      launch_gemm(OP_NN, q, s);
       tstop(p);
-    }
-    Pass2RowArgs ra;
-    ra.y = mo ? nullptr : p->y + base; ra.is = p->is + base; ra.r = p->r + base;
-    ra.rows = (int)rows; ra.mp = mp; ra.variational = p->h.variational;
-    ra.w = p->w + base; ra.v = p->v + base; ra.partial = p->rowpart;
-    if (!p->want_grad) {
-      // evidence only: the residual form of l2 needs K t per row; reuse the row kernel with Q := K, b := t
       tstart(p, "p2_rows");
-      ra.Q = p->Kc; ra.b = p->tvec;
+      Pass2RowArgs ra;
+      ra.Q = p->bufA; ra.b = p->bvec;
+      ra.y = mo ? nullptr : p->y + base; ra.is = p->is + base; ra.r = p->r + base;
+      ra.rows = (int)rows; ra.mp = mp; ra.variational = p->h.variational;
+      ra.w = p->w + base; ra.v = p->v + base; ra.partial = p->rowpart;
       launch_pass2_rows(ra, s);
       launch_reduce_rows(p->rowpart, pass1_row_blocks(rows_p), 4, ar2_tail, 1, s);
       tstop(p);
-      continue;
+      tstart(p, "p2_trmm_S");
+      GemmArgs sg;  // X~ = diag(is) Q' R~^-T - diag(v) V - w t~^T   (S, U_mat and the ger of :936-938, :1204-1206)
+      sg.A = p->bufA; sg.lda = mp; sg.B = p->rinv; sg.ldb = mp; sg.C = p->bufB; sg.ldc = mp;
+      sg.M = rows_p; sg.N = mp; sg.K = mp; sg.tri = TRI_KLO_BN;
+      sg.epi_rows_a = p->is + base; sg.epi_rows_b = p->v + base; sg.epi_rows_c = p->w + base;
+      sg.epi_col = p->ttil; sg.epi_mat = V; sg.epi_ldm = mp;
+      launch_gemm(OP_NT, sg, s);
+      tstop(p);
+      tstart(p, "p2_trmm_X");
+      GemmArgs xg;  // X = X~ U^-T
+      xg.A = p->bufB; xg.lda = mp; xg.B = p->uinv; xg.ldb = mp; xg.C = p->bufA; xg.ldc = mp;
+      xg.M = rows_p; xg.N = mp; xg.K = mp; xg.tri = TRI_KLO_BN;
+      launch_gemm(OP_NT, xg, s);
+      tstop(p);
+      tstart(p, "p2_syrk_W");
+      GemmArgs wg;  // G~_part += V^T diag(v) V   (the two dsyrk of lib/fitc_gp.ml:1198-1203, whitened, in one)
+      wg.A = V; wg.lda = mp; wg.B = V; wg.ldb = mp; wg.C = p->slices; wg.ldc = mp;
+      wg.M = mp; wg.N = mp; wg.K = rows_p; wg.beta = 1.0; wg.scale_k = p->v + base; wg.upper_only = 1;
+      wg.kslices = pick_kslices(mp, rows_p, p->kslices); wg.slice_stride = mm;
+      launch_gemm(OP_TN, wg, s);
+      tstop(p);
+      tstart(p, "p2_grad");
+      GradArgs ga;
+      ga.X = p->bufA; ga.pts = p->pts() + base * p->d; ga.Z = p->Z;
+      ga.rows = (int)rows; ga.rows_p = rows_p; ga.m = p->m; ga.mp = mp; ga.d = p->d;
+      ga.log_sf2 = p->cp.log_sf2; ga.inv_ell2_05 = p->cp.inv_ell2_05;
+      ga.colpart = p->colpart; ga.scalpart = p->scalpart;
+      launch_grad_fused(ga, s);
+      const int nslabs = (int)((rows + grad_slab_rows() - 1) / grad_slab_rows());
+      launch_reduce_rows(p->colpart, nslabs, (p->d + 1) * mp, ar2_col, 1, s);
+      launch_reduce_rows(p->scalpart, nslabs * ((mp + 255) / 256), 2, ar2_tail + A2_SUME, 1, s);
+      tstop(p);
     }
-    tstart(p, "p2_trmm_Q");
-    GemmArgs q;  // Q' = K R^-1  (Q_n = diag(sqrt is) Q', lib/fitc_gp.ml:176-182)
-    q.A = p->Kc; q.lda = mp; q.B = p->rinv; q.ldb = mp; q.C = p->Vc; q.ldc = mp;
-    q.M = rows_p; q.N = mp; q.K = mp; q.tri = TRI_KHI_BN;
-    launch_gemm(OP_NN, q, s);
-    tstop(p);
-    tstart(p, "p2_rows");
-    ra.Q = p->Vc; ra.b = p->bvec;
-    launch_pass2_rows(ra, s);
-    launch_reduce_rows(p->rowpart, pass1_row_blocks(rows_p), 4, ar2_tail, 1, s);
-    tstop(p);
-    tstart(p, "p2_trmm_S");
-    GemmArgs sg;  // S' = Q' R^-T = K B^-1   (S = diag(is) S', lib/fitc_gp.ml:936-938)
-    sg.A = p->Vc; sg.lda = mp; sg.B = p->rinv; sg.ldb = mp; sg.C = p->Sc; sg.ldc = mp;
-    sg.M = rows_p; sg.N = mp; sg.K = mp; sg.tri = TRI_KLO_BN;
-    launch_gemm(OP_NT, sg, s);
-    tstop(p);
-    tstart(p, "p2_syrk_W");
-    const double* a1 = p->A1 + base * mp;
-    GemmArgs wg;  // G_part += A1^T diag(v) A1   (the two dsyrk of lib/fitc_gp.ml:1198-1203 in one)
-    wg.A = a1; wg.lda = mp; wg.B = a1; wg.ldb = mp; wg.C = p->slices; wg.ldc = mp;
-    wg.M = mp; wg.N = mp; wg.K = rows_p; wg.beta = 1.0; wg.scale_k = p->v + base; wg.upper_only = 1;
-    wg.kslices = p->kslices; wg.slice_stride = mm;
-    launch_gemm(OP_TN, wg, s);
-    tstop(p);
-    tstart(p, "p2_grad");
-    GradArgs ga;
-    ga.K = p->Kc; ga.S = p->Sc; ga.A1 = a1; ga.pts = p->pts() + base * p->d; ga.Z = p->Z;
-    ga.is = p->is + base; ga.v = p->v + base; ga.w = p->w + base; ga.t = p->tvec;
-    ga.rows = (int)rows; ga.rows_p = rows_p; ga.m = p->m; ga.mp = mp; ga.d = p->d;
-    ga.inv_ell2_05 = p->cp.inv_ell2_05; ga.colpart = p->colpart; ga.scalpart = p->scalpart;
-    ga.rowE = nullptr;
-    launch_grad_fused(ga, s);
-    const int nslabs = (int)((rows + grad_slab_rows() - 1) / grad_slab_rows());
-    launch_reduce_rows(p->colpart, nslabs, (p->d + 1) * mp, ar2_col, 1, s);
-    launch_reduce_rows(p->scalpart, nslabs * ((mp + 255) / 256), 2, ar2_tail + A2_SUME, 1, s);
-    tstop(p);
-  }
-  if (p->want_grad)
     launch_sum_slices(nullptr, p->slices, p->kslices, mm, mp, ar2, s);
+  }
   p->stage = 2;
 }
 
@@ -447,7 +455,15 @@ void do_finish(gprhip_problem* p, const double* ar2, gprhip_result* res, double*
   const int nkslab = (m + 255) / 256;
   if (p->want_grad) {
     tstart(p, "finish");
-    launch_build_w(p->kminv, p->binv, p->tvec, ar2, mp, p->wmat, s);
+    launch_build_w(p->binv, p->ttil, ar2, mp, p->wtil, s);
+    GemmArgs y;  // Y = W~ U^-T
+    y.A = p->wtil; y.lda = mp; y.B = p->uinv; y.ldb = mp; y.C = p->bmat; y.ldc = mp;
+    y.M = mp; y.N = mp; y.K = mp; y.tri = TRI_KLO_BN;
+    launch_gemm(OP_NT, y, s);
+    GemmArgs w;  // W = U^-1 Y   (lib/fitc_gp.ml:1196-1203)
+    w.A = p->uinv; w.lda = mp; w.B = p->bmat; w.ldb = mp; w.C = p->wmat; w.ldc = mp;
+    w.M = mp; w.N = mp; w.K = mp; w.tri = TRI_KLO_BM;
+    launch_gemm(OP_NN, w, s);
     launch_km_traces(p->wmat, p->km, p->Z, m, mp, d, p->kmpart, nullptr, s);
     launch_reduce_rows(p->kmpart, nkslab, (d + 2) * mp, p->kmred, 0, s);
     tstop(p);
@@ -465,8 +481,7 @@ void do_finish(gprhip_problem* p, const double* ar2, gprhip_result* res, double*
     GPR_HIP(hipMemcpyAsync(hcol.data(), ar2_col, hcol.size() * sizeof(double), hipMemcpyDeviceToHost, s));
     GPR_HIP(hipMemcpyAsync(hkm.data(), p->kmred, hkm.size() * sizeof(double), hipMemcpyDeviceToHost, s));
   }
-  // the exchange-1 tail lives in the caller's (or our) ar1 buffer; it was copied into scal? no:
-  // pass 2 does not need it, so fetch it from the saved pointer
+  // scalar tail of the (reduced) exchange-1 buffer, kept in p->ar1 by pass 2
   GPR_HIP(hipMemcpyAsync(ha1tail.data(), p->ar1 + mm + mp, A1_TAIL * sizeof(double),
                          hipMemcpyDeviceToHost, s));
   GPR_HIP(hipStreamSynchronize(s));
@@ -476,17 +491,17 @@ void do_finish(gprhip_problem* p, const double* ar2, gprhip_result* res, double*
     char buf[160];
     snprintf(buf, sizeof buf,
              "Lacaml.D.potrf: leading minor of order %d of %s is not positive definite",
-             hinfo[0] ? hinfo[0] : hinfo[1], hinfo[0] ? "K_m + jitter" : "B = K_m + K_mn S^-1 K_nm");
+             hinfo[0] ? hinfo[0] : hinfo[1], hinfo[0] ? "K_m + jitter" : "B~ = I + V^T S^-1 V");
     set_error(buf);
     throw HipFail{ST_NOT_POSDEF};
   }
   const bool mo = p->h.model_only != 0;
-  const double sum_log_s = ha1tail[A1_SUMLOGS], sum_isr = ha1tail[A1_ISR];
-  // l1: lib/fitc_gp.ml:204-208 ; variational: :262-263
-  double l1 = -0.5 * (hscal[SC_LOGDET_B] - hscal[SC_LOGDET_KM] + sum_log_s + (double)p->n_total * LOG_2PI);
+  const double sum_log_s = ha1tail[A1_SUMLOGS], sum_isr = ha1tail[A1_ISR], sum_isy2 = ha1tail[A1_ISY2];
+  // l1: lib/fitc_gp.ml:204-208 with log|R^T R| - log|K_m| = log|B~| ; variational: :262-263
+  double l1 = -0.5 * (hscal[SC_LOGDET_B] + sum_log_s + (double)p->n_total * LOG_2PI);
   if (p->h.variational) l1 += -0.5 * sum_isr;
-  // l2 = -1/2 |y~ - Q Q^T y~|^2 in residual form: |sqrt(is)(y - K t)|^2 + |U t|^2  (DESIGN.md "l2")
-  double l2 = mo ? 0.0 : -0.5 * (htail[A2_ISRES2] + hscal[SC_UTU]);
+  // l2 = -1/2 (|y~|^2 - |Q_n^T y~|^2), lib/fitc_gp.ml:290
+  double l2 = mo ? 0.0 : -0.5 * (sum_isy2 - hscal[SC_BB]);
   res->l1 = l1;
   res->l2 = l2;
   res->l = l1 + l2;
@@ -595,17 +610,17 @@ int gprhip_problem_create(int device, int cov_kind, int64_t n, int D, int d, int
     }
     p->Z = p->alloc<double>((int64_t)mp * d);
     p->km = p->alloc<double>(mm); p->kj = p->alloc<double>(mm); p->umat = p->alloc<double>(mm);
-    p->uinv = p->alloc<double>(mm); p->kminv = p->alloc<double>(mm); p->bmat = p->alloc<double>(mm);
-    p->rinv = p->alloc<double>(mm); p->binv = p->alloc<double>(mm); p->wmat = p->alloc<double>(mm);
+    p->uinv = p->alloc<double>(mm); p->bmat = p->alloc<double>(mm);
+    p->rinv = p->alloc<double>(mm); p->binv = p->alloc<double>(mm); p->wtil = p->alloc<double>(mm);
+    p->wmat = p->alloc<double>(mm);
     p->tmp = p->alloc<double>((int64_t)mp * TILE);
     p->dinv = p->alloc<double>((int64_t)(mp / TILE) * TILE * TILE);
-    p->cvec = p->alloc<double>(mp); p->bvec = p->alloc<double>(mp); p->tvec = p->alloc<double>(mp);
-    p->utvec = p->alloc<double>(mp); p->scal = p->alloc<double>(NSCAL);
+    p->bvec = p->alloc<double>(mp); p->ttil = p->alloc<double>(mp); p->tvec = p->alloc<double>(mp);
+    p->scal = p->alloc<double>(NSCAL);
     p->info = p->alloc<int>(2);
     p->r = p->alloc<double>(npad); p->is = p->alloc<double>(npad); p->yis = p->alloc<double>(npad);
     p->w = p->alloc<double>(npad); p->v = p->alloc<double>(npad);
-    p->Kc = p->alloc<double>(chunk * mp); p->Vc = p->alloc<double>(chunk * mp);
-    p->Sc = p->alloc<double>(chunk * mp);
+    p->bufA = p->alloc<double>(chunk * mp); p->bufB = p->alloc<double>(chunk * mp);
     p->slices = p->alloc<double>((int64_t)p->kslices * mm);
     p->rowpart = p->alloc<double>((int64_t)pass1_row_blocks((int)chunk) * 4);
     p->gemvpart = p->alloc<double>(((chunk + 255) / 256) * mp);

@@ -84,20 +84,13 @@ void launch_reduce_rows(const double* partial, int nslabs, int width, double* ou
                         hipStream_t s);
 
 struct GradArgs {
-  const double* K;       // [rows_p][mp]
-  const double* S;       // [rows_p][mp]  K * Binv
-  const double* A1;      // [rows_p][mp]  K * Kminv
+  const double* X;       // [rows_p][mp]  X of lib/fitc_gp.ml:1204-1206 for this chunk
   const double* pts;     // [rows][d]  inputs (iso) or projections (fat) of the chunk
   const double* Z;       // [mp][d]
-  const double* is;      // [rows_p]
-  const double* v;       // [rows_p]
-  const double* w;       // [rows_p]
-  const double* t;       // [mp]
   int rows, rows_p, m, mp, d;
-  double inv_ell2_05;    // distance scale of the kernel (for sqr_diff recovery is not used; D recomputed)
+  double log_sf2, inv_ell2_05;  // K_rc = exp(log_sf2 + inv_ell2_05*|x_r - z_c|^2) is recomputed on the fly
   double* colpart;       // out [nslabs][(d+1)][mp]: row 0 = column sums of E, rows 1..d = sum_r x_kr E_rc
   double* scalpart;      // out [nslabs][nbx][2]: sum E, sum E*sqr_diff
-  double* rowE;          // optional out [rows][1+d]: rowsum E, (E Z)[r][k]  (Cov_se_fat Proj gradient), or null
 };
 int grad_slab_rows();
 void launch_grad_fused(const GradArgs& a, hipStream_t s);
@@ -106,9 +99,10 @@ void launch_grad_fused(const GradArgs& a, hipStream_t s);
 // dst (upper tiles) = base + sum_z slices[z]
 void launch_sum_slices(const double* base, const double* slices, int nslices, int64_t stride, int mp,
                        double* dst, hipStream_t s);
-// W (upper tiles) = Kminv - Binv - t t^T - G
-void launch_build_w(const double* kminv, const double* binv, const double* t, const double* G, int mp,
-                    double* W, hipStream_t s);
+// W~ = I - B~^-1 - t~ t~^T - G~ as a full symmetric matrix (inputs valid on upper tiles);
+// the reference's W (lib/fitc_gp.ml:1196-1203) is U^-1 W~ U^-T.
+void launch_build_w(const double* binv, const double* t, const double* G, int mp, double* W,
+                    hipStream_t s);
 // Trace terms of W against K_m and its derivatives (lib/fitc_gp.ml:956-973, lib/utils.ml:196-220),
 // as per-column partial sums over slabs of 256 rows: part[slab][q][c], q = 0: sum_r W_rc K_rc,
 // q = 1: sum_r W_rc K_rc |z_r - z_c|^2, q = 2+k: sum_r W_rc K_rc (z_kr - z_kc).  W, km full symmetric.

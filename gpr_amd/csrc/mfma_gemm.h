@@ -43,6 +43,13 @@ struct GemmArgs {
   int upper_only = 0;    // compute only tiles with row tile <= column tile
   int kslices = 1;       // split K over gridDim.z; slice z writes C + z*slice_stride
   int64_t slice_stride = 0;
+  // optional fused epilogue (when epi_rows_a != null): C[i][j] = ra[i]*acc - rb[i]*M[i][j] - rc[i]*cv[j]
+  const double* epi_rows_a = nullptr;
+  const double* epi_rows_b = nullptr;
+  const double* epi_rows_c = nullptr;
+  const double* epi_col = nullptr;
+  const double* epi_mat = nullptr;
+  int64_t epi_ldm = 0;
 };
 
 // Enqueue on `stream`.  Returns the number of multiply-add flops issued (x2), for accounting.

@@ -189,9 +189,30 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
   }
 
   // ---- epilogue
-  double* Cp = g.C + (int64_t)blockIdx.z * g.slice_stride +
-               (int64_t)(bm * TILE + wr * 64 + lq) * g.ldc + (int64_t)bn * TILE + wc * 64 + l15;
+  const int row0 = bm * TILE + wr * 64 + lq, col0 = bn * TILE + wc * 64 + l15;
+  double* Cp = g.C + (int64_t)blockIdx.z * g.slice_stride + (int64_t)row0 * g.ldc + col0;
   const double alpha = g.alpha, beta = g.beta;
+  if (g.epi_rows_a) {
+    // fused X~ epilogue: C[i][j] = ra[i]*acc - rb[i]*M[i][j] - rc[i]*cv[j]
+    //   (X~ = diag(is) Q' R~^-T - diag(v) V - w t~^T of the gradient pass)
+    const double* Mp = g.epi_mat + (int64_t)row0 * g.epi_ldm + col0;
+    double cv[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) cv[j] = g.epi_col[col0 + j * 16];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = row0 + i * 16 + 4 * r;
+        const double ra = g.epi_rows_a[row], rb = g.epi_rows_b[row], rc = g.epi_rows_c[row];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int64_t o = (int64_t)(i * 16 + 4 * r);
+          Cp[o * g.ldc + j * 16] = ra * acc[i][j][r] - rb * Mp[o * g.epi_ldm + j * 16] - rc * cv[j];
+        }
+      }
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll

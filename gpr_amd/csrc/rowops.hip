@@ -186,10 +186,10 @@ void launch_reduce_rows(const double* partial, int nslabs, int width, double* ou
 }
 
 // ---------------------------------------------------------------------------------------------
-// Fused gradient pass: never materialises X or any derivative matrix.
+// Fused gradient pass: never materialises a derivative matrix.  With
 //   X   = diag(is) K Binv - diag(v) K Kminv - w t^T          lib/fitc_gp.ml:1204-1206
-//   E   = X .* K_nm
-//   `Factor 1.  (Log_sf2)       : tr(X^T K)            = sum E                 lib/fitc_gp.ml:991
+//   E   = X .* K_nm                                           (K_nm recomputed per element)
+//   `Factor 1.  (Log_sf2)       : tr(X^T K)             = sum E                lib/fitc_gp.ml:991
 //   `Dense      (Log_ell)       : tr(X^T (K.*D)) ell^-2 = ell^-2 sum E.*D      lib/cov_se_iso.ml:303-314
 //   `Sparse_cols (Inducing c,k) : scale * sum_r (x_kr - z_kc) E_rc             lib/cov_se_iso.ml:315-327
 // Thread <-> inducing column; rows stream through; per-thread accumulators in registers.
@@ -208,27 +208,26 @@ __global__ __launch_bounds__(256) void grad_fused_kernel(GradArgs a) {
     z[k] = (k < a.d && live) ? a.Z[(int64_t)jj * a.d + k] : 0.0;
     gx[k] = 0.0;
   }
-  const double tj = live ? a.t[jj] : 0.0;
   double cs = 0.0, sE = 0.0, sED = 0.0;
   const int r0 = blockIdx.y * GRAD_SLAB;
   const int r1 = min(a.rows, r0 + GRAD_SLAB);
   for (int r = r0; r < r1; ++r) {
-    const double is = a.is[r], v = a.v[r], w = a.w[r];
     const double* x = a.pts + (int64_t)r * a.d;
-    const int64_t off = (int64_t)r * a.mp + jj;
-    const double kk = a.K[off];
-    const double xs = is * a.S[off] - v * a.A1[off] - w * tj;
-    const double e = live ? xs * kk : 0.0;
+    const double xv = a.X[(int64_t)r * a.mp + jj];
+    double xr[DT];
     double dist = 0.0;
 #pragma unroll
     for (int k = 0; k < DT; ++k) {
       if (k < a.d) {
-        const double xk = x[k];
-        const double df = xk - z[k];
+        xr[k] = x[k];
+        const double df = xr[k] - z[k];
         dist += df * df;
-        gx[k] += xk * e;
       }
     }
+    const double e = live ? xv * exp(a.log_sf2 + a.inv_ell2_05 * dist) : 0.0;
+#pragma unroll
+    for (int k = 0; k < DT; ++k)
+      if (k < a.d) gx[k] += xr[k] * e;
     cs += e;
     sE += e;
     sED += e * dist;

@@ -3,7 +3,8 @@ eval_finish on caller-owned exchange buffers).
 
 TEST INFRASTRUCTURE ONLY: lets the world_size-2 gloo tests exercise the row-sharding and
 all-reduce logic of gpr_amd.dist without a GPU.  It restates in numpy the *build's* two-pass
-formulation (SYRK + potrf(B) instead of the reference's stacked QR) on top of
+whitened formulation (B~ = I + V^T S^-1 V by SYRK + potrf instead of the reference's stacked QR;
+DESIGN.md section 3) on top of
 the oracle's covariance functions, so it doubles as an independent check of that algebra against
 the reference-sequence oracle.
 """
@@ -49,49 +50,53 @@ class StagedDouble:
         self.want_grad, self.n_total, self.jitter = want_grad, n_total, jitter
         km, self.su = O.spec_calc_shared_upper(self.k, self.Z)
         self.km = np.triu(km) + np.triu(km, 1).T
-        self.kj = self.km + jitter * np.eye(m)
-        self.U = np.linalg.cholesky(self.kj).T
+        self.U = np.linalg.cholesky(self.km + jitter * np.eye(m)).T
         self.Ui = sl.solve_triangular(self.U, np.eye(m))
         self.K, self.sc = O.spec_calc_shared_cross(self.k, self.X, self.Z)
-        V = self.K @ self.Ui
+        self.V = self.K @ self.Ui
+        V = self.V
         self.r = self.k.sf2 - np.sum(V * V, axis=1)
         s = self.r + sigma2
         self.is_ = 1.0 / s
-        self.A1 = V @ self.Ui.T
         yy = np.zeros(self.n) if model_only else self.y
         ar1 = _view(ar1_ptr, self.ar1_len())
-        ar1[:m * m] = ((self.K * self.is_[:, None]).T @ self.K).reshape(-1)
-        ar1[m * m:m * m + m] = self.K.T @ (self.is_ * yy)
+        ar1[:m * m] = ((V * self.is_[:, None]).T @ V).reshape(-1)
+        ar1[m * m:m * m + m] = V.T @ (self.is_ * yy)
         ar1[m * m + m:] = [np.sum(np.log(s)), np.sum(self.is_ * yy * yy), np.sum(self.is_ * self.r), 0.0]
 
     def eval_pass2(self, ar1_ptr, ar2_ptr):
         m, d = self.m, self.d
         ar1 = _view(ar1_ptr, self.ar1_len())
         self.tail1 = ar1[m * m + m:].copy()
-        B = self.kj + ar1[:m * m].reshape(m, m)
+        Bt = np.eye(m) + ar1[:m * m].reshape(m, m)
         c = ar1[m * m:m * m + m]
-        self.R = np.linalg.cholesky(B).T
+        self.R = np.linalg.cholesky(Bt).T
         Ri = sl.solve_triangular(self.R, np.eye(m))
-        b = Ri.T @ c
-        self.t = Ri @ b
-        self.kminv, self.binv = self.Ui @ self.Ui.T, Ri @ Ri.T
-        Q = self.K @ Ri
+        self.b = Ri.T @ c
+        self.tt = Ri @ self.b
+        self.t = self.Ui @ self.tt
+        self.binv = Ri @ Ri.T
+        ar2 = _view(ar2_ptr, self.ar2_len())
+        ar2[:] = 0.0
+        if not self.want_grad:
+            return
+        V = self.V
+        Q = V @ Ri
         q = self.is_ * np.sum(Q * Q, axis=1)
         yy = np.zeros(self.n) if self.model_only else self.y
-        res = 0.0 * yy if self.model_only else yy - Q @ b
+        res = 0.0 * yy if self.model_only else yy - Q @ self.b
         w = self.is_ * res
         v1 = self.is_ * (2.0 - self.is_ * self.r - q) if self.variational else self.is_ * (1.0 - q)
         v = v1 - w * w
-        S = Q @ Ri.T
-        Xm = self.is_[:, None] * S - v[:, None] * self.A1 - np.outer(w, self.t)
+        Xt = self.is_[:, None] * (Q @ Ri.T) - v[:, None] * V - np.outer(w, self.tt)
+        Xm = Xt @ self.Ui.T
         E = Xm * self.K
         pts = self.sc["inputs"] if isinstance(self.k, O.SeIsoKernel) else self.sc["projections"]
         sq = np.zeros_like(E)
         for i in range(d):
             df = pts[i, :][:, None] - self.Z[i, :][None, :]
             sq += df * df
-        ar2 = _view(ar2_ptr, self.ar2_len())
-        ar2[:m * m] = ((self.A1 * v[:, None]).T @ self.A1).reshape(-1)
+        ar2[:m * m] = ((V * v[:, None]).T @ V).reshape(-1)
         col = np.vstack([E.sum(0)[None, :], pts @ E])
         ar2[m * m:m * m + (d + 1) * m] = col.reshape(-1)
         ar2[m * m + (d + 1) * m:] = [v.sum(), self.is_.sum(), np.sum(w * res), v1.sum(), E.sum(),
@@ -103,16 +108,15 @@ class StagedDouble:
         G = ar2[:m * m].reshape(m, m)
         col = ar2[m * m:m * m + (d + 1) * m].reshape(d + 1, m)
         tail = ar2[m * m + (d + 1) * m:]
-        logdet_b = 2 * np.sum(np.log(np.diag(self.R)))
-        logdet_km = 2 * np.sum(np.log(np.diag(self.U)))
-        l1 = -0.5 * (logdet_b - logdet_km + self.tail1[0] + self.n_total * O.LOG_2PI)
+        logdet_bt = 2 * np.sum(np.log(np.diag(self.R)))
+        l1 = -0.5 * (logdet_bt + self.tail1[0] + self.n_total * O.LOG_2PI)
         if self.variational:
             l1 += -0.5 * self.tail1[2]
-        ut = self.U @ self.t
-        l2 = 0.0 if self.model_only else -0.5 * (tail[2] + ut @ ut)
+        l2 = 0.0 if self.model_only else -0.5 * (self.tail1[1] - self.b @ self.b)
         if not self.want_grad:
             return Evaluation(l1, l2, l1 + l2, None, None, self.t.copy())
-        W = self.kminv - self.binv - np.outer(self.t, self.t) - G
+        Wt = np.eye(m) - self.binv - np.outer(self.tt, self.tt) - G
+        W = self.Ui @ Wt @ self.Ui.T
         dls2 = -0.5 * (tail[0] - tail[1] if self.variational else tail[0])
         iso = isinstance(self.k, O.SeIsoKernel)
         scale = self.k.inv_ell2 if iso else 1.0

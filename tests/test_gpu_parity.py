@@ -1,8 +1,8 @@
 """Parity of the HIP path (through the C ABI) with the CPU oracle and the golden fixtures.
 
-Stated fp64 tolerances.  The device path forms B = K_m + K_mn S^-1 K_nm and
-factors it by Cholesky (the north-star formulation) where the reference runs a Householder QR of
-the stacked matrix, so agreement is limited by cond(B)*eps rather than by eps:
+Stated fp64 tolerances.  The device path is the whitened SYRK + potrf
+formulation (B~ = I + V^T S^-1 V), whose rounding behaviour is of the same class as the reference's
+Householder QR of the stacked matrix; the remaining differences are summation order and exp() ulps.
 """
 import numpy as np
 import pytest
@@ -14,11 +14,12 @@ from tests.util import golden_names, load_golden, oracle_kernel, relinf, synth
 
 pytestmark = pytest.mark.gpu
 
-TOL_L = 5e-8        # |l - l_ref| <= TOL_L * |l_ref|   (also l1)
-TOL_DS2 = 2e-6      # dl/dsigma2, relative
-TOL_GRAD = 2e-5     # gradient, max-abs error relative to max-abs entry
-TOL_COEFF = 2e-5    # mean coefficients t, same norm
-TOL_ROW = 1e-9      # per-row intermediates r, 1/s (before any m x m solve with B)
+TOL_L = 1e-9        # |l - l_ref| <= TOL_L * |l_ref|   (also l1)
+TOL_DS2 = 1e-8      # dl/dsigma2, relative
+TOL_GRAD = 1e-7     # gradient, max-abs error relative to max-abs entry
+TOL_COEFF = 1e-7    # mean coefficients t, same norm
+TOL_ROW = 1e-10     # per-row intermediates r, 1/s
+TOL_SHARD = 1e-9    # two different row partitions of the same problem (different summation order)
 
 
 def _problem_for(g, chunk_rows=0):
@@ -76,8 +77,8 @@ def test_chunking_does_not_change_results():
     g = load_golden("iso_ragged")
     p1, p2 = _problem_for(g), _problem_for(g, chunk_rows=256)
     a, b = _eval_golden(p1, g), _eval_golden(p2, g)
-    assert abs(a.l - b.l) <= 1e-11 * abs(a.l)
-    assert relinf(a.grad, b.grad) <= 1e-9
+    assert abs(a.l - b.l) <= TOL_SHARD * abs(a.l)
+    assert relinf(a.grad, b.grad) <= 100 * TOL_SHARD
     p1.close()
     p2.close()
 
@@ -169,9 +170,9 @@ def test_two_shards_on_one_device_equal_the_whole():
     torch.cuda.synchronize()
     evs = [p.eval_finish(tot2.data_ptr()) for p in shards]
     for ev in evs:
-        assert abs(ev.l - ref.l) <= 1e-11 * abs(ref.l)
-        assert abs(ev.dl_dsigma2 - ref.dl_dsigma2) <= 1e-9 * abs(ref.dl_dsigma2)
-        assert relinf(ev.grad, ref.grad) <= 1e-8
+        assert abs(ev.l - ref.l) <= TOL_SHARD * abs(ref.l)
+        assert abs(ev.dl_dsigma2 - ref.dl_dsigma2) <= TOL_SHARD * abs(ref.dl_dsigma2)
+        assert relinf(ev.grad, ref.grad) <= 100 * TOL_SHARD
     for p in shards + [whole]:
         p.close()
 
