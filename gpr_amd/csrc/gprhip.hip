@@ -81,7 +81,7 @@ struct gprhip_problem {
   int D = 0, d = 0, m = 0, mp = 0;
   int64_t chunk = 0;
   int nchunks = 0;
-  int kslices = 32;  // upper bound on the split-K factor (partial-sum buffers allocated)
+  int kslices = 64;  // upper bound on the split-K factor (partial-sum buffers allocated)
   hipStream_t stream = nullptr;
   std::vector<void*> allocs;
 
@@ -121,6 +121,12 @@ struct gprhip_problem {
   }
   const double* pts() const { return kind == GPRHIP_COV_SE_FAT && h.tproj ? P : X; }
   int64_t rows_of(int c) const { return std::min<int64_t>(chunk, n - (int64_t)c * chunk); }
+  // rows of the resident n x m store: full chunks are contiguous, the last one is padded to the tile
+  int64_t rows_total_padded() const {
+    return (int64_t)(nchunks - 1) * chunk + round_up(rows_of(nchunks - 1), TILE);
+  }
+  int ks_used = 8;
+  int tile_order = 0;
 };
 
 namespace {
@@ -257,17 +263,18 @@ void upload_hypers(gprhip_problem* p, const gprhip_hypers* h) {
   }
 }
 
-// Split-K factor of the SYRK-shaped accumulations: the (upper tiles) x (slices) blocks should fill
-// a whole number of residency rounds (256 CUs x 2 resident blocks) so no round runs part-empty.
-int pick_kslices(int mp, int rows_p, int max_slices) {
+// Split-K factor of the SYRK-shaped accumulations over training points.  Slices are dealt to the
+// 8 XCDs (mfma_gemm.hip), so the factor is a multiple of 8, and (tiles x slices / 8) should fill a
+// whole number of residency rounds of one XCD (32 CUs x 2 resident blocks) so no round runs part-empty.
+int pick_kslices(int mp, int64_t rows_p, int max_slices) {
   const int nt = mp / TILE, tiles = nt * (nt + 1) / 2;
-  const int slots = 512;
-  const int kmax = std::max(1, std::min(max_slices, rows_p / (BK * 8)));
-  int best = 1;
+  const int slots = 64;
+  const int64_t kmax = std::max<int64_t>(8, std::min<int64_t>(max_slices, rows_p / (BK * 16)));
+  int best = 8;
   double best_eff = 0.0;
-  for (int ks = 1; ks <= kmax; ++ks) {
-    const int blocks = tiles * ks;
-    const double eff = (double)blocks / ((double)((blocks + slots - 1) / slots) * slots);
+  for (int ks = 8; ks <= kmax; ks += 8) {
+    const int items = tiles * (ks / 8);
+    const double eff = (double)items / ((double)((items + slots - 1) / slots) * slots);
     if (eff > best_eff + 1e-9) {
       best_eff = eff;
       best = ks;
@@ -297,14 +304,13 @@ void do_pass1(gprhip_problem* p, const gprhip_hypers* h, int want_grad, int64_t 
   const int64_t mm = (int64_t)mp * mp;
   double* ar1_c = ar1 + mm;
   double* ar1_tail = ar1_c + mp;
-  if (want_grad && !p->Vstore)  // V = K U^-1 for all rows of the shard stays resident between the passes
+  if (!p->Vstore)  // V = K U^-1 for all rows of the shard stays resident (one SYRK launch; pass 2 re-reads it)
     p->Vstore = p->alloc<double>((int64_t)p->nchunks * p->chunk * mp);
 
   tstart(p, "km_chol");
   GPR_HIP(hipMemsetAsync(p->info, 0, 2 * sizeof(int), s));
   GPR_HIP(hipMemsetAsync(p->scal, 0, NSCAL * sizeof(double), s));
   GPR_HIP(hipMemsetAsync(ar1_c, 0, (size_t)(mp + A1_TAIL) * sizeof(double), s));
-  GPR_HIP(hipMemsetAsync(p->slices, 0, (size_t)p->kslices * mm * sizeof(double), s));
   launch_cov_upper(p->cp, p->Z, p->m, mp, p->d, h->jitter, p->km, p->kj, s);
   GPR_HIP(hipMemcpyAsync(p->umat, p->kj, (size_t)mm * sizeof(double), hipMemcpyDeviceToDevice, s));
   potrf_upper(p, p->umat, p->info);  // U = chol(K_m + jitter), lib/fitc_gp.ml:53-57
@@ -315,14 +321,14 @@ void do_pass1(gprhip_problem* p, const gprhip_hypers* h, int want_grad, int64_t 
     const int64_t rows = p->rows_of(c);
     const int rows_p = (int)round_up(rows, TILE);
     const int64_t base = (int64_t)c * p->chunk;
-    double* V = want_grad ? p->Vstore + base * mp : p->bufB;
+    double* V = p->Vstore + base * mp;
     tstart(p, "p1_cov");
     cov_chunk(p, c, p->bufA);
     tstop(p);
     tstart(p, "p1_trmm_V");
     GemmArgs g;  // V = K U^-1   (dtrsm `R, lib/fitc_gp.ml:226-227)
     g.A = p->bufA; g.lda = mp; g.B = p->uinv; g.ldb = mp; g.C = V; g.ldc = mp;
-    g.M = rows_p; g.N = mp; g.K = mp; g.tri = TRI_KHI_BN;
+    g.M = rows_p; g.N = mp; g.K = mp; g.tri = TRI_KHI_BN; g.order = p->tile_order;
     launch_gemm(OP_NN, g, s);
     tstop(p);
     tstart(p, "p1_rows");
@@ -333,19 +339,24 @@ void do_pass1(gprhip_problem* p, const gprhip_hypers* h, int want_grad, int64_t 
     launch_pass1_rows(ra, s);
     launch_reduce_rows(p->rowpart, pass1_row_blocks(rows_p), 4, ar1_tail, 1, s);
     tstop(p);
-    tstart(p, "p1_syrk_B");
-    GemmArgs b;  // B~_part += V^T diag(is) V   (R~^T R~ replaces the stacked QR's R, lib/fitc_gp.ml:170-182)
-    b.A = V; b.lda = mp; b.B = V; b.ldb = mp; b.C = p->slices; b.ldc = mp;
-    b.M = mp; b.N = mp; b.K = rows_p; b.beta = 1.0; b.scale_k = p->is + base; b.upper_only = 1;
-    b.kslices = pick_kslices(mp, rows_p, p->kslices); b.slice_stride = mm;
-    launch_gemm(OP_TN, b, s);
-    tstop(p);
-    tstart(p, "p1_gemv_c");
-    launch_gemv_t_partial(V, rows_p, mp, p->yis + base, p->gemvpart, s);
-    launch_reduce_rows(p->gemvpart, (rows_p + 255) / 256, mp, ar1_c, 1, s);
-    tstop(p);
   }
-  launch_sum_slices(nullptr, p->slices, p->kslices, mm, mp, ar1, s);
+  // one SYRK-shaped launch over all rows of the shard (V is resident): B~_part = V^T diag(is) V
+  // (R~^T R~ replaces the stacked QR's R, lib/fitc_gp.ml:170-182), and c~ = V^T (is .* y)
+  const int64_t ktot = p->rows_total_padded();
+  const int ks = pick_kslices(mp, ktot, p->kslices);
+  tstart(p, "p1_syrk_B");
+  GemmArgs b;
+  b.A = p->Vstore; b.lda = mp; b.B = p->Vstore; b.ldb = mp; b.C = p->slices; b.ldc = mp;
+  b.M = mp; b.N = mp; b.K = (int)ktot; b.beta = 0.0; b.scale_k = p->is; b.upper_only = 1;
+  b.kslices = ks; b.slice_stride = mm;
+  launch_gemm(OP_TN, b, s);
+  tstop(p);
+  tstart(p, "p1_gemv_c");
+  launch_gemv_t_partial(p->Vstore, (int)ktot, mp, p->yis, p->gemvpart, s);
+  launch_reduce_rows(p->gemvpart, (int)((ktot + 255) / 256), mp, ar1_c, 1, s);
+  tstop(p);
+  p->ks_used = ks;
+  launch_sum_slices(nullptr, p->slices, ks, mm, mp, ar1, s);
   p->stage = 1;
 }
 
@@ -381,7 +392,6 @@ void do_pass2(gprhip_problem* p, const double* ar1, double* ar2) {
   if (p->want_grad) {
     tstart(p, "inverses");
     triu_xxt(p, p->rinv, p->binv);  // B~^-1 (upper tiles)
-    GPR_HIP(hipMemsetAsync(p->slices, 0, (size_t)p->kslices * mm * sizeof(double), s));
     tstop(p);
     for (int c = 0; c < p->nchunks; ++c) {
       const int64_t rows = p->rows_of(c);
@@ -391,7 +401,7 @@ void do_pass2(gprhip_problem* p, const double* ar1, double* ar2) {
       tstart(p, "p2_trmm_Q");
       GemmArgs q;  // Q' = V R~^-1 = K R^-1  (Q_n = diag(sqrt is) Q', lib/fitc_gp.ml:176-182)
       q.A = V; q.lda = mp; q.B = p->rinv; q.ldb = mp; q.C = p->bufA; q.ldc = mp;
-      q.M = rows_p; q.N = mp; q.K = mp; q.tri = TRI_KHI_BN;
+      q.M = rows_p; q.N = mp; q.K = mp; q.tri = TRI_KHI_BN; q.order = p->tile_order;
       launch_gemm(OP_NN, q, s);
       tstop(p);
       tstart(p, "p2_rows");
@@ -406,7 +416,7 @@ void do_pass2(gprhip_problem* p, const double* ar1, double* ar2) {
       tstart(p, "p2_trmm_S");
       GemmArgs sg;  // X~ = diag(is) Q' R~^-T - diag(v) V - w t~^T   (S, U_mat and the ger of :936-938, :1204-1206)
       sg.A = p->bufA; sg.lda = mp; sg.B = p->rinv; sg.ldb = mp; sg.C = p->bufB; sg.ldc = mp;
-      sg.M = rows_p; sg.N = mp; sg.K = mp; sg.tri = TRI_KLO_BN;
+      sg.M = rows_p; sg.N = mp; sg.K = mp; sg.tri = TRI_KLO_BN; sg.order = p->tile_order;
       sg.epi_rows_a = p->is + base; sg.epi_rows_b = p->v + base; sg.epi_rows_c = p->w + base;
       sg.epi_col = p->ttil; sg.epi_mat = V; sg.epi_ldm = mp;
       launch_gemm(OP_NT, sg, s);
@@ -414,15 +424,8 @@ void do_pass2(gprhip_problem* p, const double* ar1, double* ar2) {
       tstart(p, "p2_trmm_X");
       GemmArgs xg;  // X = X~ U^-T
       xg.A = p->bufB; xg.lda = mp; xg.B = p->uinv; xg.ldb = mp; xg.C = p->bufA; xg.ldc = mp;
-      xg.M = rows_p; xg.N = mp; xg.K = mp; xg.tri = TRI_KLO_BN;
+      xg.M = rows_p; xg.N = mp; xg.K = mp; xg.tri = TRI_KLO_BN; xg.order = p->tile_order;
       launch_gemm(OP_NT, xg, s);
-      tstop(p);
-      tstart(p, "p2_syrk_W");
-      GemmArgs wg;  // G~_part += V^T diag(v) V   (the two dsyrk of lib/fitc_gp.ml:1198-1203, whitened, in one)
-      wg.A = V; wg.lda = mp; wg.B = V; wg.ldb = mp; wg.C = p->slices; wg.ldc = mp;
-      wg.M = mp; wg.N = mp; wg.K = rows_p; wg.beta = 1.0; wg.scale_k = p->v + base; wg.upper_only = 1;
-      wg.kslices = pick_kslices(mp, rows_p, p->kslices); wg.slice_stride = mm;
-      launch_gemm(OP_TN, wg, s);
       tstop(p);
       tstart(p, "p2_grad");
       GradArgs ga;
@@ -436,7 +439,16 @@ void do_pass2(gprhip_problem* p, const double* ar1, double* ar2) {
       launch_reduce_rows(p->scalpart, nslabs * ((mp + 255) / 256), 2, ar2_tail + A2_SUME, 1, s);
       tstop(p);
     }
-    launch_sum_slices(nullptr, p->slices, p->kslices, mm, mp, ar2, s);
+    // G~_part = V^T diag(v) V over all rows (the two dsyrk of lib/fitc_gp.ml:1198-1203, whitened, in one)
+    const int64_t ktot = p->rows_total_padded();
+    tstart(p, "p2_syrk_W");
+    GemmArgs wg;
+    wg.A = p->Vstore; wg.lda = mp; wg.B = p->Vstore; wg.ldb = mp; wg.C = p->slices; wg.ldc = mp;
+    wg.M = mp; wg.N = mp; wg.K = (int)ktot; wg.beta = 0.0; wg.scale_k = p->v; wg.upper_only = 1;
+    wg.kslices = p->ks_used; wg.slice_stride = mm;
+    launch_gemm(OP_TN, wg, s);
+    tstop(p);
+    launch_sum_slices(nullptr, p->slices, p->ks_used, mm, mp, ar2, s);
   }
   p->stage = 2;
 }
@@ -598,6 +610,7 @@ int gprhip_problem_create(int device, int cov_kind, int64_t n, int D, int d, int
     p->nchunks = (int)((n + chunk - 1) / chunk);
     if (const char* e = getenv("GPRHIP_KSLICES")) p->kslices = std::max(1, atoi(e));
     if (const char* e = getenv("GPRHIP_TIMING")) p->timer.on = atoi(e) != 0;
+    if (const char* e = getenv("GPRHIP_TILE_ORDER")) p->tile_order = atoi(e);
     GPR_HIP(hipStreamCreate(&p->stream));
     const int mp = p->mp;
     const int64_t mm = (int64_t)mp * mp;
@@ -623,7 +636,7 @@ int gprhip_problem_create(int device, int cov_kind, int64_t n, int D, int d, int
     p->bufA = p->alloc<double>(chunk * mp); p->bufB = p->alloc<double>(chunk * mp);
     p->slices = p->alloc<double>((int64_t)p->kslices * mm);
     p->rowpart = p->alloc<double>((int64_t)pass1_row_blocks((int)chunk) * 4);
-    p->gemvpart = p->alloc<double>(((chunk + 255) / 256) * mp);
+    p->gemvpart = p->alloc<double>(((npad + 255) / 256) * mp);
     const int64_t nslab = (chunk + grad_slab_rows() - 1) / grad_slab_rows();
     p->colpart = p->alloc<double>(nslab * (d + 1) * mp);
     p->scalpart = p->alloc<double>(nslab * ((mp + 255) / 256) * 2);

@@ -24,11 +24,30 @@ constexpr int KS = 144;               // k-major row stride
 constexpr int STAGE = 128 * XS;       // == 16 * KS == 2304 doubles per operand per stage
 constexpr int LDS_BYTES = 4 * STAGE * 8;
 
-__device__ __forceinline__ void tile_of_block(const GemmArgs& g, int t, int nbm, int nbn, int& bm,
-                                              int& bn) {
+// Block -> (row tile, column tile, k-slice).  The hardware dispatcher places block b on XCD b % 8
+// (observed, used for speed only): blocks are renumbered so that the blocks one XCD receives
+// back-to-back share operand panels through that XCD's L2 --
+//   full grids   : XCD x owns row panels x, x+8, ...; all column tiles of a panel run together
+//                  (the A panel is fetched once per XCD instead of once per column tile);
+//   split-K grids: XCD x owns k-slices x, x+8, ...; all output tiles of a slice run together
+//                  (every tile of the slice streams the same rows of the operand).
+__device__ __forceinline__ void tile_of_block(const GemmArgs& g, int b, int nbm, int nbn, int& bm,
+                                              int& bn, int& slice) {
+  slice = 0;
   if (g.upper_only) {
+    const int total = nbn * (nbn + 1) / 2;
+    int t = b;
+    if (g.kslices > 1) {
+      if (g.kslices % 8 == 0) {
+        const int x = b & 7, q = b >> 3;
+        slice = (q / total) * 8 + x;
+        t = q % total;
+      } else {
+        slice = b / total;
+        t = b % total;
+      }
+    }
     // enumerate (bm <= bn) pairs; heavy tiles first for the triangular k-ranges
-    int total = nbn * (nbn + 1) / 2;
     if (g.tri == TRI_KHI_MIN) t = total - 1 - t;
     int c = 0;
     while (t >= c + 1) {
@@ -40,12 +59,19 @@ __device__ __forceinline__ void tile_of_block(const GemmArgs& g, int t, int nbm,
     return;
   }
   if (g.tri == TRI_KLO_BM) {
-    bm = t / nbn;
-    bn = t % nbn;
+    bm = b / nbn;
+    bn = b % nbn;
     return;
   }
-  int bi = t / nbm;
-  bm = t % nbm;
+  int bi;
+  if (g.order == 1 && nbm % 8 == 0) {  // XCD-local row panels (all column tiles of a panel together)
+    const int x = b & 7, q = b >> 3;
+    bm = (q / nbn) * 8 + x;
+    bi = q % nbn;
+  } else {  // column-tile major: every resident block has the same k-range and shares the B panel
+    bi = b / nbm;
+    bm = b % nbm;
+  }
   bn = (g.tri == TRI_KHI_BN) ? (nbn - 1 - bi) : bi;
 }
 
@@ -62,14 +88,14 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
   const int l15 = lane & 15, lq = lane >> 4;
 
   const int nbm = g.M / TILE, nbn = g.N / TILE;
-  int bm, bn;
-  tile_of_block(g, blockIdx.x, nbm, nbn, bm, bn);
+  int bm, bn, slice;
+  tile_of_block(g, blockIdx.x, nbm, nbn, bm, bn, slice);
 
   // k-range of this block, in elements
   int k_lo = 0, k_hi = g.K;
   if (g.kslices > 1) {
     int per = ((g.K / BK + g.kslices - 1) / g.kslices) * BK;
-    k_lo = blockIdx.z * per;
+    k_lo = slice * per;
     k_hi = min(g.K, k_lo + per);
   }
   switch (g.tri) {
@@ -190,7 +216,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
 
   // ---- epilogue
   const int row0 = bm * TILE + wr * 64 + lq, col0 = bn * TILE + wc * 64 + l15;
-  double* Cp = g.C + (int64_t)blockIdx.z * g.slice_stride + (int64_t)row0 * g.ldc + col0;
+  double* Cp = g.C + (int64_t)slice * g.slice_stride + (int64_t)row0 * g.ldc + col0;
   const double alpha = g.alpha, beta = g.beta;
   if (g.epi_rows_a) {
     // fused X~ epilogue: C[i][j] = ra[i]*acc - rb[i]*M[i][j] - rc[i]*cv[j]
@@ -245,7 +271,11 @@ void launch_gemm(GemmOp op, const GemmArgs& g, hipStream_t stream) {
   }
   const int nbm = g.M / TILE, nbn = g.N / TILE;
   int tiles = g.upper_only ? nbn * (nbn + 1) / 2 : nbm * nbn;
-  dim3 grid(tiles, 1, g.kslices > 1 ? g.kslices : 1);
+  if (g.kslices > 1 && !g.upper_only) {
+    set_error("gprhip: launch_gemm: split-K is implemented for upper_only (SYRK-shaped) launches");
+    throw HipFail{ST_BAD_ARG};
+  }
+  dim3 grid(tiles * (g.kslices > 1 ? g.kslices : 1));
   dim3 block(256);
   switch (op) {
     case OP_NN: hipLaunchKernelGGL(gemm_kernel<OP_NN>, grid, block, LDS_BYTES, stream, g); break;
