@@ -92,7 +92,8 @@ struct gprhip_problem {
          *tmp = nullptr, *dinv = nullptr;
   double *bvec = nullptr, *ttil = nullptr, *tvec = nullptr, *scal = nullptr;
   int* info = nullptr;
-  double *r = nullptr, *is = nullptr, *yis = nullptr, *w = nullptr, *v = nullptr;
+  double *r = nullptr, *is = nullptr, *yis = nullptr, *w = nullptr, *v = nullptr, *es = nullptr;
+  double* projpart = nullptr;
   double *bufA = nullptr, *bufB = nullptr, *Vstore = nullptr;
   double* slices = nullptr;
   double *rowpart = nullptr, *gemvpart = nullptr, *colpart = nullptr, *scalpart = nullptr,
@@ -127,6 +128,10 @@ struct gprhip_problem {
   }
   int ks_used = 8;
   int tile_order = 0;
+  // Cov_se_fat `Proj hypers: rows of the exchange-2 column block beyond d+1, and the D x d second term
+  int dbig() const { return kind == GPRHIP_COV_SE_FAT ? D : 0; }
+  bool has_proj() const { return kind == GPRHIP_COV_SE_FAT && h.tproj != nullptr; }
+  int64_t col_rows() const { return d + 1 + dbig(); }
 };
 
 namespace {
@@ -230,6 +235,10 @@ void upload_hypers(gprhip_problem* p, const gprhip_hypers* h) {
   }
   if (p->kind == GPRHIP_COV_SE_ISO && h->tproj) {
     set_error("gprhip: tproj given for Cov_se_iso");
+    throw HipFail{ST_BAD_ARG};
+  }
+  if (p->kind == GPRHIP_COV_SE_FAT && h->tproj && p->D > 64) {
+    set_error("gprhip: Cov_se_fat with tproj supports input dimension D <= 64");
     throw HipFail{ST_BAD_ARG};
   }
   if (p->kind == GPRHIP_COV_SE_FAT && !h->tproj && p->D != p->d) {
@@ -371,8 +380,10 @@ void do_pass2(gprhip_problem* p, const double* ar1, double* ar2) {
   const int64_t mm = (int64_t)mp * mp;
   const double* ar1_c = ar1 + mm;
   double* ar2_col = ar2 + mm;
-  double* ar2_tail = ar2_col + (int64_t)(p->d + 1) * mp;
+  double* ar2_proj = ar2_col + p->col_rows() * mp;
+  double* ar2_tail = ar2_proj + (int64_t)p->dbig() * p->d;
   const bool mo = p->h.model_only != 0;
+  const bool proj = p->has_proj();
 
   tstart(p, "b_chol");
   // B~ = I + sum of shard parts; R~ = chol(B~): R = R~ U is the reference's r_mat (lib/fitc_gp.ml:181)
@@ -409,6 +420,7 @@ void do_pass2(gprhip_problem* p, const double* ar1, double* ar2) {
       ra.Q = p->bufA; ra.b = p->bvec;
       ra.y = mo ? nullptr : p->y + base; ra.is = p->is + base; ra.r = p->r + base;
       ra.rows = (int)rows; ra.mp = mp; ra.variational = p->h.variational;
+      ra.sf2 = p->cp.sf2; ra.es = proj ? p->es + base : nullptr;
       ra.w = p->w + base; ra.v = p->v + base; ra.partial = p->rowpart;
       launch_pass2_rows(ra, s);
       launch_reduce_rows(p->rowpart, pass1_row_blocks(rows_p), 4, ar2_tail, 1, s);
@@ -433,9 +445,15 @@ void do_pass2(gprhip_problem* p, const double* ar1, double* ar2) {
       ga.rows = (int)rows; ga.rows_p = rows_p; ga.m = p->m; ga.mp = mp; ga.d = p->d;
       ga.log_sf2 = p->cp.log_sf2; ga.inv_ell2_05 = p->cp.inv_ell2_05;
       ga.colpart = p->colpart; ga.scalpart = p->scalpart;
+      ga.big = proj ? p->X + base * p->D : nullptr; ga.D = proj ? p->D : 0;
       launch_grad_fused(ga, s);
       const int nslabs = (int)((rows + grad_slab_rows() - 1) / grad_slab_rows());
-      launch_reduce_rows(p->colpart, nslabs, (p->d + 1) * mp, ar2_col, 1, s);
+      launch_reduce_rows(p->colpart, nslabs, (p->d + 1 + ga.D) * mp, ar2_col, 1, s);
+      if (proj) {
+        launch_proj_term2(p->X + base * p->D, p->P + base * p->d, p->es + base, (int)rows, p->D, p->d,
+                          p->projpart, s);
+        launch_reduce_rows(p->projpart, (int)((rows + 255) / 256), p->D * p->d, ar2_proj, 1, s);
+      }
       launch_reduce_rows(p->scalpart, nslabs * ((mp + 255) / 256), 2, ar2_tail + A2_SUME, 1, s);
       tstop(p);
     }
@@ -463,7 +481,8 @@ void do_finish(gprhip_problem* p, const double* ar2, gprhip_result* res, double*
   const int mp = p->mp, m = p->m, d = p->d;
   const int64_t mm = (int64_t)mp * mp;
   const double* ar2_col = ar2 + mm;
-  const double* ar2_tail = ar2_col + (int64_t)(d + 1) * mp;
+  const double* ar2_proj = ar2_col + p->col_rows() * mp;
+  const double* ar2_tail = ar2_proj + (int64_t)p->dbig() * d;
   const int nkslab = (m + 255) / 256;
   if (p->want_grad) {
     tstart(p, "finish");
@@ -488,7 +507,7 @@ void do_finish(gprhip_problem* p, const double* ar2, gprhip_result* res, double*
   GPR_HIP(hipMemcpyAsync(ht.data(), p->tvec, mp * sizeof(double), hipMemcpyDeviceToHost, s));
   GPR_HIP(hipMemcpyAsync(hinfo, p->info, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
   if (p->want_grad) {
-    hcol.resize((size_t)(d + 1) * mp);
+    hcol.resize((size_t)(p->col_rows() * mp + (int64_t)p->dbig() * d));  // column block + Proj second term
     hkm.resize((size_t)(d + 2) * mp);
     GPR_HIP(hipMemcpyAsync(hcol.data(), ar2_col, hcol.size() * sizeof(double), hipMemcpyDeviceToHost, s));
     GPR_HIP(hipMemcpyAsync(hkm.data(), p->kmred, hkm.size() * sizeof(double), hipMemcpyDeviceToHost, s));
@@ -551,6 +570,20 @@ void do_finish(gprhip_problem* p, const double* ar2, gprhip_result* res, double*
       const double dkm_half = scale * hkm[(size_t)(2 + k) * mp + c];
       const double dknm = scale * (hcol[(size_t)(k + 1) * mp + c] - zk * hcol[c]);
       grad[pos++] = dkm_half - dknm;
+    }
+  }
+  // Proj {big_dim; small_dim} (lib/cov_se_fat.ml:429, :531, :570-596): dkm, dkn_diag `Const 0.;
+  // dknm `Dense x_big,r (z_small,c - p_small,r) K_rc
+  if (p->has_proj()) {
+    const int D = p->D;
+    const double* m1 = hcol.data() + (size_t)(d + 1) * mp;       // [big][c] = sum_r x_big,r E_rc
+    const double* term2 = hcol.data() + (size_t)p->col_rows() * mp;  // [big][small]
+    for (int big = 0; big < D; ++big) {
+      for (int small = 0; small < d; ++small) {
+        double term1 = 0.0;
+        for (int c = 0; c < m; ++c) term1 += p->hZ[(size_t)c * d + small] * m1[(size_t)big * mp + c];
+        grad[pos++] = -(term1 - term2[(size_t)big * d + small]);
+      }
     }
   }
   res->n_hypers = pos;
@@ -633,17 +666,21 @@ int gprhip_problem_create(int device, int cov_kind, int64_t n, int D, int d, int
     p->info = p->alloc<int>(2);
     p->r = p->alloc<double>(npad); p->is = p->alloc<double>(npad); p->yis = p->alloc<double>(npad);
     p->w = p->alloc<double>(npad); p->v = p->alloc<double>(npad);
+    if (cov_kind == GPRHIP_COV_SE_FAT) {
+      p->es = p->alloc<double>(npad);
+      p->projpart = p->alloc<double>(((chunk + 255) / 256) * (int64_t)D * d);
+    }
     p->bufA = p->alloc<double>(chunk * mp); p->bufB = p->alloc<double>(chunk * mp);
     p->slices = p->alloc<double>((int64_t)p->kslices * mm);
     p->rowpart = p->alloc<double>((int64_t)pass1_row_blocks((int)chunk) * 4);
     p->gemvpart = p->alloc<double>(((npad + 255) / 256) * mp);
     const int64_t nslab = (chunk + grad_slab_rows() - 1) / grad_slab_rows();
-    p->colpart = p->alloc<double>(nslab * (d + 1) * mp);
+    p->colpart = p->alloc<double>(nslab * p->col_rows() * mp);
     p->scalpart = p->alloc<double>(nslab * ((mp + 255) / 256) * 2);
     p->kmpart = p->alloc<double>((int64_t)((m + 255) / 256) * (d + 2) * mp);
     p->kmred = p->alloc<double>((int64_t)(d + 2) * mp);
     p->ar1 = p->alloc<double>(mm + mp + A1_TAIL);
-    p->ar2 = p->alloc<double>(mm + (int64_t)(d + 1) * mp + A2_TAIL);
+    p->ar2 = p->alloc<double>(gprhip_ar2_len(p));
     GPR_HIP(hipMemsetAsync(p->y, 0, (size_t)npad * sizeof(double), p->stream));
     GPR_HIP(hipStreamSynchronize(p->stream));
   });
@@ -724,7 +761,7 @@ int64_t gprhip_n_hypers(const gprhip_problem* p, int has_tproj) {
 
 int64_t gprhip_ar1_len(const gprhip_problem* p) { return (int64_t)p->mp * p->mp + p->mp + A1_TAIL; }
 int64_t gprhip_ar2_len(const gprhip_problem* p) {
-  return (int64_t)p->mp * p->mp + (int64_t)(p->d + 1) * p->mp + A2_TAIL;
+  return (int64_t)p->mp * p->mp + p->col_rows() * p->mp + (int64_t)p->dbig() * p->d + A2_TAIL;
 }
 
 int gprhip_eval_pass1(gprhip_problem* p, const gprhip_hypers* h, int want_grad, int64_t n_total,

@@ -70,6 +70,8 @@ struct Pass2RowArgs {
   const double* is;      // [rows_p]
   const double* r;       // [rows]
   int rows, mp, variational;
+  double sf2;
+  double* es;            // optional out [rows_p]: rowsum(X .* K) = q - v (sf2 - r) - w (K t)  (Proj gradient)
   double* w;             // out [rows_p]  (padding 0)
   double* v;             // out [rows_p]  (padding 0)
   double* partial;       // out [nblocks][4]: sum v, sum is, sum w*(y-Kt) (= sum is*res^2), sum v1
@@ -89,9 +91,15 @@ struct GradArgs {
   const double* Z;       // [mp][d]
   int rows, rows_p, m, mp, d;
   double log_sf2, inv_ell2_05;  // K_rc = exp(log_sf2 + inv_ell2_05*|x_r - z_c|^2) is recomputed on the fly
-  double* colpart;       // out [nslabs][(d+1)][mp]: row 0 = column sums of E, rows 1..d = sum_r x_kr E_rc
+  const double* big;     // [rows][D] original inputs of the chunk (Cov_se_fat with tproj), else null
+  int D;                 // big dimension (0 when big == null)
+  double* colpart;       // out [nslabs][(d+1+D)][mp]: row 0 = column sums of E, rows 1..d = sum_r p_kr E_rc,
+                         //     rows d+1.. = sum_r x_big,r E_rc
   double* scalpart;      // out [nslabs][nbx][2]: sum E, sum E*sqr_diff
 };
+// part[slab][big*d + small] = sum_{r in slab} x_big,r * p_small,r * es_r   (slab = 256 rows)
+void launch_proj_term2(const double* X, const double* P, const double* es, int rows, int D, int d,
+                       double* part, hipStream_t s);
 int grad_slab_rows();
 void launch_grad_fused(const GradArgs& a, hipStream_t s);
 

@@ -100,6 +100,7 @@ __global__ __launch_bounds__(256) void pass2_rows_kernel(Pass2RowArgs a, int row
         const double v = v1 - w * w;
         a.w[row] = w;
         a.v[row] = v;
+        if (a.es) a.es[row] = qd - v * (a.sf2 - a.r[row]) - w * sb;
         p_v += v;
         p_is += is;
         p_res += w * res;
@@ -107,6 +108,7 @@ __global__ __launch_bounds__(256) void pass2_rows_kernel(Pass2RowArgs a, int row
       } else {
         a.w[row] = 0.0;
         a.v[row] = 0.0;
+        if (a.es) a.es[row] = 0.0;
       }
     }
   }
@@ -196,18 +198,21 @@ void launch_reduce_rows(const double* partial, int nslabs, int width, double* ou
 constexpr int GRAD_SLAB = 256;
 int grad_slab_rows() { return GRAD_SLAB; }
 
-template <int DT>
+template <int DT, int DBT>
 __global__ __launch_bounds__(256) void grad_fused_kernel(GradArgs a) {
   __shared__ double red[4][2];
   const int j = blockIdx.x * 256 + threadIdx.x;
   const int jj = min(j, a.mp - 1);
   const bool live = (j < a.m);
   double z[DT], gx[DT];
+  double gb[DBT > 0 ? DBT : 1];
 #pragma unroll
   for (int k = 0; k < DT; ++k) {
     z[k] = (k < a.d && live) ? a.Z[(int64_t)jj * a.d + k] : 0.0;
     gx[k] = 0.0;
   }
+#pragma unroll
+  for (int k = 0; k < DBT; ++k) gb[k] = 0.0;
   double cs = 0.0, sE = 0.0, sED = 0.0;
   const int r0 = blockIdx.y * GRAD_SLAB;
   const int r1 = min(a.rows, r0 + GRAD_SLAB);
@@ -228,16 +233,25 @@ __global__ __launch_bounds__(256) void grad_fused_kernel(GradArgs a) {
 #pragma unroll
     for (int k = 0; k < DT; ++k)
       if (k < a.d) gx[k] += xr[k] * e;
+    if (DBT > 0) {
+      const double* xb = a.big + (int64_t)r * a.D;
+#pragma unroll
+      for (int k = 0; k < DBT; ++k)
+        if (k < a.D) gb[k] += xb[k] * e;
+    }
     cs += e;
     sE += e;
     sED += e * dist;
   }
   if (j < a.mp) {
-    double* cp = a.colpart + (int64_t)blockIdx.y * (a.d + 1) * a.mp;
+    double* cp = a.colpart + (int64_t)blockIdx.y * (a.d + 1 + a.D) * a.mp;
     cp[j] = cs;
 #pragma unroll
     for (int k = 0; k < DT; ++k)
       if (k < a.d) cp[(int64_t)(k + 1) * a.mp + j] = gx[k];
+#pragma unroll
+    for (int k = 0; k < DBT; ++k)
+      if (k < a.D) cp[(int64_t)(a.d + 1 + k) * a.mp + j] = gb[k];
   }
   sE = wave_sum(sE);
   sED = wave_sum(sED);
@@ -254,16 +268,47 @@ __global__ __launch_bounds__(256) void grad_fused_kernel(GradArgs a) {
   }
 }
 
+// Cov_se_fat `Proj {big; small}` (lib/cov_se_fat.ml:570-596): second term of
+//   -tr(X^T dK) = -[ sum_c z_small,c sum_r x_big,r E_rc  -  sum_r x_big,r p_small,r rowsum(E)_r ]
+__global__ __launch_bounds__(256) void proj_term2_kernel(const double* __restrict__ X,
+                                                         const double* __restrict__ P,
+                                                         const double* __restrict__ es, int rows, int D,
+                                                         int d, double* __restrict__ part) {
+  const int r0 = blockIdx.y * 256, r1 = min(rows, r0 + 256);
+  for (int idx = blockIdx.x * 256 + threadIdx.x; idx < D * d; idx += gridDim.x * 256) {
+    const int big = idx / d, small = idx % d;
+    double acc = 0.0;
+    for (int r = r0; r < r1; ++r) acc += X[(int64_t)r * D + big] * P[(int64_t)r * d + small] * es[r];
+    part[(int64_t)blockIdx.y * D * d + idx] = acc;
+  }
+}
+
+void launch_proj_term2(const double* X, const double* P, const double* es, int rows, int D, int d,
+                       double* part, hipStream_t s) {
+  dim3 grid((D * d + 255) / 256, (rows + 255) / 256);
+  hipLaunchKernelGGL(proj_term2_kernel, grid, dim3(256), 0, s, X, P, es, rows, D, d, part);
+  GPR_HIP(hipGetLastError());
+}
+
+template <int DT>
+static void grad_dispatch_big(const GradArgs& a, dim3 grid, hipStream_t s) {
+  if (!a.big) hipLaunchKernelGGL((grad_fused_kernel<DT, 0>), grid, dim3(256), 0, s, a);
+  else if (a.D <= 8) hipLaunchKernelGGL((grad_fused_kernel<DT, 8>), grid, dim3(256), 0, s, a);
+  else if (a.D <= 32) hipLaunchKernelGGL((grad_fused_kernel<DT, 32>), grid, dim3(256), 0, s, a);
+  else if (a.D <= 64) hipLaunchKernelGGL((grad_fused_kernel<DT, 64>), grid, dim3(256), 0, s, a);
+  else {
+    set_error("gprhip: Cov_se_fat input dimension D > 64 is not supported by the gradient kernel");
+    throw HipFail{ST_BAD_ARG};
+  }
+}
+
 void launch_grad_fused(const GradArgs& a, hipStream_t s) {
   dim3 grid((a.mp + 255) / 256, (a.rows + GRAD_SLAB - 1) / GRAD_SLAB);
-  auto go = [&](auto dt) {
-    hipLaunchKernelGGL((grad_fused_kernel<decltype(dt)::value>), grid, dim3(256), 0, s, a);
-  };
-  if (a.d <= 4) go(std::integral_constant<int, 4>{});
-  else if (a.d <= 8) go(std::integral_constant<int, 8>{});
-  else if (a.d <= 16) go(std::integral_constant<int, 16>{});
-  else if (a.d <= 32) go(std::integral_constant<int, 32>{});
-  else if (a.d <= 64) go(std::integral_constant<int, 64>{});
+  if (a.d <= 4) grad_dispatch_big<4>(a, grid, s);
+  else if (a.d <= 8) grad_dispatch_big<8>(a, grid, s);
+  else if (a.d <= 16) grad_dispatch_big<16>(a, grid, s);
+  else if (a.d <= 32) grad_dispatch_big<32>(a, grid, s);
+  else if (a.d <= 64) grad_dispatch_big<64>(a, grid, s);
   else {
     set_error("gprhip: input dimension d > 64 is not supported by the gradient kernel");
     throw HipFail{ST_BAD_ARG};

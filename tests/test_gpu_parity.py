@@ -73,6 +73,44 @@ def test_golden_iso(name):
     p.close()
 
 
+FAT_GOLDEN = [n for n in golden_names() if n.startswith("fat")]
+
+
+@pytest.mark.parametrize("name", FAT_GOLDEN)
+def test_golden_fat(name):
+    """Cov_se_fat (projection-only): Log_sf2, inducing and Proj hypers in lib/cov_se_fat.ml:290-342 order."""
+    g = load_golden(name)
+    p = _problem_for(g)
+    ev = _eval_golden(p, g)
+    assert abs(ev.l - g["l"]) <= TOL_L * abs(g["l"])
+    assert abs(ev.dl_dsigma2 - g["dl_dsigma2"]) <= TOL_DS2 * abs(g["dl_dsigma2"])
+    assert ev.grad.shape == g["grad"].shape
+    assert relinf(ev.grad, g["grad"]) <= TOL_GRAD
+    assert relinf(ev.coeffs, g["coeffs"]) <= TOL_COEFF
+    evm = _eval_golden(p, g, model_only=True)
+    assert relinf(evm.grad, g["model_grad"]) <= TOL_GRAD
+    p.close()
+
+
+def test_fat_functor_mirror_self_test():
+    """test/test_derivatives.ml uses Cov_se_fat: finite differences for Log_sf2, an inducing coordinate
+    and Proj entries through the mirrored functor (eps=1e-8, tol=1e-2 as in the reference)."""
+    rng = np.random.default_rng(9)
+    X = np.asfortranarray(rng.uniform(size=(3, 10)))
+    y = rng.uniform(size=10)
+    P = np.asfortranarray(rng.uniform(-1, 1, size=(3, 2)))
+    kernel = cov_se_fat.Kernel.create(cov_se_fat.Params.create(2, 0.3, P))
+    Z = np.asfortranarray((P.T @ X)[:, :5].copy())
+    GP = fitc_gp.Make_deriv(cov_se_fat)
+    FITC = GP.FITC
+    hypers = FITC.Deriv.Spec.HyperModule.get_all(kernel, Z, X)
+    assert len(hypers) == 1 + 2 * 5 + 3 * 2
+    FITC.Deriv.Test.self_test(kernel, Z, X, sigma2=1.0, targets=y, hyper="Sigma2")
+    for h in hypers:
+        FITC.Deriv.Test.self_test(kernel, Z, X, sigma2=1.0, targets=y, hyper=h)
+    GP.close()
+
+
 def test_chunking_does_not_change_results():
     g = load_golden("iso_ragged")
     p1, p2 = _problem_for(g), _problem_for(g, chunk_rows=256)
