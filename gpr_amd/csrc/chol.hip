@@ -8,39 +8,93 @@ namespace gprhip {
 
 constexpr int NB = TILE;        // 128
 constexpr int LDT = NB + 1;     // LDS row stride (bank spread)
-constexpr int POTRF_LDS = (NB * LDT) * 8 + 16;  // + flag word
+constexpr int MB = 16;          // micro-panel width
+// LDS: T[NB][LDT] | T1[NB][MB] (product scratch of the inversion) | D[MB][MB] | flag
+constexpr int POTRF_LDS = (NB * LDT + NB * MB + MB * MB) * 8 + 16;
 
-// A = U^T U in place on block j; strict lower of the block zeroed; dinv = inv(U_jj).
+// A = U^T U in place on block j (upper); strict lower of the block zeroed; dinv = inv(U_jj).
+//
+// Both phases advance by 16-column micro-panels so that the sequential part runs inside one
+// wavefront on registers (cross-lane shuffles, no workgroup barrier) and the workgroup only meets
+// at 3 barriers per micro-panel:
+//   factor : 16x16 diagonal block (wave 0, registers) -> 16 x rest panel solve (thread per column)
+//            -> rank-16 update of the trailing block (all threads)
+//   invert : inv of the 16x16 diagonal block (wave 0, registers) -> T1 = X[0:j0,0:j0] U[0:j0,j]
+//            -> X[0:j0,j] = -T1 inv(U_jj)   (in place, LAPACK dtrtri order)
 __global__ __launch_bounds__(256) void potrf_diag_kernel(double* __restrict__ A, int mp, int j,
                                                          double* __restrict__ dinv,
                                                          int* __restrict__ info) {
   extern __shared__ __attribute__((aligned(16))) double T[];  // [NB][LDT]
+  double* T1 = T + NB * LDT;                                   // [NB][MB]
+  double* Dm = T1 + NB * MB;                                   // [MB][MB]
+  int& bad = *reinterpret_cast<int*>(Dm + MB * MB);            // keep all LDS in the one dynamic array
   const int tid = threadIdx.x;
+  const int lane = tid & 63, wid = tid >> 6;
   double* Ab = A + (int64_t)j * NB * mp + (int64_t)j * NB;
   for (int idx = tid; idx < NB * NB; idx += 256) {
     int r = idx / NB, c = idx % NB;
     T[r * LDT + c] = Ab[(int64_t)r * mp + c];
   }
-  __syncthreads();
-  int& bad = *reinterpret_cast<int*>(T + NB * LDT);  // keep all LDS in the one dynamic array
   if (tid == 0) bad = 0;
   __syncthreads();
-  // right-looking unblocked Cholesky on the upper triangle
-  const int c = tid & (NB - 1);   // column owned
+
+  // ---------------- factor
+  const int c = tid & (NB - 1);   // column owned in the panel / trailing phases
   const int rh = tid >> 7;        // 0/1: which half of the rows
-  for (int k = 0; k < NB; ++k) {
-    double dkk = T[k * LDT + k];
-    if (!(dkk > 0.0)) {
-      if (tid == 0) bad = k + 1;
-      dkk = 1.0;  // keep going with finite numbers; caller reads `info`
+  for (int k0 = 0; k0 < NB; k0 += MB) {
+    if (wid == 0) {
+      const int cc = lane & 15;   // lanes 16..63 mirror lanes 0..15
+      double a[MB];
+#pragma unroll
+      for (int r = 0; r < MB; ++r) a[r] = T[(k0 + r) * LDT + k0 + cc];
+#pragma unroll
+      for (int q = 0; q < MB; ++q) {
+        double dq = __shfl(a[q], q);
+        if (!(dq > 0.0)) {
+          if (lane == 0 && bad == 0) bad = k0 + q + 1;
+          dq = 1.0;  // keep going with finite numbers; the caller reads `info`
+        }
+        const double piv = sqrt(dq);
+        double uqc = (cc == q) ? piv : a[q] / piv;
+        a[q] = uqc;
+#pragma unroll
+        for (int r = q + 1; r < MB; ++r) {
+          const double uqr = __shfl(uqc, r);
+          a[r] -= uqr * uqc;
+        }
+      }
+      if (lane < MB) {
+#pragma unroll
+        for (int r = 0; r < MB; ++r)
+          if (r <= cc) T[(k0 + r) * LDT + k0 + cc] = a[r];
+      }
     }
-    const double piv = sqrt(dkk);
     __syncthreads();
-    if (rh == 0 && c >= k) T[k * LDT + c] = (c == k) ? piv : T[k * LDT + c] / piv;
+    // panel: U12 = U11^-T A12, one thread per column (forward substitution in registers)
+    if (tid < NB && tid >= k0 + MB) {
+      double x[MB];
+#pragma unroll
+      for (int q = 0; q < MB; ++q) {
+        double s = T[(k0 + q) * LDT + tid];
+#pragma unroll
+        for (int i = 0; i < q; ++i) s -= T[(k0 + i) * LDT + k0 + q] * x[i];
+        x[q] = s / T[(k0 + q) * LDT + k0 + q];
+      }
+#pragma unroll
+      for (int q = 0; q < MB; ++q) T[(k0 + q) * LDT + tid] = x[q];
+    }
     __syncthreads();
-    if (c > k) {
-      const double ukc = T[k * LDT + c];
-      for (int r = k + 1 + rh; r <= c; r += 2) T[r * LDT + c] -= T[k * LDT + r] * ukc;
+    // trailing: A22 -= U12^T U12 on the upper triangle
+    if (c >= k0 + MB) {
+      double uc[MB];
+#pragma unroll
+      for (int q = 0; q < MB; ++q) uc[q] = T[(k0 + q) * LDT + c];
+      for (int r = k0 + MB + rh; r <= c; r += 2) {
+        double s = T[r * LDT + c];
+#pragma unroll
+        for (int q = 0; q < MB; ++q) s -= T[(k0 + q) * LDT + r] * uc[q];
+        T[r * LDT + c] = s;
+      }
     }
     __syncthreads();
   }
@@ -50,25 +104,59 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(double* __restrict__ A,
     int r = idx / NB, cc = idx % NB;
     Ab[(int64_t)r * mp + cc] = (cc >= r) ? T[r * LDT + cc] : 0.0;
   }
-  // inverse of the upper-triangular block: column cc of X solves U x = e_cc by back substitution,
-  // one thread per column.  The strict-lower part of T is free (U lives in the upper part), so
-  // thread cc keeps its partial solution x_k (k < cc) in T[cc][k].
   __syncthreads();
-  if (tid < NB) {
-    const int cc = tid;
-    double* X = dinv + cc;  // column cc, row stride NB
-    const double xcc = 1.0 / T[cc * LDT + cc];
-    for (int r = cc - 1; r >= 0; --r) {
-      double s = T[r * LDT + cc] * xcc;  // k = cc term
-      for (int k = r + 1; k < cc; ++k) s += T[r * LDT + k] * T[cc * LDT + k];  // scratch holds x_k
-      T[cc * LDT + r] = -s / T[r * LDT + r];
+
+  // ---------------- invert in place (upper), block column by block column
+  for (int j0 = 0; j0 < NB; j0 += MB) {
+    if (wid == 0) {
+      // column cc of inv(U_jj): x_cc = 1/u_cc, x_r = -(sum_{k=r+1..cc} u_rk x_k)/u_rr
+      const int cc = lane & 15;
+      double x[MB];
+#pragma unroll
+      for (int r = MB - 1; r >= 0; --r) {
+        double s = 0.0;
+#pragma unroll
+        for (int k = r + 1; k < MB; ++k) {
+          const double u = T[(j0 + r) * LDT + j0 + k];  // same address in every lane: broadcast
+          if (k <= cc) s += u * x[k];
+        }
+        const double d = T[(j0 + r) * LDT + j0 + r];
+        x[r] = (r == cc) ? 1.0 / d : ((r < cc) ? -s / d : 0.0);
+      }
+      if (lane < MB) {
+#pragma unroll
+        for (int r = 0; r < MB; ++r) Dm[r * MB + cc] = x[r];
+      }
     }
-    for (int r = 0; r < NB; ++r) {
-      double v = 0.0;
-      if (r == cc) v = xcc;
-      else if (r < cc) v = T[cc * LDT + r];
-      X[(int64_t)r * NB] = v;
+    __syncthreads();
+    // T1[r][q] = sum_{k=r..j0-1} X[r][k] U[k][j0+q]   (X = already inverted leading block, in place)
+    for (int idx = tid; idx < j0 * MB; idx += 256) {
+      const int r = idx / MB, q = idx % MB;
+      double s = 0.0;
+      for (int k = r; k < j0; ++k) s += T[r * LDT + k] * T[k * LDT + j0 + q];
+      T1[idx] = s;
     }
+    __syncthreads();
+    // X[0:j0, j0+q] = -sum_{i<=q} T1[r][i] D[i][q];  X[jj] = D
+    for (int idx = tid; idx < (j0 + MB) * MB; idx += 256) {
+      const int r = idx / MB, q = idx % MB;
+      double v;
+      if (r < j0) {
+        double s = 0.0;
+#pragma unroll
+        for (int i = 0; i < MB; ++i)
+          if (i <= q) s += T1[r * MB + i] * Dm[i * MB + q];
+        v = -s;
+      } else {
+        v = Dm[(r - j0) * MB + q];
+      }
+      T[r * LDT + j0 + q] = v;
+    }
+    __syncthreads();
+  }
+  for (int idx = tid; idx < NB * NB; idx += 256) {
+    int r = idx / NB, cc = idx % NB;
+    dinv[(int64_t)r * NB + cc] = (cc >= r) ? T[r * LDT + cc] : 0.0;
   }
 }
 

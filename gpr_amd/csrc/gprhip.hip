@@ -81,7 +81,7 @@ struct gprhip_problem {
   int D = 0, d = 0, m = 0, mp = 0;
   int64_t chunk = 0;
   int nchunks = 0;
-  int kslices = 64;  // upper bound on the split-K factor (partial-sum buffers allocated)
+  int kslices = 0;   // upper bound on the split-K factor (set at creation from the memory budget)
   hipStream_t stream = nullptr;
   std::vector<void*> allocs;
 
@@ -273,15 +273,19 @@ void upload_hypers(gprhip_problem* p, const gprhip_hypers* h) {
 }
 
 // Split-K factor of the SYRK-shaped accumulations over training points.  Slices are dealt to the
-// 8 XCDs (mfma_gemm.hip), so the factor is a multiple of 8, and (tiles x slices / 8) should fill a
-// whole number of residency rounds of one XCD (32 CUs x 2 resident blocks) so no round runs part-empty.
+// 8 XCDs (mfma_gemm.hip), so the factor is a multiple of 8.  Blocks of one slice share their operand
+// rows through the XCD's L2 only while they run in step; measured, that holds for a few hundred
+// k-stages, so slices are kept near 4096 rows (256 stages).  Among nearby factors the one whose
+// (tiles x slices / 8) fills whole residency rounds of an XCD (32 CUs x 2 blocks) is taken.
 int pick_kslices(int mp, int64_t rows_p, int max_slices) {
   const int nt = mp / TILE, tiles = nt * (nt + 1) / 2;
   const int slots = 64;
-  const int64_t kmax = std::max<int64_t>(8, std::min<int64_t>(max_slices, rows_p / (BK * 16)));
-  int best = 8;
+  int target = (int)((rows_p / 4096 + 7) / 8 * 8);
+  target = std::max(8, std::min(target, max_slices / 8 * 8));
+  int best = target;
   double best_eff = 0.0;
-  for (int ks = 8; ks <= kmax; ks += 8) {
+  for (int ks = std::max(8, target - 16); ks <= std::min(max_slices / 8 * 8, target + 16); ks += 8) {
+    if ((int64_t)ks * BK * 8 > rows_p && ks > 8) continue;
     const int items = tiles * (ks / 8);
     const double eff = (double)items / ((double)((items + slots - 1) / slots) * slots);
     if (eff > best_eff + 1e-9) {
@@ -641,7 +645,11 @@ int gprhip_problem_create(int device, int cov_kind, int64_t n, int D, int d, int
     chunk = round_up(std::min<int64_t>(chunk, round_up(n, TILE)), TILE);
     p->chunk = chunk;
     p->nchunks = (int)((n + chunk - 1) / chunk);
-    if (const char* e = getenv("GPRHIP_KSLICES")) p->kslices = std::max(1, atoi(e));
+    // partial-sum buffers of the split-K SYRK launches: one m x m slice per 4096 training points,
+    // capped at 40 GB
+    p->kslices = (int)std::max<int64_t>(8, std::min<int64_t>((round_up(n, 4096) / 4096 + 23) / 8 * 8,
+                                                              (40LL << 30) / (p->mp * (int64_t)p->mp * 8) / 8 * 8));
+    if (const char* e = getenv("GPRHIP_KSLICES")) p->kslices = std::max(8, atoi(e) / 8 * 8);
     if (const char* e = getenv("GPRHIP_TIMING")) p->timer.on = atoi(e) != 0;
     if (const char* e = getenv("GPRHIP_TILE_ORDER")) p->tile_order = atoi(e);
     GPR_HIP(hipStreamCreate(&p->stream));

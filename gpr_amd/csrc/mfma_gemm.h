@@ -42,6 +42,7 @@ struct GemmArgs {
   int tri = TRI_NONE;
   int upper_only = 0;    // compute only tiles with row tile <= column tile
   int order = 0;         // block -> tile order of full grids (see tile_of_block)
+  int prefetch = 1;      // global-load prefetch distance in k-stages (1 or 2)
   int kslices = 1;       // split K over gridDim.z; slice z writes C + z*slice_stride
   int64_t slice_stride = 0;
   // optional fused epilogue (when epi_rows_a != null): C[i][j] = ra[i]*acc - rb[i]*M[i][j] - rc[i]*cv[j]

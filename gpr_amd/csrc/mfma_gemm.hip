@@ -75,7 +75,7 @@ __device__ __forceinline__ void tile_of_block(const GemmArgs& g, int b, int nbm,
   bn = (g.tri == TRI_KHI_BN) ? (nbn - 1 - bi) : bi;
 }
 
-template <int OP>
+template <int OP, int PF>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   constexpr bool A_KMAJ = (OP == OP_TN);
@@ -137,22 +137,20 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
     Bg = g.B + (int64_t)(k_lo + km_k) * g.ldb + (int64_t)bn * TILE + 2 * km_xp;
     b_step = (int64_t)BK * g.ldb;
   }
-  const double* sk = (A_KMAJ && g.scale_k) ? g.scale_k + k_lo + km_k : nullptr;
+  // km_k is wavefront-uniform (tid >> 6): say so, and the weights come through the scalar cache
+  const double* sk = (A_KMAJ && g.scale_k) ? g.scale_k + k_lo + __builtin_amdgcn_readfirstlane(km_k) : nullptr;
 
-  d2 ra[4], rb[4];
-  auto load_global = [&](int t) {
+  // the per-k weights of the A operand are fetched with the tile and applied when the tile is
+  // written to LDS, so the multiply never waits on a load that was just issued
+  double rs[4] = {1.0, 1.0, 1.0, 1.0};
+  auto load_global = [&](int t, d2 (&ra)[4], d2 (&rb)[4]) {
     const double* ap = Ag + (int64_t)t * a_step;
     const double* bp = Bg + (int64_t)t * b_step;
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
       if (A_KMAJ) {
-        d2 v = *reinterpret_cast<const d2*>(ap + (int64_t)(4 * p) * g.lda);
-        if (sk) {
-          double s = sk[t * BK + 4 * p];
-          v.x *= s;
-          v.y *= s;
-        }
-        ra[p] = v;
+        ra[p] = *reinterpret_cast<const d2*>(ap + (int64_t)(4 * p) * g.lda);
+        if (sk) rs[p] = sk[t * BK + 4 * p];
       } else {
         ra[p] = *reinterpret_cast<const d2*>(ap + (int64_t)(32 * p) * g.lda);
       }
@@ -163,14 +161,19 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
       }
     }
   };
-  auto store_lds = [&](int stage) {
+  auto store_lds = [&](int stage, const d2 (&ra)[4], const d2 (&rb)[4]) {
     double* As = smem + stage * 2 * STAGE;
     double* Bs = As + STAGE;
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
-      if (A_KMAJ)
-        *reinterpret_cast<d2*>(As + (km_k + 4 * p) * KS + 2 * km_xp) = ra[p];
-      else
+      if (A_KMAJ) {
+        d2 v = ra[p];
+        if (sk) {
+          v.x *= rs[p];
+          v.y *= rs[p];
+        }
+        *reinterpret_cast<d2*>(As + (km_k + 4 * p) * KS + 2 * km_xp) = v;
+      } else
         *reinterpret_cast<d2*>(As + (xm_row + 32 * p) * XS + 2 * xm_kp) = ra[p];
       if (B_XMAJ)
         *reinterpret_cast<d2*>(Bs + (xm_row + 32 * p) * XS + 2 * xm_kp) = rb[p];
@@ -187,30 +190,57 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
   constexpr int B_TN = B_XMAJ ? 16 * XS : 16;
   constexpr int B_KK = B_XMAJ ? 4 : 4 * KS;
 
+  auto compute = [&](int stage) {
+    const double* As = smem + stage * 2 * STAGE;
+    const double* Bs = As + STAGE;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      double af[4], bf[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) af[i] = As[a_frag + i * A_TM + kk * A_KK];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bf[j] = Bs[b_frag + j * B_TN + kk * B_KK];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i], bf[j], acc[i][j], 0, 0, 0);
+    }
+  };
+
   if (nk > 0) {
-    load_global(0);
-    store_lds(0);
-    __syncthreads();
-    for (int t = 0; t < nk; ++t) {
-      const bool more = (t + 1 < nk);
-      if (more) load_global(t + 1);
-      const double* As = smem + (t & 1) * 2 * STAGE;
-      const double* Bs = As + STAGE;
-#pragma unroll
-      for (int kk = 0; kk < 4; ++kk) {
-        double af[4], bf[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) af[i] = As[a_frag + i * A_TM + kk * A_KK];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) bf[j] = Bs[b_frag + j * B_TN + kk * B_KK];
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-          for (int j = 0; j < 4; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i], bf[j], acc[i][j], 0, 0, 0);
-      }
-      if (more) store_lds((t + 1) & 1);
+    if (PF == 1) {
+      // global loads of stage t+1 are in flight while stage t is multiplied
+      d2 ra[4], rb[4];
+      load_global(0, ra, rb);
+      store_lds(0, ra, rb);
       __syncthreads();
+      for (int t = 0; t < nk; ++t) {
+        const bool more = (t + 1 < nk);
+        if (more) load_global(t + 1, ra, rb);
+        compute(t & 1);
+        if (more) store_lds((t + 1) & 1, ra, rb);
+        __syncthreads();
+      }
+    } else {
+      // prefetch distance 2: stage t+2 is requested before stage t is multiplied (two register sets)
+      d2 ra0[4], rb0[4], ra1[4], rb1[4];
+      load_global(0, ra0, rb0);
+      store_lds(0, ra0, rb0);
+      if (nk > 1) load_global(1, ra1, rb1);
+      __syncthreads();
+      for (int t = 0; t < nk; t += 2) {
+        if (t + 2 < nk) load_global(t + 2, ra0, rb0);
+        compute(0);
+        if (t + 1 < nk) store_lds(1, ra1, rb1);
+        __syncthreads();
+        if (t + 1 < nk) {
+          if (t + 3 < nk) load_global(t + 3, ra1, rb1);
+          compute(1);
+          if (t + 2 < nk) store_lds(0, ra0, rb0);
+          __syncthreads();
+        }
+      }
     }
   }
 
@@ -255,12 +285,12 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
 void gemm_init() {
   static bool done = false;
   if (done) return;
-  GPR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<OP_NN>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-  GPR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<OP_NT>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-  GPR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<OP_TN>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+  const void* ks[] = {
+      reinterpret_cast<const void*>(&gemm_kernel<OP_NN, 1>), reinterpret_cast<const void*>(&gemm_kernel<OP_NT, 1>),
+      reinterpret_cast<const void*>(&gemm_kernel<OP_TN, 1>), reinterpret_cast<const void*>(&gemm_kernel<OP_NN, 2>),
+      reinterpret_cast<const void*>(&gemm_kernel<OP_NT, 2>), reinterpret_cast<const void*>(&gemm_kernel<OP_TN, 2>)};
+  for (const void* k : ks)
+    GPR_HIP(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
   done = true;
 }
 
@@ -277,10 +307,18 @@ void launch_gemm(GemmOp op, const GemmArgs& g, hipStream_t stream) {
   }
   dim3 grid(tiles * (g.kslices > 1 ? g.kslices : 1));
   dim3 block(256);
-  switch (op) {
-    case OP_NN: hipLaunchKernelGGL(gemm_kernel<OP_NN>, grid, block, LDS_BYTES, stream, g); break;
-    case OP_NT: hipLaunchKernelGGL(gemm_kernel<OP_NT>, grid, block, LDS_BYTES, stream, g); break;
-    case OP_TN: hipLaunchKernelGGL(gemm_kernel<OP_TN>, grid, block, LDS_BYTES, stream, g); break;
+  if (g.prefetch == 2) {
+    switch (op) {
+      case OP_NN: hipLaunchKernelGGL((gemm_kernel<OP_NN, 2>), grid, block, LDS_BYTES, stream, g); break;
+      case OP_NT: hipLaunchKernelGGL((gemm_kernel<OP_NT, 2>), grid, block, LDS_BYTES, stream, g); break;
+      case OP_TN: hipLaunchKernelGGL((gemm_kernel<OP_TN, 2>), grid, block, LDS_BYTES, stream, g); break;
+    }
+  } else {
+    switch (op) {
+      case OP_NN: hipLaunchKernelGGL((gemm_kernel<OP_NN, 1>), grid, block, LDS_BYTES, stream, g); break;
+      case OP_NT: hipLaunchKernelGGL((gemm_kernel<OP_NT, 1>), grid, block, LDS_BYTES, stream, g); break;
+      case OP_TN: hipLaunchKernelGGL((gemm_kernel<OP_TN, 1>), grid, block, LDS_BYTES, stream, g); break;
+    }
   }
   GPR_HIP(hipGetLastError());
 }

@@ -44,7 +44,7 @@ int check(GemmOp op, int M, int N, int K, int tri, bool scale) {
   hipMemcpy(ds, hs.data(), K * 8, hipMemcpyHostToDevice);
   hipMemset(dC, 0, (int64_t)M * N * 8);
   GemmArgs g; g.A = dA; g.lda = ac; g.B = dB; g.ldb = bc; g.C = dC; g.ldc = N; g.M = M; g.N = N; g.K = K;
-  g.tri = tri; g.scale_k = scale ? ds : nullptr;
+  g.tri = tri; g.scale_k = scale ? ds : nullptr; g.prefetch = getenv("PF") ? atoi(getenv("PF")) : 1;
   launch_gemm(op, g, 0);
   naive<<<dim3((N + 255) / 256, M), 256>>>(op, dA, ac, dB, bc, dR, N, M, N, K, scale ? ds : nullptr);
   std::vector<double> hC((int64_t)M * N), hR((int64_t)M * N);
@@ -58,19 +58,20 @@ int check(GemmOp op, int M, int N, int K, int tri, bool scale) {
   return maxerr < 1e-10 * K ? 0 : 1;
 }
 
-void timeit(GemmOp op, int M, int N, int K, int tri, int upper, int kslices, const char* name) {
+void timeit(GemmOp op, int M, int N, int K, int tri, int upper, int kslices, const char* name, bool scale = false) {
   int64_t ar = op == OP_TN ? K : M, ac = op == OP_TN ? M : K;
   int64_t br = op == OP_NT ? N : K, bc = op == OP_NT ? K : N;
   double *dA, *dB, *dC;
   hipMalloc(&dA, ar * ac * 8); hipMalloc(&dB, br * bc * 8);
   hipMalloc(&dC, (int64_t)M * N * 8 * std::max(1, kslices));
   std::vector<double> h(std::max(ar * ac, br * bc));
-  for (auto& v : h) v = frand();
+  for (size_t i = 0; i < h.size(); ++i) h[i] = (double)((i * 2654435761u) & 0xffff) / 65536.0 - 0.5;
   hipMemcpy(dA, h.data(), ar * ac * 8, hipMemcpyHostToDevice);
   hipMemcpy(dB, h.data(), br * bc * 8, hipMemcpyHostToDevice);
   hipMemset(dC, 0, (int64_t)M * N * 8 * std::max(1, kslices));
-  GemmArgs g; g.A = dA; g.lda = ac; g.B = dB; g.ldb = bc; g.C = dC; g.ldc = N; g.M = M; g.N = N; g.K = K;
-  g.tri = tri; g.upper_only = upper; g.kslices = kslices; g.slice_stride = (int64_t)M * N; g.beta = kslices > 1 ? 1.0 : 0.0;
+  double* dS = nullptr; if (scale) { hipMalloc(&dS, (int64_t)K * 8); hipMemcpy(dS, h.data(), (int64_t)K * 8, hipMemcpyHostToDevice); }
+  GemmArgs g; g.scale_k = dS; g.A = dA; g.lda = ac; g.B = dB; g.ldb = bc; g.C = dC; g.ldc = N; g.M = M; g.N = N; g.K = K;
+  g.tri = tri; g.upper_only = upper; g.kslices = kslices; g.prefetch = getenv("PF") ? atoi(getenv("PF")) : 1; g.order = getenv("ORD") ? atoi(getenv("ORD")) : 0; g.slice_stride = (int64_t)M * N; g.beta = kslices > 1 ? 1.0 : 0.0;
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   for (int i = 0; i < 2; ++i) launch_gemm(op, g, 0);
   hipEventRecord(e0, 0);
@@ -102,6 +103,17 @@ int main() {
   timeit(OP_NN, 32768, 2048, 2048, TRI_KHI_BN, 0, 1, "K*Uinv triu");
   timeit(OP_NT, 32768, 2048, 2048, TRI_KLO_BN, 0, 1, "V*Uinv^T triu");
   timeit(OP_TN, 2048, 2048, 32768, TRI_NONE, 1, 8, "syrk upper ks8");
+  timeit(OP_TN, 2048, 2048, 262144, TRI_NONE, 1, 64, "syrk upper K=256k ks64");
+  if (getenv("BIG")) {
+    timeit(OP_TN, 2048, 2048, 1000064, TRI_NONE, 1, 64, "syrk upper K=1M ks64");
+    timeit(OP_TN, 2048, 2048, 1000064, TRI_NONE, 1, 64, "syrk upper K=1M ks64 scaled", true);
+    timeit(OP_TN, 2048, 2048, 1000064, TRI_NONE, 1, 248, "syrk upper K=1M ks248");
+    timeit(OP_TN, 2048, 2048, 524288, TRI_NONE, 1, 64, "syrk upper K=512k ks64");
+    timeit(OP_TN, 2048, 2048, 524288, TRI_NONE, 1, 128, "syrk upper K=512k ks128");
+    timeit(OP_TN, 2048, 2048, 131072, TRI_NONE, 1, 32, "syrk upper K=128k ks32");
+    timeit(OP_TN, 2048, 2048, 131072, TRI_NONE, 1, 64, "syrk upper K=128k ks64");
+    return 0;
+  }
   timeit(OP_TN, 2048, 2048, 32768, TRI_NONE, 1, 16, "syrk upper ks16");
   timeit(OP_NN, 8192, 2048, 2048, TRI_KHI_BN, 0, 1, "K*Uinv triu small chunk");
   timeit(OP_NN, 131072, 2048, 2048, TRI_KHI_BN, 0, 1, "K*Uinv triu big chunk");
