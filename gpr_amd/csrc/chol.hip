@@ -9,39 +9,57 @@ namespace gprhip {
 constexpr int NB = TILE;        // 128
 constexpr int LDT = NB + 1;     // LDS row stride (bank spread)
 constexpr int MB = 16;          // micro-panel width
-// LDS: T[NB][LDT] | T1[NB][MB] (product scratch of the inversion) | D[MB][MB] | flag
-constexpr int POTRF_LDS = (NB * LDT + NB * MB + MB * MB) * 8 + 16;
+constexpr int PT = 512;         // threads of the diagonal-block kernel
+// LDS: T[NB][LDT] | T1[NB][MB] (product scratch of the inversion) | rdiag[NB] | flag
+constexpr int POTRF_LDS = (NB * LDT + NB * MB + NB) * 8 + 16;
 
 // A = U^T U in place on block j (upper); strict lower of the block zeroed; dinv = inv(U_jj).
 //
 // Both phases advance by 16-column micro-panels so that the sequential part runs inside one
-// wavefront on registers (cross-lane shuffles, no workgroup barrier) and the workgroup only meets
-// at 3 barriers per micro-panel:
-//   factor : 16x16 diagonal block (wave 0, registers) -> 16 x rest panel solve (thread per column)
-//            -> rank-16 update of the trailing block (all threads)
-//   invert : inv of the 16x16 diagonal block (wave 0, registers) -> T1 = X[0:j0,0:j0] U[0:j0,j]
-//            -> X[0:j0,j] = -T1 inv(U_jj)   (in place, LAPACK dtrtri order)
-__global__ __launch_bounds__(256) void potrf_diag_kernel(double* __restrict__ A, int mp, int j,
-                                                         double* __restrict__ dinv,
-                                                         int* __restrict__ info) {
+// wavefront on registers (cross-lane broadcasts, no workgroup barrier):
+//   factor : 16x16 diagonal block (wave 0, registers) -> 16 x rest panel solve (thread per column,
+//            reciprocal pivots) -> rank-16 update of the trailing block (all threads)
+//   invert : the eight 16x16 diagonal inverses first, all at once (kept in the unused strictly-lower
+//            blocks of T); then per block column  T1 = X[0:j0,0:j0] U[0:j0,j],  X[0:j0,j] = -T1 inv(U_jj)
+//            in place (LAPACK dtrtri order), four outputs per thread.
+// broadcast lane `l` (compile-time constant after unrolling) through v_readlane, not the LDS crossbar
+__device__ __forceinline__ double bcast_lane(double v, int l) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), l);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+  return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ double* dblk(double* T, int b) {
+  // home of the inverse of diagonal micro-block b: the free block just below the diagonal (b<7: (b+1,b); 7: (7,0))
+  return (b < 7) ? T + ((b + 1) * MB) * LDT + b * MB : T + (7 * MB) * LDT;
+}
+
+__global__ __launch_bounds__(PT) void potrf_diag_kernel(double* __restrict__ A, int mp, int j,
+                                                        double* __restrict__ dinv,
+                                                        int* __restrict__ info, int flags) {
   extern __shared__ __attribute__((aligned(16))) double T[];  // [NB][LDT]
   double* T1 = T + NB * LDT;                                   // [NB][MB]
-  double* Dm = T1 + NB * MB;                                   // [MB][MB]
-  int& bad = *reinterpret_cast<int*>(Dm + MB * MB);            // keep all LDS in the one dynamic array
+  double* rdiag = T1 + NB * MB;                                // [NB] reciprocal pivots
+  int& bad = *reinterpret_cast<int*>(rdiag + NB);              // keep all LDS in the one dynamic array
   const int tid = threadIdx.x;
   const int lane = tid & 63, wid = tid >> 6;
   double* Ab = A + (int64_t)j * NB * mp + (int64_t)j * NB;
-  for (int idx = tid; idx < NB * NB; idx += 256) {
-    int r = idx / NB, c = idx % NB;
-    T[r * LDT + c] = Ab[(int64_t)r * mp + c];
+  for (int idx = tid; idx < NB * NB / 2; idx += PT) {
+    const int r = idx / (NB / 2), c2 = (idx % (NB / 2)) * 2;
+    if (c2 + 1 >= r) {
+      const double2 v = *reinterpret_cast<const double2*>(Ab + (int64_t)r * mp + c2);
+      T[r * LDT + c2] = v.x;
+      T[r * LDT + c2 + 1] = v.y;
+    }
   }
   if (tid == 0) bad = 0;
   __syncthreads();
 
   // ---------------- factor
   const int c = tid & (NB - 1);   // column owned in the panel / trailing phases
-  const int rh = tid >> 7;        // 0/1: which half of the rows
-  for (int k0 = 0; k0 < NB; k0 += MB) {
+  const int rh = tid >> 7;        // row phase 0..3
+  constexpr int RS = PT / NB;     // row stride
+  for (int k0 = 0; k0 < ((flags & 1) ? 0 : NB); k0 += MB) {
     if (wid == 0) {
       const int cc = lane & 15;   // lanes 16..63 mirror lanes 0..15
       double a[MB];
@@ -49,17 +67,19 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(double* __restrict__ A,
       for (int r = 0; r < MB; ++r) a[r] = T[(k0 + r) * LDT + k0 + cc];
 #pragma unroll
       for (int q = 0; q < MB; ++q) {
-        double dq = __shfl(a[q], q);
+        double dq = bcast_lane(a[q], q);
         if (!(dq > 0.0)) {
           if (lane == 0 && bad == 0) bad = k0 + q + 1;
           dq = 1.0;  // keep going with finite numbers; the caller reads `info`
         }
         const double piv = sqrt(dq);
-        double uqc = (cc == q) ? piv : a[q] / piv;
+        const double rp = 1.0 / piv;
+        double uqc = (cc == q) ? piv : a[q] * rp;
         a[q] = uqc;
+        if (lane == q) rdiag[k0 + q] = rp;
 #pragma unroll
         for (int r = q + 1; r < MB; ++r) {
-          const double uqr = __shfl(uqc, r);
+          const double uqr = bcast_lane(uqc, r);
           a[r] -= uqr * uqc;
         }
       }
@@ -78,7 +98,7 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(double* __restrict__ A,
         double s = T[(k0 + q) * LDT + tid];
 #pragma unroll
         for (int i = 0; i < q; ++i) s -= T[(k0 + i) * LDT + k0 + q] * x[i];
-        x[q] = s / T[(k0 + q) * LDT + k0 + q];
+        x[q] = s * rdiag[k0 + q];
       }
 #pragma unroll
       for (int q = 0; q < MB; ++q) T[(k0 + q) * LDT + tid] = x[q];
@@ -89,7 +109,8 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(double* __restrict__ A,
       double uc[MB];
 #pragma unroll
       for (int q = 0; q < MB; ++q) uc[q] = T[(k0 + q) * LDT + c];
-      for (int r = k0 + MB + rh; r <= c; r += 2) {
+#pragma unroll 2
+      for (int r = k0 + MB + rh; r <= c; r += RS) {
         double s = T[r * LDT + c];
 #pragma unroll
         for (int q = 0; q < MB; ++q) s -= T[(k0 + q) * LDT + r] * uc[q];
@@ -100,17 +121,20 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(double* __restrict__ A,
   }
   if (tid == 0 && bad != 0) atomicCAS(info, 0, j * NB + bad);
   // write U back (zero strict lower of the block)
-  for (int idx = tid; idx < NB * NB; idx += 256) {
-    int r = idx / NB, cc = idx % NB;
-    Ab[(int64_t)r * mp + cc] = (cc >= r) ? T[r * LDT + cc] : 0.0;
+  for (int idx = tid; idx < NB * NB / 2; idx += PT) {
+    const int r = idx / (NB / 2), c2 = (idx % (NB / 2)) * 2;
+    double2 v;
+    v.x = (c2 >= r) ? T[r * LDT + c2] : 0.0;
+    v.y = (c2 + 1 >= r) ? T[r * LDT + c2 + 1] : 0.0;
+    *reinterpret_cast<double2*>(Ab + (int64_t)r * mp + c2) = v;
   }
   __syncthreads();
 
-  // ---------------- invert in place (upper), block column by block column
-  for (int j0 = 0; j0 < NB; j0 += MB) {
-    if (wid == 0) {
-      // column cc of inv(U_jj): x_cc = 1/u_cc, x_r = -(sum_{k=r+1..cc} u_rk x_k)/u_rr
-      const int cc = lane & 15;
+  // ---------------- invert in place (upper)
+  if (!(flags & 2)) {
+    // all eight diagonal micro-block inverses: wave w handles blocks w (8 waves)
+    {
+      const int b = wid, j0 = b * MB, cc = lane & 15;
       double x[MB];
 #pragma unroll
       for (int r = MB - 1; r >= 0; --r) {
@@ -120,43 +144,58 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(double* __restrict__ A,
           const double u = T[(j0 + r) * LDT + j0 + k];  // same address in every lane: broadcast
           if (k <= cc) s += u * x[k];
         }
-        const double d = T[(j0 + r) * LDT + j0 + r];
-        x[r] = (r == cc) ? 1.0 / d : ((r < cc) ? -s / d : 0.0);
+        const double rd = rdiag[j0 + r];
+        x[r] = (r == cc) ? rd : ((r < cc) ? -s * rd : 0.0);
       }
+      double* D = dblk(T, b);
       if (lane < MB) {
 #pragma unroll
-        for (int r = 0; r < MB; ++r) Dm[r * MB + cc] = x[r];
+        for (int r = 0; r < MB; ++r) D[r * LDT + cc] = x[r];
       }
     }
     __syncthreads();
-    // T1[r][q] = sum_{k=r..j0-1} X[r][k] U[k][j0+q]   (X = already inverted leading block, in place)
-    for (int idx = tid; idx < j0 * MB; idx += 256) {
-      const int r = idx / MB, q = idx % MB;
-      double s = 0.0;
-      for (int k = r; k < j0; ++k) s += T[r * LDT + k] * T[k * LDT + j0 + q];
-      T1[idx] = s;
-    }
-    __syncthreads();
-    // X[0:j0, j0+q] = -sum_{i<=q} T1[r][i] D[i][q];  X[jj] = D
-    for (int idx = tid; idx < (j0 + MB) * MB; idx += 256) {
-      const int r = idx / MB, q = idx % MB;
-      double v;
-      if (r < j0) {
-        double s = 0.0;
+    for (int j0 = 0; j0 < NB; j0 += MB) {
+      const double* D = dblk(T, j0 / MB);
+      // T1[r][q..q+3] = sum_{k=r..j0-1} X[r][k] U[k][j0+q..]   (X = already inverted leading block, in place)
+      for (int idx = tid; idx < j0 * (MB / 4); idx += PT) {
+        const int r = idx / (MB / 4), q = (idx % (MB / 4)) * 4;
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+        for (int k = r; k < j0; ++k) {
+          const double xv = T[r * LDT + k];
+          const double* u = T + k * LDT + j0 + q;
+          s0 += xv * u[0];
+          s1 += xv * u[1];
+          s2 += xv * u[2];
+          s3 += xv * u[3];
+        }
+        double* o = T1 + r * MB + q;
+        o[0] = s0; o[1] = s1; o[2] = s2; o[3] = s3;
+      }
+      __syncthreads();
+      // X[0:j0, j0+q] = -sum_{i<=q} T1[r][i] D[i][q];  X[jj] = D
+      for (int idx = tid; idx < (j0 + MB) * MB; idx += PT) {
+        const int r = idx / MB, q = idx % MB;
+        double v;
+        if (r < j0) {
+          double s = 0.0;
 #pragma unroll
-        for (int i = 0; i < MB; ++i)
-          if (i <= q) s += T1[r * MB + i] * Dm[i * MB + q];
-        v = -s;
-      } else {
-        v = Dm[(r - j0) * MB + q];
+          for (int i = 0; i < MB; ++i)
+            if (i <= q) s += T1[r * MB + i] * D[i * LDT + q];
+          v = -s;
+        } else {
+          v = D[(r - j0) * LDT + q];
+        }
+        T[r * LDT + j0 + q] = v;
       }
-      T[r * LDT + j0 + q] = v;
+      __syncthreads();
     }
-    __syncthreads();
   }
-  for (int idx = tid; idx < NB * NB; idx += 256) {
-    int r = idx / NB, cc = idx % NB;
-    dinv[(int64_t)r * NB + cc] = (cc >= r) ? T[r * LDT + cc] : 0.0;
+  for (int idx = tid; idx < NB * NB / 2; idx += PT) {
+    const int r = idx / (NB / 2), c2 = (idx % (NB / 2)) * 2;
+    double2 v;
+    v.x = (c2 >= r) ? T[r * LDT + c2] : 0.0;
+    v.y = (c2 + 1 >= r) ? T[r * LDT + c2 + 1] : 0.0;
+    *reinterpret_cast<double2*>(dinv + (int64_t)r * NB + c2) = v;
   }
 }
 
@@ -171,6 +210,19 @@ __global__ void copy_block_kernel(const double* __restrict__ src, int64_t lds, d
   int c = blockIdx.x * 256 + threadIdx.x;
   int r = blockIdx.y;
   if (c < cols && r < rows) dst[(int64_t)r * ldd + c] = src[(int64_t)r * lds + c];
+}
+
+__global__ void scatter_diag_blocks_kernel(const double* __restrict__ dinv, int mp, double* __restrict__ X) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  const int r = blockIdx.y;
+  if (c >= mp) return;
+  const int br = r / NB, bc = c / NB;
+  X[(int64_t)r * mp + c] = (br == bc) ? dinv[(int64_t)br * NB * NB + (r % NB) * NB + (c % NB)] : 0.0;
+}
+
+void launch_scatter_diag_blocks(const double* dinv, int mp, double* X, hipStream_t s) {
+  hipLaunchKernelGGL(scatter_diag_blocks_kernel, dim3((mp + 255) / 256, mp), dim3(256), 0, s, dinv, mp, X);
+  GPR_HIP(hipGetLastError());
 }
 
 __global__ __launch_bounds__(256) void logdet_kernel(const double* __restrict__ A, int mp, int m,
@@ -205,14 +257,19 @@ __global__ __launch_bounds__(256) void triu_matvec_kernel(const double* __restri
   if (lane == 0) y[i] = s;
 }
 
+void launch_potrf_diag_flags(double* A, int mp, int j, double* dinv, int* info, int flags, hipStream_t s);
 void launch_potrf_diag(double* A, int mp, int j, double* dinv, int* info, hipStream_t s) {
+  launch_potrf_diag_flags(A, mp, j, dinv, info, 0, s);
+}
+// flags: ablation switches of tools/potrf_check (bit0 skip factor, bit1 skip invert); 0 in the library
+void launch_potrf_diag_flags(double* A, int mp, int j, double* dinv, int* info, int flags, hipStream_t s) {
   static bool attr = false;
   if (!attr) {
     GPR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&potrf_diag_kernel),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, POTRF_LDS));
     attr = true;
   }
-  hipLaunchKernelGGL(potrf_diag_kernel, dim3(1), dim3(256), POTRF_LDS, s, A, mp, j, dinv, info);
+  hipLaunchKernelGGL(potrf_diag_kernel, dim3(1), dim3(PT), POTRF_LDS, s, A, mp, j, dinv, info, flags);
   GPR_HIP(hipGetLastError());
 }
 

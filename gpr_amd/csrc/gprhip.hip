@@ -194,25 +194,37 @@ void potrf_upper(gprhip_problem* p, double* A, int* info) {
   }
 }
 
-// inv(U) for the upper-triangular factor, column block by column block:
-//   X[0:j, j] = -X[0:j, 0:j] * U[0:j, j] * inv(U_jj)
-void trtri_upper(gprhip_problem* p, const double* U, double* X) {
-  const int mp = p->mp, nb = mp / TILE;
+// inv(U) for the upper-triangular factor by recursive doubling over the 128-blocks:
+//   inv([U11 U12; 0 U22]) = [X11, -X11 U12 X22; 0, X22]
+// Level s joins neighbouring inverted diagonal blocks of s rows; all joins of a level are independent
+// and run as one batched launch (two per level: T = U12 X22, X12 = -X11 T), so the whole inverse is
+// 2 log2(mp/128) launches instead of one short GEMM chain per block column.
+void trtri_upper(gprhip_problem* p, const double* U, double* X, double* tmp) {
+  const int mp = p->mp;
   hipStream_t s = p->stream;
-  GPR_HIP(hipMemsetAsync(X, 0, (size_t)mp * mp * sizeof(double), s));
-  for (int j = 0; j < nb; ++j) {
-    const double* dj = p->dinv + (int64_t)j * TILE * TILE;
-    launch_copy_block(dj, TILE, X + (int64_t)j * TILE * mp + (int64_t)j * TILE, mp, TILE, TILE, s);
-    if (j > 0) {
-      GemmArgs g;
-      g.A = X; g.lda = mp; g.B = U + (int64_t)j * TILE; g.ldb = mp; g.C = p->tmp; g.ldc = TILE;
-      g.M = j * TILE; g.N = TILE; g.K = j * TILE; g.tri = TRI_KLO_BM;
-      launch_gemm(OP_NN, g, s);
-      GemmArgs h;
-      h.A = p->tmp; h.lda = TILE; h.B = dj; h.ldb = TILE; h.C = X + (int64_t)j * TILE; h.ldc = mp;
-      h.M = j * TILE; h.N = TILE; h.K = TILE; h.alpha = -1.0;
-      launch_gemm(OP_NN, h, s);
-    }
+  launch_scatter_diag_blocks(p->dinv, mp, X, s);
+  for (int64_t sz = TILE; sz < mp; sz *= 2) {
+    const int64_t pair = 2 * sz;
+    const int nfull = (int)(mp / pair);                 // pairs with two full halves
+    const int64_t rem = mp - (int64_t)nfull * pair;     // a trailing pair with a short second half?
+    auto join = [&](int64_t off, int64_t s2, int nb) {
+      // T = U12 * X22   (X22 upper triangular)
+      GemmArgs a;
+      a.A = U + off * mp + off + sz; a.lda = mp; a.B = X + (off + sz) * (mp + 1); a.ldb = mp;
+      a.C = tmp + off * mp + off + sz; a.ldc = mp;
+      a.M = (int)sz; a.N = (int)s2; a.K = (int)s2; a.tri = TRI_KHI_BN;
+      a.nbatch = nb; a.batch_a = a.batch_b = a.batch_c = pair * (mp + 1);
+      launch_gemm(OP_NN, a, s);
+      // X12 = -X11 * T  (X11 upper triangular)
+      GemmArgs b;
+      b.A = X + off * (mp + 1); b.lda = mp; b.B = tmp + off * mp + off + sz; b.ldb = mp;
+      b.C = X + off * mp + off + sz; b.ldc = mp;
+      b.M = (int)sz; b.N = (int)s2; b.K = (int)sz; b.tri = TRI_KLO_BM; b.alpha = -1.0;
+      b.nbatch = nb; b.batch_a = b.batch_b = b.batch_c = pair * (mp + 1);
+      launch_gemm(OP_NN, b, s);
+    };
+    if (nfull > 0) join(0, sz, nfull);
+    if (rem > sz) join((int64_t)nfull * pair, rem - sz, 1);
   }
 }
 
@@ -327,7 +339,7 @@ void do_pass1(gprhip_problem* p, const gprhip_hypers* h, int want_grad, int64_t 
   launch_cov_upper(p->cp, p->Z, p->m, mp, p->d, h->jitter, p->km, p->kj, s);
   GPR_HIP(hipMemcpyAsync(p->umat, p->kj, (size_t)mm * sizeof(double), hipMemcpyDeviceToDevice, s));
   potrf_upper(p, p->umat, p->info);  // U = chol(K_m + jitter), lib/fitc_gp.ml:53-57
-  trtri_upper(p, p->umat, p->uinv);
+  trtri_upper(p, p->umat, p->uinv, p->wmat);
   tstop(p);
 
   for (int c = 0; c < p->nchunks; ++c) {
@@ -395,7 +407,7 @@ void do_pass2(gprhip_problem* p, const double* ar1, double* ar2) {
                      p->bmat);
   potrf_upper(p, p->bmat, p->info + 1);
   launch_logdet(p->bmat, mp, mp, p->scal + SC_LOGDET_B, s);
-  trtri_upper(p, p->bmat, p->rinv);
+  trtri_upper(p, p->bmat, p->rinv, p->wmat);
   // b = R~^-T c~ (= Q_n^T y~, lib/fitc_gp.ml:285-286);  t~ = R~^-1 b;  t = U^-1 t~ (trsv, :291 / :1167)
   launch_triu_matvec(p->rinv, mp, ar1_c, p->bvec, 1, s);
   launch_triu_matvec(p->rinv, mp, p->bvec, p->ttil, 0, s);

@@ -41,6 +41,8 @@ void launch_potrf_diag(double* A, int mp, int j, double* dinv, int* info, hipStr
 void launch_zero_strict_lower(double* A, int mp, hipStream_t s);
 void launch_copy_block(const double* src, int64_t lds, double* dst, int64_t ldd, int rows, int cols,
                        hipStream_t s);
+// X (mp x mp) = block-diagonal matrix of the nb 128x128 blocks stored consecutively in dinv
+void launch_scatter_diag_blocks(const double* dinv, int mp, double* X, hipStream_t s);
 // out[0] = 2 * sum_{i<m} log A[i][i]   (lib/utils.ml:95-101)
 void launch_logdet(const double* A, int mp, int m, double* out, hipStream_t s);
 

@@ -90,6 +90,11 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
   const int nbm = g.M / TILE, nbn = g.N / TILE;
   int bm, bn, slice;
   tile_of_block(g, blockIdx.x, nbm, nbn, bm, bn, slice);
+  if (g.nbatch > 1) {  // kernel-argument copy: advance to this block's problem
+    g.A += (int64_t)blockIdx.y * g.batch_a;
+    g.B += (int64_t)blockIdx.y * g.batch_b;
+    g.C += (int64_t)blockIdx.y * g.batch_c;
+  }
 
   // k-range of this block, in elements
   int k_lo = 0, k_hi = g.K;
@@ -305,7 +310,7 @@ void launch_gemm(GemmOp op, const GemmArgs& g, hipStream_t stream) {
     set_error("gprhip: launch_gemm: split-K is implemented for upper_only (SYRK-shaped) launches");
     throw HipFail{ST_BAD_ARG};
   }
-  dim3 grid(tiles * (g.kslices > 1 ? g.kslices : 1));
+  dim3 grid(tiles * (g.kslices > 1 ? g.kslices : 1), g.nbatch > 1 ? g.nbatch : 1);
   dim3 block(256);
   if (g.prefetch == 2) {
     switch (op) {

@@ -136,6 +136,23 @@ def test_mid_size_against_oracle():
     p.close()
 
 
+@pytest.mark.parametrize("m", [640, 800])
+def test_odd_block_counts_of_the_triangular_inverse(m):
+    """m/128 = 5 and 7: exercises the ragged joins of the recursive triangular inverse and the
+    split-K / tile enumeration away from powers of two."""
+    n, d = 3000, 4
+    X, y, Z = synth(17, n, m, d)
+    ref = O.evaluate_fast(O.SeIsoKernel(0.7, 0.0), Z, X, y, 0.1)
+    p = gpr_amd.Problem(gpr_amd.COV_SE_ISO, n, d, d, m)
+    p.set_inputs(X)
+    p.set_targets(y)
+    ev = p.eval(log_ell=0.7, log_sf2=0.0, sigma2=0.1, inducing=Z)
+    assert abs(ev.l - ref["l"]) <= TOL_L * abs(ref["l"])
+    assert relinf(ev.grad, ref["grad"]) <= TOL_GRAD
+    assert relinf(ev.coeffs, ref["coeffs"]) <= TOL_COEFF
+    p.close()
+
+
 def test_functor_mirror_and_reference_self_test_recipe():
     """test/test_derivatives.ml's recipe through the mirrored module surface: finite differences at
     the reference's eps=1e-8 / tol=1e-2 for sigma2 and every hyper (n=10, m=5, D=3)."""
