@@ -195,9 +195,39 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
   constexpr int B_TN = B_XMAJ ? 16 * XS : 16;
   constexpr int B_KK = B_XMAJ ? 4 : 4 * KS;
 
-  auto compute = [&](int stage) {
+  // Inside the diagonal 128-block of a triangular B operand, column sub-tile cj (16 columns,
+  // cj = 0..7 across the block tile) only meets non-zeros in k-stages u <= cj (k-range ends at the
+  // diagonal, TRI_KHI_BN) or u >= cj (k-range starts at it, TRI_KLO_BN): the MFMAs of the other
+  // (sub-tile, stage) pairs multiply zeros and are skipped -- about half of that block's work.
+  const int diag_first = (g.tri == TRI_KHI_BN && k_hi == (bn + 1) * TILE) ? nk - TILE / BK
+                         : (g.tri == TRI_KLO_BN && k_lo == bn * TILE) ? 0 : -(1 << 30);
+  const int cj0 = wc * 4;
+  auto compute = [&](int stage, int t) {
     const double* As = smem + stage * 2 * STAGE;
     const double* Bs = As + STAGE;
+    int jlo = 0, jhi = 7;  // live column sub-tiles of this stage
+    const int u = t - diag_first;
+    if (u >= 0 && u < TILE / BK) {
+      if (g.tri == TRI_KHI_BN) jlo = u; else jhi = u;
+    }
+    if (jlo > cj0 + 3 || jhi < cj0) return;
+    if (jlo <= cj0 && jhi >= cj0 + 3) {
+      // every sub-tile live: the common case, one straight MFMA stream
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        double af[4], bf[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) af[i] = As[a_frag + i * A_TM + kk * A_KK];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bf[j] = Bs[b_frag + j * B_TN + kk * B_KK];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i], bf[j], acc[i][j], 0, 0, 0);
+      }
+      return;
+    }
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
       double af[4], bf[4];
@@ -206,10 +236,13 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) bf[j] = Bs[b_frag + j * B_TN + kk * B_KK];
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int j = 0; j < 4; ++j) {
+        if (cj0 + j >= jlo && cj0 + j <= jhi) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i], bf[j], acc[i][j], 0, 0, 0);
+          for (int i = 0; i < 4; ++i)
+            acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+      }
     }
   };
 
@@ -223,7 +256,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
       for (int t = 0; t < nk; ++t) {
         const bool more = (t + 1 < nk);
         if (more) load_global(t + 1, ra, rb);
-        compute(t & 1);
+        compute(t & 1, t);
         if (more) store_lds((t + 1) & 1, ra, rb);
         __syncthreads();
       }
@@ -236,12 +269,12 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
       __syncthreads();
       for (int t = 0; t < nk; t += 2) {
         if (t + 2 < nk) load_global(t + 2, ra0, rb0);
-        compute(0);
+        compute(0, t);
         if (t + 1 < nk) store_lds(1, ra1, rb1);
         __syncthreads();
         if (t + 1 < nk) {
           if (t + 3 < nk) load_global(t + 3, ra1, rb1);
-          compute(1);
+          compute(1, t + 1);
           if (t + 2 < nk) store_lds(0, ra0, rb0);
           __syncthreads();
         }
