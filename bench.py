@@ -128,14 +128,14 @@ def main():
         ms_per_step = dt / args.steps * 1e3
         value = n * args.steps / dt
         F = algorithmic_flops(n, m, d)
-        # dominant kernel: gemm_kernel<OP_TN> (the two SYRK-shaped accumulations over training points,
-        # one launch per row chunk and pass); algorithmic flops per launch = chunk_rows * m^2
+        # dominant kernel by time per launch: gemm_kernel<OP_TN> -- the two SYRK-shaped accumulations over
+        # the shard's training points (one launch per pass, HIP events on the library's own stream);
+        # algorithmic flops per launch = n_local * m^2 ("SYRK B nm^2", "weighted-SYRK W nm^2")
         chunk = min(int(os.environ.get("GPRHIP_CHUNK_ROWS", "32768")), hi - lo)
         n_local = hi - lo
-        nchunks = (n_local + chunk - 1) // chunk
         syrk_ms = (np.mean(tim.get("p1_syrk_B", [0.0])) + np.mean(tim.get("p2_syrk_W", [0.0])))
-        launches = 2 * nchunks
-        flops_per_launch = (n_local / nchunks) * m * m
+        launches = 2
+        flops_per_launch = float(n_local) * m * m
         achieved = flops_per_launch / (syrk_ms / launches * 1e-3) * 1e-12 if syrk_ms > 0 else None
         engine_ms = sum(np.mean(tim.get(k_, [0.0])) for k_ in
                         ("p1_syrk_B", "p2_syrk_W", "p1_trmm_V", "p1_trmm_A1", "p2_trmm_Q", "p2_trmm_S"))
