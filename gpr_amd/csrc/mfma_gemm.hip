@@ -75,7 +75,7 @@ __device__ __forceinline__ void tile_of_block(const GemmArgs& g, int b, int nbm,
   bn = (g.tri == TRI_KHI_BN) ? (nbn - 1 - bi) : bi;
 }
 
-template <int OP, int PF>
+template <int OP>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   constexpr bool A_KMAJ = (OP == OP_TN);
@@ -247,7 +247,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
   };
 
   if (nk > 0) {
-    if (PF == 1) {
+    {
       // global loads of stage t+1 are in flight while stage t is multiplied
       d2 ra[4], rb[4];
       load_global(0, ra, rb);
@@ -259,25 +259,6 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
         compute(t & 1, t);
         if (more) store_lds((t + 1) & 1, ra, rb);
         __syncthreads();
-      }
-    } else {
-      // prefetch distance 2: stage t+2 is requested before stage t is multiplied (two register sets)
-      d2 ra0[4], rb0[4], ra1[4], rb1[4];
-      load_global(0, ra0, rb0);
-      store_lds(0, ra0, rb0);
-      if (nk > 1) load_global(1, ra1, rb1);
-      __syncthreads();
-      for (int t = 0; t < nk; t += 2) {
-        if (t + 2 < nk) load_global(t + 2, ra0, rb0);
-        compute(0, t);
-        if (t + 1 < nk) store_lds(1, ra1, rb1);
-        __syncthreads();
-        if (t + 1 < nk) {
-          if (t + 3 < nk) load_global(t + 3, ra1, rb1);
-          compute(1, t + 1);
-          if (t + 2 < nk) store_lds(0, ra0, rb0);
-          __syncthreads();
-        }
       }
     }
   }
@@ -323,10 +304,9 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
 void gemm_init() {
   static bool done = false;
   if (done) return;
-  const void* ks[] = {
-      reinterpret_cast<const void*>(&gemm_kernel<OP_NN, 1>), reinterpret_cast<const void*>(&gemm_kernel<OP_NT, 1>),
-      reinterpret_cast<const void*>(&gemm_kernel<OP_TN, 1>), reinterpret_cast<const void*>(&gemm_kernel<OP_NN, 2>),
-      reinterpret_cast<const void*>(&gemm_kernel<OP_NT, 2>), reinterpret_cast<const void*>(&gemm_kernel<OP_TN, 2>)};
+  const void* ks[] = {reinterpret_cast<const void*>(&gemm_kernel<OP_NN>),
+                      reinterpret_cast<const void*>(&gemm_kernel<OP_NT>),
+                      reinterpret_cast<const void*>(&gemm_kernel<OP_TN>)};
   for (const void* k : ks)
     GPR_HIP(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
   done = true;
@@ -345,18 +325,10 @@ void launch_gemm(GemmOp op, const GemmArgs& g, hipStream_t stream) {
   }
   dim3 grid(tiles * (g.kslices > 1 ? g.kslices : 1), g.nbatch > 1 ? g.nbatch : 1);
   dim3 block(256);
-  if (g.prefetch == 2) {
-    switch (op) {
-      case OP_NN: hipLaunchKernelGGL((gemm_kernel<OP_NN, 2>), grid, block, LDS_BYTES, stream, g); break;
-      case OP_NT: hipLaunchKernelGGL((gemm_kernel<OP_NT, 2>), grid, block, LDS_BYTES, stream, g); break;
-      case OP_TN: hipLaunchKernelGGL((gemm_kernel<OP_TN, 2>), grid, block, LDS_BYTES, stream, g); break;
-    }
-  } else {
-    switch (op) {
-      case OP_NN: hipLaunchKernelGGL((gemm_kernel<OP_NN, 1>), grid, block, LDS_BYTES, stream, g); break;
-      case OP_NT: hipLaunchKernelGGL((gemm_kernel<OP_NT, 1>), grid, block, LDS_BYTES, stream, g); break;
-      case OP_TN: hipLaunchKernelGGL((gemm_kernel<OP_TN, 1>), grid, block, LDS_BYTES, stream, g); break;
-    }
+  switch (op) {
+    case OP_NN: hipLaunchKernelGGL(gemm_kernel<OP_NN>, grid, block, LDS_BYTES, stream, g); break;
+    case OP_NT: hipLaunchKernelGGL(gemm_kernel<OP_NT>, grid, block, LDS_BYTES, stream, g); break;
+    case OP_TN: hipLaunchKernelGGL(gemm_kernel<OP_TN>, grid, block, LDS_BYTES, stream, g); break;
   }
   GPR_HIP(hipGetLastError());
 }

@@ -44,7 +44,7 @@ int check(GemmOp op, int M, int N, int K, int tri, bool scale) {
   hipMemcpy(ds, hs.data(), K * 8, hipMemcpyHostToDevice);
   hipMemset(dC, 0, (int64_t)M * N * 8);
   GemmArgs g; g.A = dA; g.lda = ac; g.B = dB; g.ldb = bc; g.C = dC; g.ldc = N; g.M = M; g.N = N; g.K = K;
-  g.tri = tri; g.scale_k = scale ? ds : nullptr; g.prefetch = getenv("PF") ? atoi(getenv("PF")) : 1;
+  g.tri = tri; g.scale_k = scale ? ds : nullptr;
   launch_gemm(op, g, 0);
   naive<<<dim3((N + 255) / 256, M), 256>>>(op, dA, ac, dB, bc, dR, N, M, N, K, scale ? ds : nullptr);
   std::vector<double> hC((int64_t)M * N), hR((int64_t)M * N);
@@ -71,7 +71,7 @@ void timeit(GemmOp op, int M, int N, int K, int tri, int upper, int kslices, con
   hipMemset(dC, 0, (int64_t)M * N * 8 * std::max(1, kslices));
   double* dS = nullptr; if (scale) { hipMalloc(&dS, (int64_t)K * 8); hipMemcpy(dS, h.data(), (int64_t)K * 8, hipMemcpyHostToDevice); }
   GemmArgs g; g.scale_k = dS; g.A = dA; g.lda = ac; g.B = dB; g.ldb = bc; g.C = dC; g.ldc = N; g.M = M; g.N = N; g.K = K;
-  g.tri = tri; g.upper_only = upper; g.kslices = kslices; g.prefetch = getenv("PF") ? atoi(getenv("PF")) : 1; g.order = getenv("ORD") ? atoi(getenv("ORD")) : 0; g.slice_stride = (int64_t)M * N; g.beta = kslices > 1 ? 1.0 : 0.0;
+  g.tri = tri; g.upper_only = upper; g.kslices = kslices; g.order = getenv("ORD") ? atoi(getenv("ORD")) : 0; g.slice_stride = (int64_t)M * N; g.beta = kslices > 1 ? 1.0 : 0.0;
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   for (int i = 0; i < 2; ++i) launch_gemm(op, g, 0);
   hipEventRecord(e0, 0);
