@@ -11,35 +11,38 @@ namespace gprhip {
 
 #pragma clang fp contract(off)
 
+// Thread <-> inducing column (coalesced stores along a row of K_nm); the block's 32 training points
+// are staged in LDS zero-padded to DT dimensions, so the distance loop is branch-free and reads its
+// x values as LDS broadcasts.  Padded dimensions add (0-0)^2 = 0 exactly: the rounding sequence of the
+// real dimensions is unchanged.
 template <int DT>
 __global__ __launch_bounds__(256) void cov_cross_kernel(CovParams cp, const double* __restrict__ pts,
                                                         int rows, int rows_p,
                                                         const double* __restrict__ Z, int m, int mp,
                                                         int d, double* __restrict__ K) {
+  __shared__ double xs[32][DT];
   const int j = blockIdx.x * 256 + threadIdx.x;
-  if (j >= mp) return;
   const int r0 = blockIdx.y * 32;
+  for (int idx = threadIdx.x; idx < 32 * DT; idx += 256) {
+    const int r = idx / DT, k = idx % DT;
+    xs[r][k] = (k < d && r0 + r < rows) ? pts[(int64_t)(r0 + r) * d + k] : 0.0;
+  }
+  __syncthreads();
+  if (j >= mp) return;
   double z[DT];
 #pragma unroll
   for (int k = 0; k < DT; ++k) z[k] = (k < d && j < m) ? Z[(int64_t)j * d + k] : 0.0;
   const bool live_col = j < m;
-  for (int i = 0; i < 32; ++i) {
-    const int r = r0 + i;
-    if (r >= rows_p) break;
-    double val = 0.0;
-    if (r < rows && live_col) {
-      const double* x = pts + (int64_t)r * d;
-      double acc = 0.0;
+  const int nr = min(32, rows_p - r0);
+  for (int i = 0; i < nr; ++i) {
+    double acc = 0.0;
 #pragma unroll
-      for (int k = 0; k < DT; ++k) {
-        if (k < d) {
-          double diff = x[k] - z[k];
-          acc = acc + diff * diff;
-        }
-      }
-      val = exp(cp.log_sf2 + cp.inv_ell2_05 * acc);
+    for (int k = 0; k < DT; ++k) {
+      const double diff = xs[i][k] - z[k];
+      acc = acc + diff * diff;
     }
-    K[(int64_t)r * mp + j] = val;
+    const double val = (r0 + i < rows && live_col) ? exp(cp.log_sf2 + cp.inv_ell2_05 * acc) : 0.0;
+    K[(int64_t)(r0 + i) * mp + j] = val;
   }
 }
 

@@ -201,6 +201,8 @@ int grad_slab_rows() { return GRAD_SLAB; }
 template <int DT, int DBT>
 __global__ __launch_bounds__(256) void grad_fused_kernel(GradArgs a) {
   __shared__ double red[4][2];
+  __shared__ double xs[32][DT];                  // the 32 points being streamed, zero-padded to DT
+  __shared__ double xbs[32][DBT > 0 ? DBT : 1];  // their original inputs (Cov_se_fat with tproj)
   const int j = blockIdx.x * 256 + threadIdx.x;
   const int jj = min(j, a.mp - 1);
   const bool live = (j < a.m);
@@ -216,32 +218,37 @@ __global__ __launch_bounds__(256) void grad_fused_kernel(GradArgs a) {
   double cs = 0.0, sE = 0.0, sED = 0.0;
   const int r0 = blockIdx.y * GRAD_SLAB;
   const int r1 = min(a.rows, r0 + GRAD_SLAB);
-  for (int r = r0; r < r1; ++r) {
-    const double* x = a.pts + (int64_t)r * a.d;
-    const double xv = a.X[(int64_t)r * a.mp + jj];
-    double xr[DT];
-    double dist = 0.0;
-#pragma unroll
-    for (int k = 0; k < DT; ++k) {
-      if (k < a.d) {
-        xr[k] = x[k];
-        const double df = xr[k] - z[k];
-        dist += df * df;
+  for (int rb = r0; rb < r1; rb += 32) {
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < 32 * DT; idx += 256) {
+      const int r = idx / DT, k = idx % DT;
+      xs[r][k] = (k < a.d && rb + r < r1) ? a.pts[(int64_t)(rb + r) * a.d + k] : 0.0;
+    }
+    if (DBT > 0) {
+      for (int idx = threadIdx.x; idx < 32 * DBT; idx += 256) {
+        const int r = idx / DBT, k = idx % DBT;
+        xbs[r][k] = (k < a.D && rb + r < r1) ? a.big[(int64_t)(rb + r) * a.D + k] : 0.0;
       }
     }
-    const double e = live ? xv * exp(a.log_sf2 + a.inv_ell2_05 * dist) : 0.0;
+    __syncthreads();
+    const int nr = min(32, r1 - rb);
+    for (int i = 0; i < nr; ++i) {
+      const double xv = a.X[(int64_t)(rb + i) * a.mp + jj];
+      double dist = 0.0;
 #pragma unroll
-    for (int k = 0; k < DT; ++k)
-      if (k < a.d) gx[k] += xr[k] * e;
-    if (DBT > 0) {
-      const double* xb = a.big + (int64_t)r * a.D;
+      for (int k = 0; k < DT; ++k) {
+        const double df = xs[i][k] - z[k];
+        dist += df * df;
+      }
+      const double e = live ? xv * exp(a.log_sf2 + a.inv_ell2_05 * dist) : 0.0;
 #pragma unroll
-      for (int k = 0; k < DBT; ++k)
-        if (k < a.D) gb[k] += xb[k] * e;
+      for (int k = 0; k < DT; ++k) gx[k] += xs[i][k] * e;
+#pragma unroll
+      for (int k = 0; k < DBT; ++k) gb[k] += xbs[i][k] * e;
+      cs += e;
+      sE += e;
+      sED += e * dist;
     }
-    cs += e;
-    sE += e;
-    sED += e * dist;
   }
   if (j < a.mp) {
     double* cp = a.colpart + (int64_t)blockIdx.y * (a.d + 1 + a.D) * a.mp;
@@ -256,6 +263,7 @@ __global__ __launch_bounds__(256) void grad_fused_kernel(GradArgs a) {
   sE = wave_sum(sE);
   sED = wave_sum(sED);
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  __syncthreads();
   if (lane == 0) {
     red[wv][0] = sE;
     red[wv][1] = sED;
