@@ -35,7 +35,7 @@ struct HipFail {
   } while (0)
 
 constexpr int TILE = 128;  // MFMA engine block tile (rows and columns)
-constexpr int BK = 16;     // MFMA engine k-depth per LDS stage
+constexpr int BK = 16;     // fp64 MFMA engine k-depth per LDS stage (fp32: 32)
 
 static inline int64_t round_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
 

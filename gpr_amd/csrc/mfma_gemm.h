@@ -1,12 +1,12 @@
-// fp64 MFMA contraction engine for gfx950 (v_mfma_f64_16x16x4_f64).
+// MFMA contraction engine for gfx950: v_mfma_f64_16x16x4_f64 (fp64) and v_mfma_f32_16x16x4_f32 (fp32).
 //
 // One kernel family covers every n x m x m / m x m x m contraction on the FITC
 // path: right-side triangular
-// multiplies (the TRSM/TRMM rows), SYRK-shaped accumulations over training
-// points, and the trailing updates of the blocked Cholesky / triangular inverse.
+// multiplies (the TRSM/TRMM rows), SYRK-shaped accumulations over training points,
+// and the trailing updates of the blocked Cholesky / triangular inverse.
 //
-// All matrices are dense row-major doubles whose dimensions the caller has padded:
-// M, N multiples of 128 (TILE), K a multiple of 16 (BK).
+// All matrices are dense row-major whose dimensions the caller has padded:
+// M, N multiples of 128 (TILE), K a multiple of the stage depth (16 for fp64, 32 for fp32).
 #pragma once
 #include "common.h"
 
@@ -28,12 +28,13 @@ enum GemmTri : int {
   TRI_KHI_MIN = 5,  // k <  min(row tile, column tile) end   (TN, A and B upper triangular)
 };
 
-struct GemmArgs {
-  const double* A = nullptr;
+template <typename T>
+struct GemmArgsT {
+  const T* A = nullptr;
   int64_t lda = 0;
-  const double* B = nullptr;
+  const T* B = nullptr;
   int64_t ldb = 0;
-  double* C = nullptr;
+  T* C = nullptr;
   int64_t ldc = 0;
   int M = 0, N = 0, K = 0;
   double alpha = 1.0;
@@ -44,19 +45,22 @@ struct GemmArgs {
   int order = 0;         // block -> tile order of full grids (see tile_of_block)
   int nbatch = 1;        // independent problems of identical shape: gridDim.y, pointers advance by the strides
   int64_t batch_a = 0, batch_b = 0, batch_c = 0;
-  int kslices = 1;       // split K over gridDim.z; slice z writes C + z*slice_stride
+  int kslices = 1;       // split K over the grid; slice z writes C + z*slice_stride
   int64_t slice_stride = 0;
   // optional fused epilogue (when epi_rows_a != null): C[i][j] = ra[i]*acc - rb[i]*M[i][j] - rc[i]*cv[j]
   const double* epi_rows_a = nullptr;
   const double* epi_rows_b = nullptr;
   const double* epi_rows_c = nullptr;
   const double* epi_col = nullptr;
-  const double* epi_mat = nullptr;
+  const T* epi_mat = nullptr;
   int64_t epi_ldm = 0;
 };
+using GemmArgs = GemmArgsT<double>;
+using GemmArgsF = GemmArgsT<float>;
 
-// Enqueue on `stream`.  Returns the number of multiply-add flops issued (x2), for accounting.
+// Enqueue on `stream`.
 void launch_gemm(GemmOp op, const GemmArgs& g, hipStream_t stream);
+void launch_gemm(GemmOp op, const GemmArgsF& g, hipStream_t stream);
 
 // One-time per-process setup (raises the dynamic-LDS limit of the kernels).
 void gemm_init();

@@ -1,28 +1,54 @@
-// fp64 MFMA contraction engine (see mfma_gemm.h).
+// MFMA contraction engine (see mfma_gemm.h), templated on the element type.
 //
 // Block = 256 threads = 4 wavefronts (2 x 2), block tile 128 x 128, wave tile 64 x 64 held as
-// 4 x 4 accumulators of v_mfma_f64_16x16x4_f64 (4 doubles per lane each = 128 VGPRs).
-// k advances 16 per LDS stage; two stages are double-buffered so the global loads of stage t+1
-// are in flight while stage t is multiplied (one barrier per stage).
+// 4 x 4 accumulators of a 16x16x4 MFMA (fp64: 4 doubles per lane each = 128 VGPRs; fp32: 64).
+// A k-stage is 128 bytes of k per row (16 doubles / 32 floats); two stages are double-buffered so
+// the global loads of stage t+1 are in flight while stage t is multiplied (one barrier per stage).
 //
-// LDS images (doubles):
-//   x-major operand (global contiguous along k):  [128][18]  -- row stride 18 makes the fragment
-//       read (lane -> row l&15, k l>>4) hit 32 distinct 8-byte bank pairs per half-wave;
-//   k-major operand (global contiguous along x):  [16][144]  -- row stride 144 puts the two k-rows
-//       a half-wave touches on disjoint bank halves.
-// Fragment maps (cdna_hip_programming.md section 3, f64 form): A lane l holds A[i=l&15][k=l>>4],
-// B lane l holds B[k=l>>4][j=l&15], C/D lane l reg r holds C[(l>>4)+4r][l&15].
+// LDS images (elements; identical byte geometry for both types):
+//   x-major operand (global contiguous along k):  [128][BK+pad]  fp64 stride 18: the fragment read
+//       (lane -> row l&15, k l>>4) hits 32 distinct 8-byte bank pairs per half-wave; fp32 stride 36
+//       (16-byte aligned rows; 2-way conflicts on a read that is far off the critical path);
+//   k-major operand (global contiguous along x):  [BK][144]  -- the k-rows a half-wave touches fall on
+//       disjoint bank ranges.
+// Fragment maps (cdna_hip_programming.md section 3): A lane l holds A[i=l&15][k=l>>4], B lane l holds
+// B[k=l>>4][j=l&15]; C/D lane l reg r holds C[(l>>4)+4r][l&15] for f64 and C[4(l>>4)+r][l&15] for f32.
 #include "mfma_gemm.h"
 
 namespace gprhip {
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 typedef double d2 __attribute__((ext_vector_type(2)));
+typedef float f4 __attribute__((ext_vector_type(4)));
 
-constexpr int XS = 18;                // x-major row stride
-constexpr int KS = 144;               // k-major row stride
-constexpr int STAGE = 128 * XS;       // == 16 * KS == 2304 doubles per operand per stage
-constexpr int LDS_BYTES = 4 * STAGE * 8;
+template <typename T>
+struct Geo;
+template <>
+struct Geo<double> {
+  static constexpr int BKT = 16;   // k-depth of a stage
+  static constexpr int EPV = 2;    // elements per 16-byte vector
+  static constexpr int XS = 18;    // x-major row stride (elements)
+  typedef d2 vec;
+  typedef d4 acc_t;
+  static __device__ __forceinline__ acc_t mfma(double a, double b, acc_t c) {
+    return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ int crow(int lq, int r) { return lq + 4 * r; }
+};
+template <>
+struct Geo<float> {
+  static constexpr int BKT = 32;
+  static constexpr int EPV = 4;
+  static constexpr int XS = 36;
+  typedef f4 vec;
+  typedef f4 acc_t;
+  static __device__ __forceinline__ acc_t mfma(float a, float b, acc_t c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ int crow(int lq, int r) { return 4 * lq + r; }
+};
+constexpr int KS = 144;               // k-major row stride (elements)
+constexpr int LDS_BYTES = 4 * 128 * 18 * 8;  // 2 stages x 2 operands x 18432 bytes
 
 // Block -> (row tile, column tile, k-slice).  The hardware dispatcher places block b on XCD b % 8
 // (observed, used for speed only): blocks are renumbered so that the blocks one XCD receives
@@ -31,7 +57,8 @@ constexpr int LDS_BYTES = 4 * STAGE * 8;
 //                  (the A panel is fetched once per XCD instead of once per column tile);
 //   split-K grids: XCD x owns k-slices x, x+8, ...; all output tiles of a slice run together
 //                  (every tile of the slice streams the same rows of the operand).
-__device__ __forceinline__ void tile_of_block(const GemmArgs& g, int b, int nbm, int nbn, int& bm,
+template <typename T>
+__device__ __forceinline__ void tile_of_block(const GemmArgsT<T>& g, int b, int nbm, int nbn, int& bm,
                                               int& bn, int& slice) {
   slice = 0;
   if (g.upper_only) {
@@ -75,9 +102,17 @@ __device__ __forceinline__ void tile_of_block(const GemmArgs& g, int b, int nbm,
   bn = (g.tri == TRI_KHI_BN) ? (nbn - 1 - bi) : bi;
 }
 
-template <int OP>
-__global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
-  extern __shared__ __attribute__((aligned(16))) double smem[];
+template <typename T, int OP>
+__global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgsT<T> g) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  T* smem = reinterpret_cast<T*>(smem_raw);
+  typedef Geo<T> G;
+  typedef typename G::vec vec;
+  typedef typename G::acc_t acc_t;
+  constexpr int BK = G::BKT, EPV = G::EPV, XS = G::XS;
+  constexpr int STAGE = 128 * XS;          // elements per operand per stage (18432 bytes)
+  constexpr int VPR = 128 / EPV;           // 16-byte vectors per k-major row
+  constexpr int KPP = 256 / VPR;           // k-rows covered per staging pass
   constexpr bool A_KMAJ = (OP == OP_TN);
   constexpr bool B_XMAJ = (OP == OP_NT);
 
@@ -113,81 +148,80 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
   }
   const int nk = (k_hi - k_lo) / BK;
 
-  d4 acc[4][4];
+  acc_t acc[4][4];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = (d4){0.0, 0.0, 0.0, 0.0};
+    for (int j = 0; j < 4; ++j) acc[i][j] = (acc_t){0, 0, 0, 0};
 
-  // ---- per-thread staging coordinates
-  // x-major tile: row = (tid>>3) + 32p, kpair = tid&7 ; k-major tile: k = (tid>>6) + 4p, xpair = tid&63
-  const int xm_row = tid >> 3, xm_kp = tid & 7;
-  const int km_k = tid >> 6, km_xp = tid & 63;
+  // ---- per-thread staging coordinates (16-byte vectors)
+  // x-major tile: row = (tid>>3) + 32p, vector tid&7 of the row's 128 bytes;
+  // k-major tile: k = tid/VPR + KPP*p, vector tid%VPR of the row's 128 elements
+  const int xm_row = tid >> 3, xm_v = tid & 7;
+  const int km_k = tid / VPR, km_v = tid % VPR;
 
-  const double* Ag;
+  const T* Ag;
   int64_t a_step;  // global advance per k-stage
   if (A_KMAJ) {
-    Ag = g.A + (int64_t)(k_lo + km_k) * g.lda + (int64_t)bm * TILE + 2 * km_xp;
+    Ag = g.A + (int64_t)(k_lo + km_k) * g.lda + (int64_t)bm * TILE + EPV * km_v;
     a_step = (int64_t)BK * g.lda;
   } else {
-    Ag = g.A + (int64_t)(bm * TILE + xm_row) * g.lda + k_lo + 2 * xm_kp;
+    Ag = g.A + (int64_t)(bm * TILE + xm_row) * g.lda + k_lo + EPV * xm_v;
     a_step = BK;
   }
-  const double* Bg;
+  const T* Bg;
   int64_t b_step;
   if (B_XMAJ) {
-    Bg = g.B + (int64_t)(bn * TILE + xm_row) * g.ldb + k_lo + 2 * xm_kp;
+    Bg = g.B + (int64_t)(bn * TILE + xm_row) * g.ldb + k_lo + EPV * xm_v;
     b_step = BK;
   } else {
-    Bg = g.B + (int64_t)(k_lo + km_k) * g.ldb + (int64_t)bn * TILE + 2 * km_xp;
+    Bg = g.B + (int64_t)(k_lo + km_k) * g.ldb + (int64_t)bn * TILE + EPV * km_v;
     b_step = (int64_t)BK * g.ldb;
   }
-  // km_k is wavefront-uniform (tid >> 6): say so, and the weights come through the scalar cache
-  const double* sk = (A_KMAJ && g.scale_k) ? g.scale_k + k_lo + __builtin_amdgcn_readfirstlane(km_k) : nullptr;
+  // fp64: km_k is wavefront-uniform (tid >> 6): say so, and the weights come through the scalar cache
+  const int km_ku = (VPR == 64) ? __builtin_amdgcn_readfirstlane(km_k) : km_k;
+  const double* sk = (A_KMAJ && g.scale_k) ? g.scale_k + k_lo + km_ku : nullptr;
 
   // the per-k weights of the A operand are fetched with the tile and applied when the tile is
   // written to LDS, so the multiply never waits on a load that was just issued
-  double rs[4] = {1.0, 1.0, 1.0, 1.0};
-  auto load_global = [&](int t, d2 (&ra)[4], d2 (&rb)[4]) {
-    const double* ap = Ag + (int64_t)t * a_step;
-    const double* bp = Bg + (int64_t)t * b_step;
+  T rs[4] = {1, 1, 1, 1};
+  auto load_global = [&](int t, vec (&ra)[4], vec (&rb)[4]) {
+    const T* ap = Ag + (int64_t)t * a_step;
+    const T* bp = Bg + (int64_t)t * b_step;
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
       if (A_KMAJ) {
-        ra[p] = *reinterpret_cast<const d2*>(ap + (int64_t)(4 * p) * g.lda);
-        if (sk) rs[p] = sk[t * BK + 4 * p];
+        ra[p] = *reinterpret_cast<const vec*>(ap + (int64_t)(KPP * p) * g.lda);
+        if (sk) rs[p] = (T)sk[t * BK + KPP * p];
       } else {
-        ra[p] = *reinterpret_cast<const d2*>(ap + (int64_t)(32 * p) * g.lda);
+        ra[p] = *reinterpret_cast<const vec*>(ap + (int64_t)(32 * p) * g.lda);
       }
       if (B_XMAJ) {
-        rb[p] = *reinterpret_cast<const d2*>(bp + (int64_t)(32 * p) * g.ldb);
+        rb[p] = *reinterpret_cast<const vec*>(bp + (int64_t)(32 * p) * g.ldb);
       } else {
-        rb[p] = *reinterpret_cast<const d2*>(bp + (int64_t)(4 * p) * g.ldb);
+        rb[p] = *reinterpret_cast<const vec*>(bp + (int64_t)(KPP * p) * g.ldb);
       }
     }
   };
-  auto store_lds = [&](int stage, const d2 (&ra)[4], const d2 (&rb)[4]) {
-    double* As = smem + stage * 2 * STAGE;
-    double* Bs = As + STAGE;
+  auto store_lds = [&](int stage, const vec (&ra)[4], const vec (&rb)[4]) {
+    T* As = smem + stage * 2 * STAGE;
+    T* Bs = As + STAGE;
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
       if (A_KMAJ) {
-        d2 v = ra[p];
-        if (sk) {
-          v.x *= rs[p];
-          v.y *= rs[p];
-        }
-        *reinterpret_cast<d2*>(As + (km_k + 4 * p) * KS + 2 * km_xp) = v;
+        vec v = ra[p];
+        if (sk) v *= rs[p];
+        *reinterpret_cast<vec*>(As + (km_k + KPP * p) * KS + EPV * km_v) = v;
       } else
-        *reinterpret_cast<d2*>(As + (xm_row + 32 * p) * XS + 2 * xm_kp) = ra[p];
+        *reinterpret_cast<vec*>(As + (xm_row + 32 * p) * XS + EPV * xm_v) = ra[p];
       if (B_XMAJ)
-        *reinterpret_cast<d2*>(Bs + (xm_row + 32 * p) * XS + 2 * xm_kp) = rb[p];
+        *reinterpret_cast<vec*>(Bs + (xm_row + 32 * p) * XS + EPV * xm_v) = rb[p];
       else
-        *reinterpret_cast<d2*>(Bs + (km_k + 4 * p) * KS + 2 * km_xp) = rb[p];
+        *reinterpret_cast<vec*>(Bs + (km_k + KPP * p) * KS + EPV * km_v) = rb[p];
     }
   };
 
-  // fragment base offsets (doubles) inside a stage
+  // fragment base offsets (elements) inside a stage
   const int a_frag = A_KMAJ ? (lq * KS + wr * 64 + l15) : ((wr * 64 + l15) * XS + lq);
   const int b_frag = B_XMAJ ? ((wc * 64 + l15) * XS + lq) : (lq * KS + wc * 64 + l15);
   constexpr int A_TM = A_KMAJ ? 16 : 16 * XS;  // advance per 16-row sub-tile
@@ -196,26 +230,27 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
   constexpr int B_KK = B_XMAJ ? 4 : 4 * KS;
 
   // Inside the diagonal 128-block of a triangular B operand, column sub-tile cj (16 columns,
-  // cj = 0..7 across the block tile) only meets non-zeros in k-stages u <= cj (k-range ends at the
-  // diagonal, TRI_KHI_BN) or u >= cj (k-range starts at it, TRI_KLO_BN): the MFMAs of the other
+  // cj = 0..7 across the block tile) only meets non-zeros in k-stages that start at or before its last
+  // column (k-range ends at the diagonal, TRI_KHI_BN) or end at or after its first column (k-range
+  // starts at it, TRI_KLO_BN): the MFMAs of the other
   // (sub-tile, stage) pairs multiply zeros and are skipped -- about half of that block's work.
   const int diag_first = (g.tri == TRI_KHI_BN && k_hi == (bn + 1) * TILE) ? nk - TILE / BK
                          : (g.tri == TRI_KLO_BN && k_lo == bn * TILE) ? 0 : -(1 << 30);
   const int cj0 = wc * 4;
   auto compute = [&](int stage, int t) {
-    const double* As = smem + stage * 2 * STAGE;
-    const double* Bs = As + STAGE;
+    const T* As = smem + stage * 2 * STAGE;
+    const T* Bs = As + STAGE;
     int jlo = 0, jhi = 7;  // live column sub-tiles of this stage
     const int u = t - diag_first;
-    if (u >= 0 && u < TILE / BK) {
-      if (g.tri == TRI_KHI_BN) jlo = u; else jhi = u;
+    if (u >= 0 && u < TILE / BK) {  // stage u of the diagonal block covers k in [BK*u, BK*u + BK)
+      if (g.tri == TRI_KHI_BN) jlo = (BK * u) / 16; else jhi = (BK * u + BK - 1) / 16;
     }
     if (jlo > cj0 + 3 || jhi < cj0) return;
     if (jlo <= cj0 && jhi >= cj0 + 3) {
       // every sub-tile live: the common case, one straight MFMA stream
 #pragma unroll
-      for (int kk = 0; kk < 4; ++kk) {
-        double af[4], bf[4];
+      for (int kk = 0; kk < BK / 4; ++kk) {
+        T af[4], bf[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) af[i] = As[a_frag + i * A_TM + kk * A_KK];
 #pragma unroll
@@ -224,13 +259,13 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
         for (int i = 0; i < 4; ++i)
 #pragma unroll
           for (int j = 0; j < 4; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i], bf[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = G::mfma(af[i], bf[j], acc[i][j]);
       }
       return;
     }
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-      double af[4], bf[4];
+    for (int kk = 0; kk < BK / 4; ++kk) {
+      T af[4], bf[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) af[i] = As[a_frag + i * A_TM + kk * A_KK];
 #pragma unroll
@@ -240,7 +275,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
         if (cj0 + j >= jlo && cj0 + j <= jhi) {
 #pragma unroll
           for (int i = 0; i < 4; ++i)
-            acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i], bf[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = G::mfma(af[i], bf[j], acc[i][j]);
         }
       }
     }
@@ -249,7 +284,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
   if (nk > 0) {
     {
       // global loads of stage t+1 are in flight while stage t is multiplied
-      d2 ra[4], rb[4];
+      vec ra[4], rb[4];
       load_global(0, ra, rb);
       store_lds(0, ra, rb);
       __syncthreads();
@@ -264,27 +299,26 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
   }
 
   // ---- epilogue
-  const int row0 = bm * TILE + wr * 64 + lq, col0 = bn * TILE + wc * 64 + l15;
-  double* Cp = g.C + (int64_t)slice * g.slice_stride + (int64_t)row0 * g.ldc + col0;
-  const double alpha = g.alpha, beta = g.beta;
+  const int rowb = bm * TILE + wr * 64, col0 = bn * TILE + wc * 64 + l15;
+  T* Cp = g.C + (int64_t)slice * g.slice_stride + col0;
+  const T alpha = (T)g.alpha, beta = (T)g.beta;
   if (g.epi_rows_a) {
     // fused X~ epilogue: C[i][j] = ra[i]*acc - rb[i]*M[i][j] - rc[i]*cv[j]
     //   (X~ = diag(is) Q' R~^-T - diag(v) V - w t~^T of the gradient pass)
-    const double* Mp = g.epi_mat + (int64_t)row0 * g.epi_ldm + col0;
-    double cv[4];
+    const T* Mp = g.epi_mat + col0;
+    T cv[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) cv[j] = g.epi_col[col0 + j * 16];
+    for (int j = 0; j < 4; ++j) cv[j] = (T)g.epi_col[col0 + j * 16];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int row = row0 + i * 16 + 4 * r;
-        const double ra = g.epi_rows_a[row], rb = g.epi_rows_b[row], rc = g.epi_rows_c[row];
+        const int row = rowb + i * 16 + G::crow(lq, r);
+        const T ra = (T)g.epi_rows_a[row], rb = (T)g.epi_rows_b[row], rc = (T)g.epi_rows_c[row];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int64_t o = (int64_t)(i * 16 + 4 * r);
-          Cp[o * g.ldc + j * 16] = ra * acc[i][j][r] - rb * Mp[o * g.epi_ldm + j * 16] - rc * cv[j];
-        }
+        for (int j = 0; j < 4; ++j)
+          Cp[(int64_t)row * g.ldc + j * 16] =
+              ra * acc[i][j][r] - rb * Mp[(int64_t)row * g.epi_ldm + j * 16] - rc * cv[j];
       }
     return;
   }
@@ -294,9 +328,9 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
     for (int j = 0; j < 4; ++j)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        double* p = Cp + (int64_t)(i * 16 + 4 * r) * g.ldc + j * 16;
-        double v = alpha * acc[i][j][r];
-        if (beta != 0.0) v += beta * (*p);
+        T* p = Cp + (int64_t)(rowb + i * 16 + G::crow(lq, r)) * g.ldc + j * 16;
+        T v = alpha * acc[i][j][r];
+        if (beta != (T)0) v += beta * (*p);
         *p = v;
       }
 }
@@ -304,17 +338,22 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
 void gemm_init() {
   static bool done = false;
   if (done) return;
-  const void* ks[] = {reinterpret_cast<const void*>(&gemm_kernel<OP_NN>),
-                      reinterpret_cast<const void*>(&gemm_kernel<OP_NT>),
-                      reinterpret_cast<const void*>(&gemm_kernel<OP_TN>)};
+  const void* ks[] = {reinterpret_cast<const void*>(&gemm_kernel<double, OP_NN>),
+                      reinterpret_cast<const void*>(&gemm_kernel<double, OP_NT>),
+                      reinterpret_cast<const void*>(&gemm_kernel<double, OP_TN>),
+                      reinterpret_cast<const void*>(&gemm_kernel<float, OP_NN>),
+                      reinterpret_cast<const void*>(&gemm_kernel<float, OP_NT>),
+                      reinterpret_cast<const void*>(&gemm_kernel<float, OP_TN>)};
   for (const void* k : ks)
     GPR_HIP(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
   done = true;
 }
 
-void launch_gemm(GemmOp op, const GemmArgs& g, hipStream_t stream) {
+template <typename T>
+static void launch_gemm_t(GemmOp op, const GemmArgsT<T>& g, hipStream_t stream) {
+  constexpr int BK = Geo<T>::BKT;
   if (g.M % TILE || g.N % TILE || g.K % BK || g.M <= 0 || g.N <= 0 || g.K <= 0) {
-    set_error("gprhip: launch_gemm: dimensions must be padded (M,N % 128, K % 16)");
+    set_error("gprhip: launch_gemm: dimensions must be padded (M,N % 128, K % stage depth)");
     throw HipFail{ST_BAD_ARG};
   }
   const int nbm = g.M / TILE, nbn = g.N / TILE;
@@ -326,11 +365,14 @@ void launch_gemm(GemmOp op, const GemmArgs& g, hipStream_t stream) {
   dim3 grid(tiles * (g.kslices > 1 ? g.kslices : 1), g.nbatch > 1 ? g.nbatch : 1);
   dim3 block(256);
   switch (op) {
-    case OP_NN: hipLaunchKernelGGL(gemm_kernel<OP_NN>, grid, block, LDS_BYTES, stream, g); break;
-    case OP_NT: hipLaunchKernelGGL(gemm_kernel<OP_NT>, grid, block, LDS_BYTES, stream, g); break;
-    case OP_TN: hipLaunchKernelGGL(gemm_kernel<OP_TN>, grid, block, LDS_BYTES, stream, g); break;
+    case OP_NN: hipLaunchKernelGGL((gemm_kernel<T, OP_NN>), grid, block, LDS_BYTES, stream, g); break;
+    case OP_NT: hipLaunchKernelGGL((gemm_kernel<T, OP_NT>), grid, block, LDS_BYTES, stream, g); break;
+    case OP_TN: hipLaunchKernelGGL((gemm_kernel<T, OP_TN>), grid, block, LDS_BYTES, stream, g); break;
   }
   GPR_HIP(hipGetLastError());
 }
+
+void launch_gemm(GemmOp op, const GemmArgs& g, hipStream_t stream) { launch_gemm_t<double>(op, g, stream); }
+void launch_gemm(GemmOp op, const GemmArgsF& g, hipStream_t stream) { launch_gemm_t<float>(op, g, stream); }
 
 }  // namespace gprhip

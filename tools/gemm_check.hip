@@ -87,8 +87,96 @@ void timeit(GemmOp op, int M, int N, int K, int tri, int upper, int kslices, con
   hipFree(dA); hipFree(dB); hipFree(dC);
 }
 
+template <typename T>
+__global__ void naive_t(int op, const T* A, int64_t lda, const T* B, int64_t ldb, double* C, int64_t ldc, int M,
+                        int N, int K, const double* sk) {
+  int j = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y;
+  if (j >= N) return;
+  double s = 0;
+  for (int k = 0; k < K; ++k) {
+    double a = op == OP_TN ? (double)A[(int64_t)k * lda + i] * (sk ? sk[k] : 1.0) : (double)A[(int64_t)i * lda + k];
+    double b = op == OP_NT ? (double)B[(int64_t)j * ldb + k] : (double)B[(int64_t)k * ldb + j];
+    s += a * b;
+  }
+  C[(int64_t)i * ldc + j] = s;
+}
+
+int check_f32(GemmOp op, int M, int N, int K, int tri, bool scale, bool epi) {
+  int64_t ar = op == OP_TN ? K : M, ac = op == OP_TN ? M : K;
+  int64_t br = op == OP_NT ? N : K, bc = op == OP_NT ? K : N;
+  std::vector<float> hA(ar * ac), hB(br * bc), hM((int64_t)M * N);
+  std::vector<double> hs(std::max(K, M)), hcol(N);
+  for (auto& v : hA) v = (float)frand();
+  for (auto& v : hB) v = (float)frand();
+  for (auto& v : hM) v = (float)frand();
+  for (auto& v : hs) v = frand();
+  for (auto& v : hcol) v = frand();
+  if (tri == TRI_KHI_BN) for (int k = 0; k < K; ++k) for (int j = 0; j < N; ++j) if (k > j) hB[(int64_t)k * bc + j] = 0;
+  if (tri == TRI_KLO_BN) for (int j = 0; j < N; ++j) for (int k = 0; k < K; ++k) if (k < j) hB[(int64_t)j * bc + k] = 0;
+  float *dA, *dB, *dC, *dM; double *dR, *ds, *dcol;
+  hipMalloc(&dA, hA.size() * 4); hipMalloc(&dB, hB.size() * 4); hipMalloc(&dC, (int64_t)M * N * 4); hipMalloc(&dM, (int64_t)M * N * 4);
+  hipMalloc(&dR, (int64_t)M * N * 8); hipMalloc(&ds, hs.size() * 8); hipMalloc(&dcol, N * 8);
+  hipMemcpy(dA, hA.data(), hA.size() * 4, hipMemcpyHostToDevice); hipMemcpy(dB, hB.data(), hB.size() * 4, hipMemcpyHostToDevice);
+  hipMemcpy(dM, hM.data(), hM.size() * 4, hipMemcpyHostToDevice);
+  hipMemcpy(ds, hs.data(), hs.size() * 8, hipMemcpyHostToDevice); hipMemcpy(dcol, hcol.data(), N * 8, hipMemcpyHostToDevice);
+  hipMemset(dC, 0, (int64_t)M * N * 4);
+  GemmArgsF g; g.A = dA; g.lda = ac; g.B = dB; g.ldb = bc; g.C = dC; g.ldc = N; g.M = M; g.N = N; g.K = K; g.tri = tri;
+  g.scale_k = scale ? ds : nullptr;
+  if (epi) { g.epi_rows_a = ds; g.epi_rows_b = ds; g.epi_rows_c = ds; g.epi_col = dcol; g.epi_mat = dM; g.epi_ldm = N; }
+  launch_gemm(op, g, 0);
+  naive_t<float><<<dim3((N + 255) / 256, M), 256>>>(op, dA, ac, dB, bc, dR, N, M, N, K, scale ? ds : nullptr);
+  std::vector<float> hC((int64_t)M * N); std::vector<double> hR((int64_t)M * N);
+  hipMemcpy(hC.data(), dC, hC.size() * 4, hipMemcpyDeviceToHost); hipMemcpy(hR.data(), dR, hR.size() * 8, hipMemcpyDeviceToHost);
+  double maxerr = 0;
+  for (int i = 0; i < M; ++i) for (int j = 0; j < N; ++j) {
+    double ref = hR[(int64_t)i * N + j];
+    if (epi) ref = hs[i] * ref - hs[i] * hM[(int64_t)i * N + j] - hs[i] * hcol[j];
+    maxerr = std::max(maxerr, fabs(hC[(int64_t)i * N + j] - ref));
+  }
+  bool ok = maxerr < 2e-6 * K;
+  printf("check f32 op=%d M=%d N=%d K=%d tri=%d scale=%d epi=%d maxerr=%.3e %s\n", op, M, N, K, tri, (int)scale, (int)epi, maxerr, ok ? "OK" : "FAIL");
+  hipFree(dA); hipFree(dB); hipFree(dC); hipFree(dM); hipFree(dR); hipFree(ds); hipFree(dcol);
+  return ok ? 0 : 1;
+}
+
+void timeit_f32(GemmOp op, int M, int N, int K, int tri, int upper, int kslices, const char* name) {
+  int64_t ar = op == OP_TN ? K : M, ac = op == OP_TN ? M : K;
+  int64_t br = op == OP_NT ? N : K, bc = op == OP_NT ? K : N;
+  float *dA, *dB, *dC;
+  hipMalloc(&dA, ar * ac * 4); hipMalloc(&dB, br * bc * 4); hipMalloc(&dC, (int64_t)M * N * 4 * std::max(1, kslices));
+  std::vector<float> h(std::max(ar * ac, br * bc));
+  for (size_t i = 0; i < h.size(); ++i) h[i] = (float)((i * 2654435761u) & 0xffff) / 65536.0f - 0.5f;
+  hipMemcpy(dA, h.data(), ar * ac * 4, hipMemcpyHostToDevice); hipMemcpy(dB, h.data(), br * bc * 4, hipMemcpyHostToDevice);
+  GemmArgsF g; g.A = dA; g.lda = ac; g.B = dB; g.ldb = bc; g.C = dC; g.ldc = N; g.M = M; g.N = N; g.K = K;
+  g.tri = tri; g.upper_only = upper; g.kslices = kslices; g.slice_stride = (int64_t)M * N;
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  for (int i = 0; i < 2; ++i) launch_gemm(op, g, 0);
+  hipEventRecord(e0, 0);
+  int reps = 5;
+  for (int i = 0; i < reps; ++i) launch_gemm(op, g, 0);
+  hipEventRecord(e1, 0); hipEventSynchronize(e1);
+  float ms; hipEventElapsedTime(&ms, e0, e1); ms /= reps;
+  double flops = 2.0 * M * N * (double)K; if (tri != TRI_NONE) flops *= 0.5; if (upper) flops *= 0.5;
+  printf("time f32 %-24s M=%d N=%d K=%d tri=%d upper=%d ks=%d : %.3f ms  %.1f TFLOP/s (useful)\n", name, M, N, K, tri, upper, kslices, ms, flops / ms * 1e-9);
+  hipFree(dA); hipFree(dB); hipFree(dC);
+}
+
 int main() {
   gemm_init();
+  if (getenv("F32")) {
+    int bad = 0;
+    bad += check_f32(OP_NN, 256, 256, 64, TRI_NONE, false, false);
+    bad += check_f32(OP_NT, 256, 384, 96, TRI_NONE, false, false);
+    bad += check_f32(OP_TN, 256, 256, 160, TRI_NONE, true, false);
+    bad += check_f32(OP_NN, 384, 256, 256, TRI_KHI_BN, false, false);
+    bad += check_f32(OP_NT, 384, 256, 256, TRI_KLO_BN, false, true);
+    printf("f32 checks failed: %d\n", bad);
+    timeit_f32(OP_NN, 8192, 8192, 8192, TRI_NONE, 0, 1, "square NN 8192");
+    timeit_f32(OP_NN, 32768, 4096, 4096, TRI_KHI_BN, 0, 1, "K*Uinv triu m4096");
+    timeit_f32(OP_NT, 32768, 4096, 4096, TRI_KLO_BN, 0, 1, "V*Uinv^T triu m4096");
+    timeit_f32(OP_TN, 4096, 4096, 262144, TRI_NONE, 1, 64, "syrk m4096 K=256k ks64");
+    return bad;
+  }
   int bad = 0;
   bad += check(OP_NN, 256, 256, 64, TRI_NONE, false);
   bad += check(OP_NT, 256, 384, 48, TRI_NONE, false);
