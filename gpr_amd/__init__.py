@@ -3,6 +3,6 @@
 The compute path is the hand-written HIP library gpr_amd/libgprhip.so (C ABI: include/gprhip.h);
 this package is the host-side mirror of the reference's functor interface for that path.
 """
-from ._lib import (COV_SE_FAT, COV_SE_ISO, GprHipError, NotPositiveDefinite, device_count,  # noqa: F401
-                   load)
+from ._lib import (COV_SE_FAT, COV_SE_ISO, F32_BULK, F64, GprHipError, NotPositiveDefinite,  # noqa: F401
+                   device_count, load)
 from .problem import CHOLESKY_JITTER, Evaluation, Problem  # noqa: F401

@@ -14,6 +14,7 @@ LIB_PATH = os.path.join(_HERE, "libgprhip.so")
 
 OK, EBADARG, ENOTPOSDEF, EHIP, EOOM, ESTATE = range(6)
 COV_SE_ISO, COV_SE_FAT = 0, 1
+F64, F32_BULK = 0, 1
 
 
 class GprHipError(RuntimeError):
@@ -56,6 +57,8 @@ SIGNATURES = {
     "gprhip_device_count": (C.c_int, [C.POINTER(C.c_int)]),
     "gprhip_problem_create": (C.c_int, [C.c_int, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int,
                                         C.c_int64, C.POINTER(_vp)]),
+    "gprhip_problem_create_ex": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int,
+                                           C.c_int64, C.POINTER(_vp)]),
     "gprhip_problem_destroy": (None, [_vp]),
     "gprhip_set_inputs": (C.c_int, [_vp, _dp, C.c_int64]),
     "gprhip_set_targets": (C.c_int, [_vp, _dp]),

@@ -15,11 +15,11 @@ namespace gprhip {
 // are staged in LDS zero-padded to DT dimensions, so the distance loop is branch-free and reads its
 // x values as LDS broadcasts.  Padded dimensions add (0-0)^2 = 0 exactly: the rounding sequence of the
 // real dimensions is unchanged.
-template <int DT>
+template <int DT, typename TS>
 __global__ __launch_bounds__(256) void cov_cross_kernel(CovParams cp, const double* __restrict__ pts,
                                                         int rows, int rows_p,
                                                         const double* __restrict__ Z, int m, int mp,
-                                                        int d, double* __restrict__ K) {
+                                                        int d, TS* __restrict__ K) {
   __shared__ double xs[32][DT];
   const int j = blockIdx.x * 256 + threadIdx.x;
   const int r0 = blockIdx.y * 32;
@@ -42,7 +42,7 @@ __global__ __launch_bounds__(256) void cov_cross_kernel(CovParams cp, const doub
       acc = acc + diff * diff;
     }
     const double val = (r0 + i < rows && live_col) ? exp(cp.log_sf2 + cp.inv_ell2_05 * acc) : 0.0;
-    K[(int64_t)(r0 + i) * mp + j] = val;
+    K[(int64_t)(r0 + i) * mp + j] = (TS)val;
   }
 }
 
@@ -126,15 +126,20 @@ void launch_cov_upper(const CovParams& cp, const double* Z, int m, int mp, int d
   GPR_HIP(hipGetLastError());
 }
 
+template <typename TS>
 void launch_cov_cross(const CovParams& cp, const double* pts, int rows, int rows_p, const double* Z,
-                      int m, int mp, int d, double* K, hipStream_t s) {
+                      int m, int mp, int d, TS* K, hipStream_t s) {
   dim3 grid(mp / 256 + (mp % 256 ? 1 : 0), (rows_p + 31) / 32);
   dispatch_dt(d, [&](auto dt) {
-    hipLaunchKernelGGL((cov_cross_kernel<decltype(dt)::value>), grid, dim3(256), 0, s, cp, pts, rows,
+    hipLaunchKernelGGL((cov_cross_kernel<decltype(dt)::value, TS>), grid, dim3(256), 0, s, cp, pts, rows,
                        rows_p, Z, m, mp, d, K);
   });
   GPR_HIP(hipGetLastError());
 }
+template void launch_cov_cross<double>(const CovParams&, const double*, int, int, const double*, int, int, int,
+                                       double*, hipStream_t);
+template void launch_cov_cross<float>(const CovParams&, const double*, int, int, const double*, int, int, int,
+                                      float*, hipStream_t);
 
 void launch_project(const double* X, int64_t n, int D, int d, const double* tproj, double* P,
                     hipStream_t s) {

@@ -4,8 +4,9 @@
 namespace gprhip {
 
 // dst = base + sum_z slices[z] on upper tiles (row tile <= column tile), 0 elsewhere.
+template <typename TS>
 __global__ __launch_bounds__(256) void sum_slices_kernel(const double* __restrict__ base,
-                                                         const double* __restrict__ slices, int nslices,
+                                                         const TS* __restrict__ slices, int nslices,
                                                          int64_t stride, int mp,
                                                          double* __restrict__ dst) {
   const int c = blockIdx.x * 256 + threadIdx.x;
@@ -15,15 +16,28 @@ __global__ __launch_bounds__(256) void sum_slices_kernel(const double* __restric
   double acc = 0.0;
   if (r / TILE <= c / TILE) {
     acc = base ? base[off] : 0.0;
-    for (int z = 0; z < nslices; ++z) acc += slices[(int64_t)z * stride + off];
+    for (int z = 0; z < nslices; ++z) acc += (double)slices[(int64_t)z * stride + off];
   }
   dst[off] = acc;
 }
 
-void launch_sum_slices(const double* base, const double* slices, int nslices, int64_t stride, int mp,
+template <typename TS>
+void launch_sum_slices(const double* base, const TS* slices, int nslices, int64_t stride, int mp,
                        double* dst, hipStream_t s) {
-  hipLaunchKernelGGL(sum_slices_kernel, dim3((mp + 255) / 256, mp), dim3(256), 0, s, base, slices,
+  hipLaunchKernelGGL(sum_slices_kernel<TS>, dim3((mp + 255) / 256, mp), dim3(256), 0, s, base, slices,
                      nslices, stride, mp, dst);
+  GPR_HIP(hipGetLastError());
+}
+template void launch_sum_slices<double>(const double*, const double*, int, int64_t, int, double*, hipStream_t);
+template void launch_sum_slices<float>(const double*, const float*, int, int64_t, int, double*, hipStream_t);
+
+__global__ void to_float_kernel(const double* __restrict__ src, float* __restrict__ dst, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) dst[i] = (float)src[i];
+}
+
+void launch_to_float(const double* src, float* dst, int64_t n, hipStream_t s) {
+  hipLaunchKernelGGL(to_float_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, dst, n);
   GPR_HIP(hipGetLastError());
 }
 

@@ -94,8 +94,12 @@ struct gprhip_problem {
   int* info = nullptr;
   double *r = nullptr, *is = nullptr, *yis = nullptr, *w = nullptr, *v = nullptr, *es = nullptr;
   double* projpart = nullptr;
-  double *bufA = nullptr, *bufB = nullptr, *Vstore = nullptr;
-  double* slices = nullptr;
+  // n x m storage: double, or float in the fp32-bulk mode (element size `esz`)
+  void *bufA = nullptr, *bufB = nullptr, *Vstore = nullptr;
+  float *uinv_f = nullptr, *rinv_f = nullptr;  // fp32 copies of U^-1 / R~^-1 (fp32-bulk mode)
+  int f32 = 0;
+  size_t esz = 8;
+  void* slices = nullptr;
   double *rowpart = nullptr, *gemvpart = nullptr, *colpart = nullptr, *scalpart = nullptr,
          *kmpart = nullptr, *kmred = nullptr;
   double *ar1 = nullptr, *ar2 = nullptr;  // internal exchange buffers for single-device eval
@@ -135,6 +139,13 @@ struct gprhip_problem {
 };
 
 namespace {
+
+template <typename TS> const TS* inv_u(const gprhip_problem* p);
+template <> const double* inv_u<double>(const gprhip_problem* p) { return p->uinv; }
+template <> const float* inv_u<float>(const gprhip_problem* p) { return p->uinv_f; }
+template <typename TS> const TS* inv_r(const gprhip_problem* p);
+template <> const double* inv_r<double>(const gprhip_problem* p) { return p->rinv; }
+template <> const float* inv_r<float>(const gprhip_problem* p) { return p->rinv_f; }
 
 void tstart(gprhip_problem* p, const char* name) {
   if (!p->timer.on) return;
@@ -308,13 +319,15 @@ int pick_kslices(int mp, int64_t rows_p, int max_slices) {
   return best;
 }
 
-void cov_chunk(gprhip_problem* p, int c, double* K) {
+template <typename TS>
+void cov_chunk(gprhip_problem* p, int c, TS* K) {
   const int64_t rows = p->rows_of(c);
   const int64_t rows_p = round_up(rows, TILE);
   const double* pts = p->pts() + (int64_t)c * p->chunk * p->d;
-  launch_cov_cross(p->cp, pts, (int)rows, (int)rows_p, p->Z, p->m, p->mp, p->d, K, p->stream);
+  launch_cov_cross<TS>(p->cp, pts, (int)rows, (int)rows_p, p->Z, p->m, p->mp, p->d, K, p->stream);
 }
 
+template <typename TS>
 void do_pass1(gprhip_problem* p, const gprhip_hypers* h, int want_grad, int64_t n_total, double* ar1) {
   if (!p->have_inputs || (!p->have_targets && !h->model_only)) {
     set_error("gprhip: inputs/targets not set");
@@ -330,7 +343,10 @@ void do_pass1(gprhip_problem* p, const gprhip_hypers* h, int want_grad, int64_t 
   double* ar1_c = ar1 + mm;
   double* ar1_tail = ar1_c + mp;
   if (!p->Vstore)  // V = K U^-1 for all rows of the shard stays resident (one SYRK launch; pass 2 re-reads it)
-    p->Vstore = p->alloc<double>((int64_t)p->nchunks * p->chunk * mp);
+    p->Vstore = p->alloc<TS>((int64_t)p->nchunks * p->chunk * mp);
+  TS* const Vstore = static_cast<TS*>(p->Vstore);
+  TS* const bufA = static_cast<TS*>(p->bufA);
+  TS* const slices = static_cast<TS*>(p->slices);
 
   tstart(p, "km_chol");
   GPR_HIP(hipMemsetAsync(p->info, 0, 2 * sizeof(int), s));
@@ -340,24 +356,25 @@ void do_pass1(gprhip_problem* p, const gprhip_hypers* h, int want_grad, int64_t 
   GPR_HIP(hipMemcpyAsync(p->umat, p->kj, (size_t)mm * sizeof(double), hipMemcpyDeviceToDevice, s));
   potrf_upper(p, p->umat, p->info);  // U = chol(K_m + jitter), lib/fitc_gp.ml:53-57
   trtri_upper(p, p->umat, p->uinv, p->wmat);
+  if (p->f32) launch_to_float(p->uinv, p->uinv_f, mm, s);
   tstop(p);
 
   for (int c = 0; c < p->nchunks; ++c) {
     const int64_t rows = p->rows_of(c);
     const int rows_p = (int)round_up(rows, TILE);
     const int64_t base = (int64_t)c * p->chunk;
-    double* V = p->Vstore + base * mp;
+    TS* V = Vstore + base * mp;
     tstart(p, "p1_cov");
-    cov_chunk(p, c, p->bufA);
+    cov_chunk<TS>(p, c, bufA);
     tstop(p);
     tstart(p, "p1_trmm_V");
-    GemmArgs g;  // V = K U^-1   (dtrsm `R, lib/fitc_gp.ml:226-227)
-    g.A = p->bufA; g.lda = mp; g.B = p->uinv; g.ldb = mp; g.C = V; g.ldc = mp;
+    GemmArgsT<TS> g;  // V = K U^-1   (dtrsm `R, lib/fitc_gp.ml:226-227)
+    g.A = bufA; g.lda = mp; g.B = inv_u<TS>(p); g.ldb = mp; g.C = V; g.ldc = mp;
     g.M = rows_p; g.N = mp; g.K = mp; g.tri = TRI_KHI_BN; g.order = p->tile_order;
     launch_gemm(OP_NN, g, s);
     tstop(p);
     tstart(p, "p1_rows");
-    Pass1RowArgs ra;
+    Pass1RowArgs<TS> ra;
     ra.V = V; ra.y = h->model_only ? nullptr : p->y + base; ra.rows = (int)rows; ra.mp = mp;
     ra.sf2 = p->cp.sf2; ra.sigma2 = h->sigma2;
     ra.r = p->r + base; ra.is = p->is + base; ra.yis = p->yis + base; ra.partial = p->rowpart;
@@ -370,21 +387,22 @@ void do_pass1(gprhip_problem* p, const gprhip_hypers* h, int want_grad, int64_t 
   const int64_t ktot = p->rows_total_padded();
   const int ks = pick_kslices(mp, ktot, p->kslices);
   tstart(p, "p1_syrk_B");
-  GemmArgs b;
-  b.A = p->Vstore; b.lda = mp; b.B = p->Vstore; b.ldb = mp; b.C = p->slices; b.ldc = mp;
+  GemmArgsT<TS> b;
+  b.A = Vstore; b.lda = mp; b.B = Vstore; b.ldb = mp; b.C = slices; b.ldc = mp;
   b.M = mp; b.N = mp; b.K = (int)ktot; b.beta = 0.0; b.scale_k = p->is; b.upper_only = 1;
   b.kslices = ks; b.slice_stride = mm;
   launch_gemm(OP_TN, b, s);
   tstop(p);
   tstart(p, "p1_gemv_c");
-  launch_gemv_t_partial(p->Vstore, (int)ktot, mp, p->yis, p->gemvpart, s);
+  launch_gemv_t_partial<TS>(Vstore, (int)ktot, mp, p->yis, p->gemvpart, s);
   launch_reduce_rows(p->gemvpart, (int)((ktot + 255) / 256), mp, ar1_c, 1, s);
   tstop(p);
   p->ks_used = ks;
-  launch_sum_slices(nullptr, p->slices, ks, mm, mp, ar1, s);
+  launch_sum_slices<TS>(nullptr, slices, ks, mm, mp, ar1, s);
   p->stage = 1;
 }
 
+template <typename TS>
 void do_pass2(gprhip_problem* p, const double* ar1, double* ar2) {
   if (p->stage != 1) {
     set_error("gprhip: eval_pass2 called before eval_pass1");
@@ -408,6 +426,11 @@ void do_pass2(gprhip_problem* p, const double* ar1, double* ar2) {
   potrf_upper(p, p->bmat, p->info + 1);
   launch_logdet(p->bmat, mp, mp, p->scal + SC_LOGDET_B, s);
   trtri_upper(p, p->bmat, p->rinv, p->wmat);
+  if (p->f32) launch_to_float(p->rinv, p->rinv_f, mm, s);
+  TS* const Vstore = static_cast<TS*>(p->Vstore);
+  TS* const bufA = static_cast<TS*>(p->bufA);
+  TS* const bufB = static_cast<TS*>(p->bufB);
+  TS* const slices = static_cast<TS*>(p->slices);
   // b = R~^-T c~ (= Q_n^T y~, lib/fitc_gp.ml:285-286);  t~ = R~^-1 b;  t = U^-1 t~ (trsv, :291 / :1167)
   launch_triu_matvec(p->rinv, mp, ar1_c, p->bvec, 1, s);
   launch_triu_matvec(p->rinv, mp, p->bvec, p->ttil, 0, s);
@@ -424,16 +447,16 @@ void do_pass2(gprhip_problem* p, const double* ar1, double* ar2) {
       const int64_t rows = p->rows_of(c);
       const int rows_p = (int)round_up(rows, TILE);
       const int64_t base = (int64_t)c * p->chunk;
-      const double* V = p->Vstore + base * mp;
+      const TS* V = Vstore + base * mp;
       tstart(p, "p2_trmm_Q");
-      GemmArgs q;  // Q' = V R~^-1 = K R^-1  (Q_n = diag(sqrt is) Q', lib/fitc_gp.ml:176-182)
-      q.A = V; q.lda = mp; q.B = p->rinv; q.ldb = mp; q.C = p->bufA; q.ldc = mp;
+      GemmArgsT<TS> q;  // Q' = V R~^-1 = K R^-1  (Q_n = diag(sqrt is) Q', lib/fitc_gp.ml:176-182)
+      q.A = V; q.lda = mp; q.B = inv_r<TS>(p); q.ldb = mp; q.C = bufA; q.ldc = mp;
       q.M = rows_p; q.N = mp; q.K = mp; q.tri = TRI_KHI_BN; q.order = p->tile_order;
       launch_gemm(OP_NN, q, s);
       tstop(p);
       tstart(p, "p2_rows");
-      Pass2RowArgs ra;
-      ra.Q = p->bufA; ra.b = p->bvec;
+      Pass2RowArgs<TS> ra;
+      ra.Q = bufA; ra.b = p->bvec;
       ra.y = mo ? nullptr : p->y + base; ra.is = p->is + base; ra.r = p->r + base;
       ra.rows = (int)rows; ra.mp = mp; ra.variational = p->h.variational;
       ra.sf2 = p->cp.sf2; ra.es = proj ? p->es + base : nullptr;
@@ -442,22 +465,22 @@ void do_pass2(gprhip_problem* p, const double* ar1, double* ar2) {
       launch_reduce_rows(p->rowpart, pass1_row_blocks(rows_p), 4, ar2_tail, 1, s);
       tstop(p);
       tstart(p, "p2_trmm_S");
-      GemmArgs sg;  // X~ = diag(is) Q' R~^-T - diag(v) V - w t~^T   (S, U_mat and the ger of :936-938, :1204-1206)
-      sg.A = p->bufA; sg.lda = mp; sg.B = p->rinv; sg.ldb = mp; sg.C = p->bufB; sg.ldc = mp;
+      GemmArgsT<TS> sg;  // X~ = diag(is) Q' R~^-T - diag(v) V - w t~^T   (S, U_mat and the ger of :936-938, :1204-1206)
+      sg.A = bufA; sg.lda = mp; sg.B = inv_r<TS>(p); sg.ldb = mp; sg.C = bufB; sg.ldc = mp;
       sg.M = rows_p; sg.N = mp; sg.K = mp; sg.tri = TRI_KLO_BN; sg.order = p->tile_order;
       sg.epi_rows_a = p->is + base; sg.epi_rows_b = p->v + base; sg.epi_rows_c = p->w + base;
       sg.epi_col = p->ttil; sg.epi_mat = V; sg.epi_ldm = mp;
       launch_gemm(OP_NT, sg, s);
       tstop(p);
       tstart(p, "p2_trmm_X");
-      GemmArgs xg;  // X = X~ U^-T
-      xg.A = p->bufB; xg.lda = mp; xg.B = p->uinv; xg.ldb = mp; xg.C = p->bufA; xg.ldc = mp;
+      GemmArgsT<TS> xg;  // X = X~ U^-T
+      xg.A = bufB; xg.lda = mp; xg.B = inv_u<TS>(p); xg.ldb = mp; xg.C = bufA; xg.ldc = mp;
       xg.M = rows_p; xg.N = mp; xg.K = mp; xg.tri = TRI_KLO_BN; xg.order = p->tile_order;
       launch_gemm(OP_NT, xg, s);
       tstop(p);
       tstart(p, "p2_grad");
-      GradArgs ga;
-      ga.X = p->bufA; ga.pts = p->pts() + base * p->d; ga.Z = p->Z;
+      GradArgs<TS> ga;
+      ga.X = bufA; ga.pts = p->pts() + base * p->d; ga.Z = p->Z;
       ga.rows = (int)rows; ga.rows_p = rows_p; ga.m = p->m; ga.mp = mp; ga.d = p->d;
       ga.log_sf2 = p->cp.log_sf2; ga.inv_ell2_05 = p->cp.inv_ell2_05;
       ga.colpart = p->colpart; ga.scalpart = p->scalpart;
@@ -476,13 +499,13 @@ void do_pass2(gprhip_problem* p, const double* ar1, double* ar2) {
     // G~_part = V^T diag(v) V over all rows (the two dsyrk of lib/fitc_gp.ml:1198-1203, whitened, in one)
     const int64_t ktot = p->rows_total_padded();
     tstart(p, "p2_syrk_W");
-    GemmArgs wg;
-    wg.A = p->Vstore; wg.lda = mp; wg.B = p->Vstore; wg.ldb = mp; wg.C = p->slices; wg.ldc = mp;
+    GemmArgsT<TS> wg;
+    wg.A = Vstore; wg.lda = mp; wg.B = Vstore; wg.ldb = mp; wg.C = slices; wg.ldc = mp;
     wg.M = mp; wg.N = mp; wg.K = (int)ktot; wg.beta = 0.0; wg.scale_k = p->v; wg.upper_only = 1;
     wg.kslices = p->ks_used; wg.slice_stride = mm;
     launch_gemm(OP_TN, wg, s);
     tstop(p);
-    launch_sum_slices(nullptr, p->slices, p->ks_used, mm, mp, ar2, s);
+    launch_sum_slices<TS>(nullptr, slices, p->ks_used, mm, mp, ar2, s);
   }
   p->stage = 2;
 }
@@ -639,7 +662,16 @@ int gprhip_device_count(int* count) {
 
 int gprhip_problem_create(int device, int cov_kind, int64_t n, int D, int d, int m, int64_t chunk_rows,
                           gprhip_problem** out) {
+  return gprhip_problem_create_ex(device, cov_kind, GPRHIP_F64, n, D, d, m, chunk_rows, out);
+}
+
+int gprhip_problem_create_ex(int device, int cov_kind, int precision, int64_t n, int D, int d, int m,
+                             int64_t chunk_rows, gprhip_problem** out) {
   return guarded([&] {
+    if (precision != GPRHIP_F64 && precision != GPRHIP_F32_BULK) {
+      set_error("gprhip_problem_create_ex: unknown precision");
+      throw HipFail{ST_BAD_ARG};
+    }
     if (!out || n < 1 || D < 1 || d < 1 || m < 1 ||
         (cov_kind != GPRHIP_COV_SE_ISO && cov_kind != GPRHIP_COV_SE_FAT) ||
         (cov_kind == GPRHIP_COV_SE_ISO && d != D) || d > 64) {
@@ -651,6 +683,8 @@ int gprhip_problem_create(int device, int cov_kind, int64_t n, int D, int d, int
     auto* p = new gprhip_problem();
     *out = p;
     p->device = device; p->kind = cov_kind; p->n = n; p->D = D; p->d = d; p->m = m;
+    p->f32 = (precision == GPRHIP_F32_BULK);
+    p->esz = p->f32 ? 4 : 8;
     p->mp = (int)round_up(m, TILE);
     int64_t chunk = chunk_rows > 0 ? chunk_rows : 32768;
     if (const char* e = getenv("GPRHIP_CHUNK_ROWS")) chunk = atoll(e);
@@ -690,8 +724,12 @@ int gprhip_problem_create(int device, int cov_kind, int64_t n, int D, int d, int
       p->es = p->alloc<double>(npad);
       p->projpart = p->alloc<double>(((chunk + 255) / 256) * (int64_t)D * d);
     }
-    p->bufA = p->alloc<double>(chunk * mp); p->bufB = p->alloc<double>(chunk * mp);
-    p->slices = p->alloc<double>((int64_t)p->kslices * mm);
+    p->bufA = p->alloc<char>(chunk * mp * p->esz); p->bufB = p->alloc<char>(chunk * mp * p->esz);
+    if (p->f32) {
+      p->uinv_f = p->alloc<float>(mm);
+      p->rinv_f = p->alloc<float>(mm);
+    }
+    p->slices = p->alloc<char>((int64_t)p->kslices * mm * p->esz);
     p->rowpart = p->alloc<double>((int64_t)pass1_row_blocks((int)chunk) * 4);
     p->gemvpart = p->alloc<double>(((npad + 255) / 256) * mp);
     const int64_t nslab = (chunk + grad_slab_rows() - 1) / grad_slab_rows();
@@ -791,7 +829,8 @@ int gprhip_eval_pass1(gprhip_problem* p, const gprhip_hypers* h, int want_grad, 
       set_error("gprhip_eval_pass1: NULL argument");
       throw HipFail{ST_BAD_ARG};
     }
-    do_pass1(p, h, want_grad, n_total, d_ar1);
+    if (p->f32) do_pass1<float>(p, h, want_grad, n_total, d_ar1);
+    else do_pass1<double>(p, h, want_grad, n_total, d_ar1);
   });
 }
 
@@ -805,7 +844,8 @@ int gprhip_eval_pass2(gprhip_problem* p, const double* d_ar1, double* d_ar2) {
     if (d_ar1 != p->ar1)
       GPR_HIP(hipMemcpyAsync(p->ar1, d_ar1, (size_t)gprhip_ar1_len(p) * sizeof(double),
                              hipMemcpyDeviceToDevice, p->stream));
-    do_pass2(p, p->ar1, d_ar2);
+    if (p->f32) do_pass2<float>(p, p->ar1, d_ar2);
+    else do_pass2<double>(p, p->ar1, d_ar2);
   });
 }
 
@@ -827,8 +867,13 @@ int gprhip_eval(gprhip_problem* p, const gprhip_hypers* h, int want_grad, gprhip
       set_error("gprhip_eval: NULL argument");
       throw HipFail{ST_BAD_ARG};
     }
-    do_pass1(p, h, want_grad, p->n, p->ar1);
-    do_pass2(p, p->ar1, p->ar2);
+    if (p->f32) {
+      do_pass1<float>(p, h, want_grad, p->n, p->ar1);
+      do_pass2<float>(p, p->ar1, p->ar2);
+    } else {
+      do_pass1<double>(p, h, want_grad, p->n, p->ar1);
+      do_pass2<double>(p, p->ar1, p->ar2);
+    }
     do_finish(p, p->ar2, res, grad, coeffs);
   });
 }

@@ -25,8 +25,11 @@ void launch_cov_upper(const CovParams& cp, const double* Z, int m, int mp, int d
 
 // K_nm rows [0, rows) of a chunk (lib/cov_se_iso.ml:128-159, lib/cov_se_fat.ml:224-240);
 // rows in [rows, rows_p) and columns in [m, mp) are written as 0.
+// TS = storage type of the n x m matrices (double, or float for the fp32-bulk mode: distances and
+// exp are still evaluated in fp64, only the stored value is rounded).
+template <typename TS>
 void launch_cov_cross(const CovParams& cp, const double* pts, int rows, int rows_p, const double* Z,
-                      int m, int mp, int d, double* K, hipStream_t s);
+                      int m, int mp, int d, TS* K, hipStream_t s);
 
 // Cov_se_fat.Eval.Inputs.project (lib/cov_se_fat.ml:215-218): P[n][d] = X[n][D] * tproj[D][d]
 // (tproj given as the reference's Fortran D x d matrix, i.e. element (big,small) at tproj[small*D+big]).
@@ -52,8 +55,9 @@ void launch_logdet(const double* A, int mp, int m, double* out, hipStream_t s);
 void launch_triu_matvec(const double* A, int mp, const double* x, double* y, int trans, hipStream_t s);
 
 // ---- row kernels (rowops.hip)
+template <typename TS>
 struct Pass1RowArgs {
-  const double* V;       // [rows_p][mp]
+  const TS* V;           // [rows_p][mp]
   const double* y;       // [rows] targets of this chunk (may be null: model-only)
   int rows, mp;
   double sf2, sigma2;
@@ -63,10 +67,12 @@ struct Pass1RowArgs {
   double* partial;       // out [nblocks][4]: sum log s, sum is*y^2, sum is*r, unused
 };
 int pass1_row_blocks(int rows);
-void launch_pass1_rows(const Pass1RowArgs& a, hipStream_t s);
+template <typename TS>
+void launch_pass1_rows(const Pass1RowArgs<TS>& a, hipStream_t s);
 
+template <typename TS>
 struct Pass2RowArgs {
-  const double* Q;       // [rows_p][mp]  K_chunk * Rinv
+  const TS* Q;           // [rows_p][mp]  K_chunk * Rinv
   const double* b;       // [mp]          Rinv^T c  (= Q_n^T y~ of the reference)
   const double* y;       // [rows] or null
   const double* is;      // [rows_p]
@@ -78,17 +84,20 @@ struct Pass2RowArgs {
   double* v;             // out [rows_p]  (padding 0)
   double* partial;       // out [nblocks][4]: sum v, sum is, sum w*(y-Kt) (= sum is*res^2), sum v1
 };
-void launch_pass2_rows(const Pass2RowArgs& a, hipStream_t s);
+template <typename TS>
+void launch_pass2_rows(const Pass2RowArgs<TS>& a, hipStream_t s);
 
 // partial[slab][col] = sum_{rows of slab} K[row][col] * x[row]; slab = 256 rows
-void launch_gemv_t_partial(const double* K, int rows_p, int mp, const double* x, double* partial,
+template <typename TS>
+void launch_gemv_t_partial(const TS* K, int rows_p, int mp, const double* x, double* partial,
                            hipStream_t s);
 // out[col] (+)= sum_slab partial[slab][col]
 void launch_reduce_rows(const double* partial, int nslabs, int width, double* out, int accumulate,
                         hipStream_t s);
 
+template <typename TS>
 struct GradArgs {
-  const double* X;       // [rows_p][mp]  X of lib/fitc_gp.ml:1204-1206 for this chunk
+  const TS* X;           // [rows_p][mp]  X of lib/fitc_gp.ml:1204-1206 for this chunk
   const double* pts;     // [rows][d]  inputs (iso) or projections (fat) of the chunk
   const double* Z;       // [mp][d]
   int rows, rows_p, m, mp, d;
@@ -103,12 +112,16 @@ struct GradArgs {
 void launch_proj_term2(const double* X, const double* P, const double* es, int rows, int D, int d,
                        double* part, hipStream_t s);
 int grad_slab_rows();
-void launch_grad_fused(const GradArgs& a, hipStream_t s);
+template <typename TS>
+void launch_grad_fused(const GradArgs<TS>& a, hipStream_t s);
 
 // ---- m x m finalisation (finalize.hip)
 // dst (upper tiles) = base + sum_z slices[z]
-void launch_sum_slices(const double* base, const double* slices, int nslices, int64_t stride, int mp,
+template <typename TS>
+void launch_sum_slices(const double* base, const TS* slices, int nslices, int64_t stride, int mp,
                        double* dst, hipStream_t s);
+// dst (float) = src (double), n elements: fp32 copies of U^-1 / R~^-1 for the fp32 contractions
+void launch_to_float(const double* src, float* dst, int64_t n, hipStream_t s);
 // W~ = I - B~^-1 - t~ t~^T - G~ as a full symmetric matrix (inputs valid on upper tiles);
 // the reference's W (lib/fitc_gp.ml:1196-1203) is U^-1 W~ U^-T.
 void launch_build_w(const double* binv, const double* t, const double* G, int mp, double* W,

@@ -11,24 +11,48 @@ __device__ __forceinline__ double wave_sum(double v) {
   return v;
 }
 
+// 16 bytes of a row per lane: two doubles or four floats, accumulated in fp64 either way
+template <typename TS>
+struct RowVec;
+template <>
+struct RowVec<double> {
+  static constexpr int N = 2;
+  static __device__ __forceinline__ void load(const double* p, double (&v)[2]) {
+    const double2 x = *reinterpret_cast<const double2*>(p);
+    v[0] = x.x; v[1] = x.y;
+  }
+};
+template <>
+struct RowVec<float> {
+  static constexpr int N = 4;
+  static __device__ __forceinline__ void load(const float* p, double (&v)[4]) {
+    const float4 x = *reinterpret_cast<const float4*>(p);
+    v[0] = x.x; v[1] = x.y; v[2] = x.z; v[3] = x.w;
+  }
+};
+
 constexpr int ROWS_PER_BLOCK = 16;  // 4 wavefronts x 4 rows
 
 int pass1_row_blocks(int rows_p) { return (rows_p + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK; }
 
 // r = k_diag - rowsum(V.^2)            lib/fitc_gp.ml:222-223 (Mat.syrk_diag)
 // s = r + sigma2, is = 1/s, sum log s   lib/fitc_gp.ml:155-166
-__global__ __launch_bounds__(256) void pass1_rows_kernel(Pass1RowArgs a, int rows_p) {
+template <typename TS>
+__global__ __launch_bounds__(256) void pass1_rows_kernel(Pass1RowArgs<TS> a, int rows_p) {
   __shared__ double red[4][4];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   double p_log = 0.0, p_y2 = 0.0, p_isr = 0.0;
   for (int q = 0; q < 4; ++q) {
     const int row = blockIdx.x * ROWS_PER_BLOCK + wv * 4 + q;
     if (row >= rows_p) break;
-    const double* v = a.V + (int64_t)row * a.mp;
+    const TS* v = a.V + (int64_t)row * a.mp;
     double s2 = 0.0;
-    for (int c = lane * 2; c < a.mp; c += 128) {
-      double2 x = *reinterpret_cast<const double2*>(v + c);
-      s2 += x.x * x.x + x.y * x.y;
+    constexpr int NV = RowVec<TS>::N;
+    for (int c = lane * NV; c < a.mp; c += 64 * NV) {
+      double x[NV];
+      RowVec<TS>::load(v + c, x);
+#pragma unroll
+      for (int e = 0; e < NV; ++e) s2 += x[e] * x[e];
     }
     s2 = wave_sum(s2);
     if (lane == 0) {
@@ -63,29 +87,37 @@ __global__ __launch_bounds__(256) void pass1_rows_kernel(Pass1RowArgs a, int row
   if (threadIdx.x == 3) a.partial[(int64_t)blockIdx.x * 4 + 3] = 0.0;
 }
 
-void launch_pass1_rows(const Pass1RowArgs& a, hipStream_t s) {
+template <typename TS>
+void launch_pass1_rows(const Pass1RowArgs<TS>& a, hipStream_t s) {
   const int rows_p = (int)round_up(a.rows, TILE);
-  hipLaunchKernelGGL(pass1_rows_kernel, dim3(pass1_row_blocks(rows_p)), dim3(256), 0, s, a, rows_p);
+  hipLaunchKernelGGL(pass1_rows_kernel<TS>, dim3(pass1_row_blocks(rows_p)), dim3(256), 0, s, a, rows_p);
   GPR_HIP(hipGetLastError());
 }
+template void launch_pass1_rows<double>(const Pass1RowArgs<double>&, hipStream_t);
+template void launch_pass1_rows<float>(const Pass1RowArgs<float>&, hipStream_t);
 
 // q_diag, u, w, v of lib/fitc_gp.ml:1048, :1092-1108, :1158-1181 from Q' = K R^-1 (so that
 // Q_n = diag(sqrt is) Q'):  q_diag = is*|Q'_i|^2,  u/sqrt(is) = y - Q' b  (b = Q_n^T y~),
 // w = is*(y - Q' b),  v1 = is*(1-q) [variational: is*(2 - is*r - q)],  v = v1 - w^2.
-__global__ __launch_bounds__(256) void pass2_rows_kernel(Pass2RowArgs a, int rows_p) {
+template <typename TS>
+__global__ __launch_bounds__(256) void pass2_rows_kernel(Pass2RowArgs<TS> a, int rows_p) {
   __shared__ double red[4][4];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   double p_v = 0.0, p_is = 0.0, p_res = 0.0, p_v1 = 0.0;
   for (int q = 0; q < 4; ++q) {
     const int row = blockIdx.x * ROWS_PER_BLOCK + wv * 4 + q;
     if (row >= rows_p) break;
-    const double* qr = a.Q + (int64_t)row * a.mp;
+    const TS* qr = a.Q + (int64_t)row * a.mp;
     double s2 = 0.0, sb = 0.0;
-    for (int c = lane * 2; c < a.mp; c += 128) {
-      double2 x = *reinterpret_cast<const double2*>(qr + c);
-      double2 bb = *reinterpret_cast<const double2*>(a.b + c);
-      s2 += x.x * x.x + x.y * x.y;
-      sb += x.x * bb.x + x.y * bb.y;
+    constexpr int NV = RowVec<TS>::N;
+    for (int c = lane * NV; c < a.mp; c += 64 * NV) {
+      double x[NV];
+      RowVec<TS>::load(qr + c, x);
+#pragma unroll
+      for (int e = 0; e < NV; ++e) {
+        s2 += x[e] * x[e];
+        sb += x[e] * a.b[c + e];
+      }
     }
     s2 = wave_sum(s2);
     sb = wave_sum(sb);
@@ -125,14 +157,18 @@ __global__ __launch_bounds__(256) void pass2_rows_kernel(Pass2RowArgs a, int row
   }
 }
 
-void launch_pass2_rows(const Pass2RowArgs& a, hipStream_t s) {
+template <typename TS>
+void launch_pass2_rows(const Pass2RowArgs<TS>& a, hipStream_t s) {
   const int rows_p = (int)round_up(a.rows, TILE);
-  hipLaunchKernelGGL(pass2_rows_kernel, dim3(pass1_row_blocks(rows_p)), dim3(256), 0, s, a, rows_p);
+  hipLaunchKernelGGL(pass2_rows_kernel<TS>, dim3(pass1_row_blocks(rows_p)), dim3(256), 0, s, a, rows_p);
   GPR_HIP(hipGetLastError());
 }
+template void launch_pass2_rows<double>(const Pass2RowArgs<double>&, hipStream_t);
+template void launch_pass2_rows<float>(const Pass2RowArgs<float>&, hipStream_t);
 
 // partial[slab][col] = sum_{r in slab} K[r][col] * x[r]
-__global__ __launch_bounds__(256) void gemv_t_partial_kernel(const double* __restrict__ K, int rows_p,
+template <typename TS>
+__global__ __launch_bounds__(256) void gemv_t_partial_kernel(const TS* __restrict__ K, int rows_p,
                                                              int mp, const double* __restrict__ x,
                                                              double* __restrict__ partial) {
   const int col = blockIdx.x * 256 + threadIdx.x;
@@ -140,16 +176,19 @@ __global__ __launch_bounds__(256) void gemv_t_partial_kernel(const double* __res
   const int r0 = blockIdx.y * 256;
   const int r1 = min(rows_p, r0 + 256);
   double acc = 0.0;
-  for (int r = r0; r < r1; ++r) acc += K[(int64_t)r * mp + col] * x[r];
+  for (int r = r0; r < r1; ++r) acc += (double)K[(int64_t)r * mp + col] * x[r];
   partial[(int64_t)blockIdx.y * mp + col] = acc;
 }
 
-void launch_gemv_t_partial(const double* K, int rows_p, int mp, const double* x, double* partial,
+template <typename TS>
+void launch_gemv_t_partial(const TS* K, int rows_p, int mp, const double* x, double* partial,
                            hipStream_t s) {
   dim3 grid((mp + 255) / 256, (rows_p + 255) / 256);
-  hipLaunchKernelGGL(gemv_t_partial_kernel, grid, dim3(256), 0, s, K, rows_p, mp, x, partial);
+  hipLaunchKernelGGL(gemv_t_partial_kernel<TS>, grid, dim3(256), 0, s, K, rows_p, mp, x, partial);
   GPR_HIP(hipGetLastError());
 }
+template void launch_gemv_t_partial<double>(const double*, int, int, const double*, double*, hipStream_t);
+template void launch_gemv_t_partial<float>(const float*, int, int, const double*, double*, hipStream_t);
 
 // out[col] (+)= sum_slab partial[slab][col].  A block covers COLS columns with 256/COLS slab lanes
 // per column; each lane strides over the slabs, then the lanes are combined in a fixed order.
@@ -198,8 +237,8 @@ void launch_reduce_rows(const double* partial, int nslabs, int width, double* ou
 constexpr int GRAD_SLAB = 256;
 int grad_slab_rows() { return GRAD_SLAB; }
 
-template <int DT, int DBT>
-__global__ __launch_bounds__(256) void grad_fused_kernel(GradArgs a) {
+template <int DT, int DBT, typename TS>
+__global__ __launch_bounds__(256) void grad_fused_kernel(GradArgs<TS> a) {
   __shared__ double red[4][2];
   __shared__ double xs[32][DT];                  // the 32 points being streamed, zero-padded to DT
   __shared__ double xbs[32][DBT > 0 ? DBT : 1];  // their original inputs (Cov_se_fat with tproj)
@@ -233,7 +272,7 @@ __global__ __launch_bounds__(256) void grad_fused_kernel(GradArgs a) {
     __syncthreads();
     const int nr = min(32, r1 - rb);
     for (int i = 0; i < nr; ++i) {
-      const double xv = a.X[(int64_t)(rb + i) * a.mp + jj];
+      const double xv = (double)a.X[(int64_t)(rb + i) * a.mp + jj];
       double dist = 0.0;
 #pragma unroll
       for (int k = 0; k < DT; ++k) {
@@ -298,30 +337,33 @@ void launch_proj_term2(const double* X, const double* P, const double* es, int r
   GPR_HIP(hipGetLastError());
 }
 
-template <int DT>
-static void grad_dispatch_big(const GradArgs& a, dim3 grid, hipStream_t s) {
-  if (!a.big) hipLaunchKernelGGL((grad_fused_kernel<DT, 0>), grid, dim3(256), 0, s, a);
-  else if (a.D <= 8) hipLaunchKernelGGL((grad_fused_kernel<DT, 8>), grid, dim3(256), 0, s, a);
-  else if (a.D <= 32) hipLaunchKernelGGL((grad_fused_kernel<DT, 32>), grid, dim3(256), 0, s, a);
-  else if (a.D <= 64) hipLaunchKernelGGL((grad_fused_kernel<DT, 64>), grid, dim3(256), 0, s, a);
+template <int DT, typename TS>
+static void grad_dispatch_big(const GradArgs<TS>& a, dim3 grid, hipStream_t s) {
+  if (!a.big) hipLaunchKernelGGL((grad_fused_kernel<DT, 0, TS>), grid, dim3(256), 0, s, a);
+  else if (a.D <= 8) hipLaunchKernelGGL((grad_fused_kernel<DT, 8, TS>), grid, dim3(256), 0, s, a);
+  else if (a.D <= 32) hipLaunchKernelGGL((grad_fused_kernel<DT, 32, TS>), grid, dim3(256), 0, s, a);
+  else if (a.D <= 64) hipLaunchKernelGGL((grad_fused_kernel<DT, 64, TS>), grid, dim3(256), 0, s, a);
   else {
     set_error("gprhip: Cov_se_fat input dimension D > 64 is not supported by the gradient kernel");
     throw HipFail{ST_BAD_ARG};
   }
 }
 
-void launch_grad_fused(const GradArgs& a, hipStream_t s) {
+template <typename TS>
+void launch_grad_fused(const GradArgs<TS>& a, hipStream_t s) {
   dim3 grid((a.mp + 255) / 256, (a.rows + GRAD_SLAB - 1) / GRAD_SLAB);
-  if (a.d <= 4) grad_dispatch_big<4>(a, grid, s);
-  else if (a.d <= 8) grad_dispatch_big<8>(a, grid, s);
-  else if (a.d <= 16) grad_dispatch_big<16>(a, grid, s);
-  else if (a.d <= 32) grad_dispatch_big<32>(a, grid, s);
-  else if (a.d <= 64) grad_dispatch_big<64>(a, grid, s);
+  if (a.d <= 4) grad_dispatch_big<4, TS>(a, grid, s);
+  else if (a.d <= 8) grad_dispatch_big<8, TS>(a, grid, s);
+  else if (a.d <= 16) grad_dispatch_big<16, TS>(a, grid, s);
+  else if (a.d <= 32) grad_dispatch_big<32, TS>(a, grid, s);
+  else if (a.d <= 64) grad_dispatch_big<64, TS>(a, grid, s);
   else {
     set_error("gprhip: input dimension d > 64 is not supported by the gradient kernel");
     throw HipFail{ST_BAD_ARG};
   }
   GPR_HIP(hipGetLastError());
 }
+template void launch_grad_fused<double>(const GradArgs<double>&, hipStream_t);
+template void launch_grad_fused<float>(const GradArgs<float>&, hipStream_t);
 
 }  // namespace gprhip

@@ -13,7 +13,7 @@ from typing import Optional
 import numpy as np
 
 from . import _lib
-from ._lib import COV_SE_FAT, COV_SE_ISO, Hypers, Result
+from ._lib import COV_SE_FAT, COV_SE_ISO, F32_BULK, F64, Hypers, Result
 
 CHOLESKY_JITTER = 1e-6  # Utils.cholesky_jitter, lib/utils.ml:35
 
@@ -33,13 +33,14 @@ def _f64_ptr(a):
 
 
 class Problem:
-    def __init__(self, cov_kind, n, D, d, m, device=0, chunk_rows=0):
+    def __init__(self, cov_kind, n, D, d, m, device=0, chunk_rows=0, precision=F64):
+        """precision: F64 (reference parity) or F32_BULK (n x m contractions in fp32, m x m work in fp64)."""
         self._lib = _lib.load()
         self._h = C.c_void_p()
         self.cov_kind, self.n, self.D, self.d, self.m = cov_kind, int(n), int(D), int(d), int(m)
-        self.device = device
-        _lib.check(self._lib.gprhip_problem_create(device, cov_kind, self.n, self.D, self.d, self.m,
-                                                   int(chunk_rows), C.byref(self._h)))
+        self.device, self.precision = device, precision
+        _lib.check(self._lib.gprhip_problem_create_ex(device, cov_kind, int(precision), self.n, self.D, self.d,
+                                                      self.m, int(chunk_rows), C.byref(self._h)))
 
     def close(self):
         if self._h:

@@ -39,6 +39,14 @@ enum {
 
 enum { GPRHIP_COV_SE_ISO = 0, GPRHIP_COV_SE_FAT = 1 }; /* lib/cov_se_iso.ml, lib/cov_se_fat.ml */
 
+/* Arithmetic of the n x m contractions.  The reference is fp64 only (Lacaml.D, lib/fitc_gp.ml:23).
+ *   GPRHIP_F64      : everything fp64 (reference parity).
+ *   GPRHIP_F32_BULK : K_nm and every n x m intermediate stored in fp32, n x m x m contractions on the
+ *                     fp32 MFMA with split-K partial sums combined in fp64; covariance evaluation,
+ *                     row reductions, and all m x m factorisations/solves stay fp64 (BASELINE.json
+ *                     config 3).  Agreement with the fp64 reference is ~1e-5 relative. */
+enum { GPRHIP_F64 = 0, GPRHIP_F32_BULK = 1 };
+
 typedef struct gprhip_problem gprhip_problem;
 
 /* Number of visible HIP devices (does not initialise a device). */
@@ -51,6 +59,8 @@ int gprhip_device_count(int* count);
  * Replaces: the Bigarray allocations spread over Eval_inputs / Eval_model (lib/fitc_gp.ml:105-229). */
 int gprhip_problem_create(int device, int cov_kind, int64_t n, int D, int d, int m, int64_t chunk_rows,
                           gprhip_problem** out);
+int gprhip_problem_create_ex(int device, int cov_kind, int precision, int64_t n, int D, int d, int m,
+                             int64_t chunk_rows, gprhip_problem** out);
 void gprhip_problem_destroy(gprhip_problem* p);
 
 /* Training inputs (Fortran D x n, leading dimension ld >= D) and targets (n): copied to the device.

@@ -153,6 +153,58 @@ def test_odd_block_counts_of_the_triangular_inverse(m):
     p.close()
 
 
+# fp32-bulk mode (BASELINE.json config 3): the reference is fp64 only, so parity is "fp32 build vs
+# fp64 oracle" within these stated tolerances (n x m data and contractions in fp32; everything
+# m x m, the covariance evaluation and every accumulation across training points in fp64)
+TOL32_L = 1e-4
+TOL32_DS2 = 1e-3
+TOL32_GRAD = 5e-3
+TOL32_COEFF = 5e-3
+
+
+@pytest.mark.parametrize("case", [(1, 2000, 50, 3, 0.1), (4, 5000, 300, 8, 0.1), (6, 20000, 512, 16, 0.1),
+                                  (7, 8000, 256, 8, 1e-3)])
+def test_fp32_bulk_iso_against_fp64_oracle(case):
+    seed, n, m, d, s2 = case
+    X, y, Z = synth(seed, n, m, d)
+    le = 0.5 * np.log(d)
+    ref = O.evaluate_fast(O.SeIsoKernel(le, 0.0), Z, X, y, s2)
+    p = gpr_amd.Problem(gpr_amd.COV_SE_ISO, n, d, d, m, precision=gpr_amd.F32_BULK)
+    p.set_inputs(X)
+    p.set_targets(y)
+    ev = p.eval(log_ell=le, log_sf2=0.0, sigma2=s2, inducing=Z)
+    assert abs(ev.l - ref["l"]) <= TOL32_L * abs(ref["l"])
+    assert abs(ev.dl_dsigma2 - ref["dl_dsigma2"]) <= TOL32_DS2 * abs(ref["dl_dsigma2"])
+    assert relinf(ev.grad, ref["grad"]) <= TOL32_GRAD
+    assert relinf(ev.coeffs, ref["coeffs"]) <= TOL32_COEFF
+    ev0 = p.eval(log_ell=le, log_sf2=0.0, sigma2=s2, inducing=Z, want_grad=False)
+    assert ev0.l == ev.l
+    p.close()
+
+
+def test_fp32_bulk_fat_ard_config3_shape():
+    """BASELINE.json config 3 in miniature: Cov_se_fat with tproj = diag(1/ell_i) (ARD), d = D = 32,
+    fp32 bulk, against the fp64 oracle; gradient includes all D*d Proj entries."""
+    rng = np.random.default_rng(3)
+    n, m, d = 6000, 256, 32
+    X = np.asfortranarray(rng.normal(size=(d, n)))
+    y = np.sin(X.sum(0)) + 0.1 * rng.normal(size=n)
+    ell = rng.uniform(-0.5, 0.5, size=d)
+    P = np.asfortranarray(np.diag(np.exp(-ell)) / np.sqrt(d))
+    k = O.SeFatKernel(d, 0.0, P)
+    Z = np.asfortranarray(O.se_fat_project(k, X[:, rng.permutation(n)[:m]]) + 0.01 * rng.normal(size=(d, m)))
+    ref = O.evaluate_fast(k, Z, X, y, 0.1)
+    for prec, tl, tg in ((gpr_amd.F64, TOL_L, TOL_GRAD), (gpr_amd.F32_BULK, TOL32_L, TOL32_GRAD)):
+        p = gpr_amd.Problem(gpr_amd.COV_SE_FAT, n, d, d, m, precision=prec)
+        p.set_inputs(X)
+        p.set_targets(y)
+        ev = p.eval(log_sf2=0.0, sigma2=0.1, inducing=Z, tproj=P)
+        assert ev.grad.shape == ref["grad"].shape == (1 + d * m + d * d,)
+        assert abs(ev.l - ref["l"]) <= tl * abs(ref["l"])
+        assert relinf(ev.grad, ref["grad"]) <= tg
+        p.close()
+
+
 def test_functor_mirror_and_reference_self_test_recipe():
     """test/test_derivatives.ml's recipe through the mirrored module surface: finite differences at
     the reference's eps=1e-8 / tol=1e-2 for sigma2 and every hyper (n=10, m=5, D=3)."""
