@@ -73,6 +73,7 @@ SIGNATURES = {
     "gprhip_eval_finish": (C.c_int, [_vp, _vp, C.POINTER(Result), _dp, _dp]),
     "gprhip_sync": (C.c_int, [_vp]),
     "gprhip_stream": (_vp, [_vp]),
+    "gprhip_predict": (C.c_int, [_vp, _dp, C.c_int64, C.c_int64, C.c_int, _dp, _dp]),
     "gprhip_debug_fetch": (C.c_int, [_vp, C.c_char_p, _dp, C.c_int64]),
     "gprhip_last_timings": (C.c_int, [_vp, C.POINTER(C.c_char_p), C.POINTER(C.c_float), C.c_int]),
     "gprhip_last_error": (C.c_char_p, []),

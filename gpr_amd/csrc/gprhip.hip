@@ -94,6 +94,8 @@ struct gprhip_problem {
   int* info = nullptr;
   double *r = nullptr, *is = nullptr, *yis = nullptr, *w = nullptr, *v = nullptr, *es = nullptr;
   double* projpart = nullptr;
+  double *xt = nullptr, *pt = nullptr, *prow = nullptr;  // prediction: test-point chunk, its projection, 3 row vectors
+  bool have_model = false;
   // n x m storage: double, or float in the fp32-bulk mode (element size `esz`)
   void *bufA = nullptr, *bufB = nullptr, *Vstore = nullptr;
   float *uinv_f = nullptr, *rinv_f = nullptr;  // fp32 copies of U^-1 / R~^-1 (fp32-bulk mode)
@@ -556,6 +558,7 @@ void do_finish(gprhip_problem* p, const double* ar2, gprhip_result* res, double*
                          hipMemcpyDeviceToHost, s));
   GPR_HIP(hipStreamSynchronize(s));
   p->stage = 0;
+  p->have_model = true;
   if (p->timer.on) tcollect(p);
   if (hinfo[0] != 0 || hinfo[1] != 0) {
     char buf[160];
@@ -626,6 +629,64 @@ void do_finish(gprhip_problem* p, const double* ar2, gprhip_result* res, double*
     }
   }
   res->n_hypers = pos;
+}
+
+// Means.calc / Variances.calc (lib/fitc_gp.ml:418-425, :498-518) at nt test points, chunk by chunk,
+// with the m x m state of the last evaluation: V_t = K_tm U^-1, Q_t = V_t R~^-1 (= K_tm R^-1).
+template <typename TS>
+void do_predict(gprhip_problem* p, const double* test_inputs, int64_t ld, int64_t nt, int predictive,
+                double* means, double* variances) {
+  if (!p->have_model || p->stage != 0) {
+    set_error("gprhip_predict: no completed evaluation to predict from");
+    throw HipFail{ST_STATE};
+  }
+  GPR_HIP(hipSetDevice(p->device));
+  hipStream_t s = p->stream;
+  const int mp = p->mp;
+  const int64_t chunk = p->chunk;
+  if (!p->xt) {
+    p->xt = p->alloc<double>(chunk * p->D);
+    p->pt = p->alloc<double>(chunk * p->d);
+    p->prow = p->alloc<double>(3 * chunk);
+  }
+  TS* const bufA = static_cast<TS*>(p->bufA);
+  TS* const bufB = static_cast<TS*>(p->bufB);
+  double* rmean = p->prow;
+  double* rk = p->prow + chunk;
+  double* rb = p->prow + 2 * chunk;
+  const bool proj = p->has_proj();
+  for (int64_t lo = 0; lo < nt; lo += chunk) {
+    const int rows = (int)std::min<int64_t>(chunk, nt - lo);
+    const int rows_p = (int)round_up(rows, TILE);
+    GPR_HIP(hipMemcpy2DAsync(p->xt, (size_t)p->D * sizeof(double), test_inputs + lo * ld,
+                             (size_t)ld * sizeof(double), (size_t)p->D * sizeof(double), (size_t)rows,
+                             hipMemcpyHostToDevice, s));
+    const double* pts = p->xt;
+    if (proj) {
+      launch_project(p->xt, rows, p->D, p->d, p->tproj, p->pt, s);
+      pts = p->pt;
+    }
+    launch_cov_cross<TS>(p->cp, pts, rows, rows_p, p->Z, p->m, mp, p->d, bufA, s);
+    if (means) {
+      launch_row_sumsq_dot<TS>(bufA, p->tvec, rows, mp, nullptr, rmean, s);
+      GPR_HIP(hipMemcpyAsync(means + lo, rmean, (size_t)rows * sizeof(double), hipMemcpyDeviceToHost, s));
+    }
+    if (variances) {
+      GemmArgsT<TS> g;  // trsm ~side:`R chol_km
+      g.A = bufA; g.lda = mp; g.B = inv_u<TS>(p); g.ldb = mp; g.C = bufB; g.ldc = mp;
+      g.M = rows_p; g.N = mp; g.K = mp; g.tri = TRI_KHI_BN;
+      launch_gemm(OP_NN, g, s);
+      launch_row_sumsq_dot<TS>(bufB, nullptr, rows, mp, rk, nullptr, s);
+      GemmArgsT<TS> q;  // trsm ~side:`R r_mat  (R = R~ U)
+      q.A = bufB; q.lda = mp; q.B = inv_r<TS>(p); q.ldb = mp; q.C = bufA; q.ldc = mp;
+      q.M = rows_p; q.N = mp; q.K = mp; q.tri = TRI_KHI_BN;
+      launch_gemm(OP_NN, q, s);
+      launch_row_sumsq_dot<TS>(bufA, nullptr, rows, mp, rb, nullptr, s);
+      launch_variance_combine(rk, rb, rows, p->cp.sf2, predictive ? p->h.sigma2 : 0.0, rk, s);
+      GPR_HIP(hipMemcpyAsync(variances + lo, rk, (size_t)rows * sizeof(double), hipMemcpyDeviceToHost, s));
+    }
+    GPR_HIP(hipStreamSynchronize(s));  // xt / row buffers are reused by the next chunk
+  }
 }
 
 template <typename F>
@@ -875,6 +936,18 @@ int gprhip_eval(gprhip_problem* p, const gprhip_hypers* h, int want_grad, gprhip
       do_pass2<double>(p, p->ar1, p->ar2);
     }
     do_finish(p, p->ar2, res, grad, coeffs);
+  });
+}
+
+int gprhip_predict(gprhip_problem* p, const double* test_inputs, int64_t ld, int64_t nt, int predictive,
+                   double* means, double* variances) {
+  return guarded([&] {
+    if (!p || !test_inputs || nt < 1 || ld < p->D) {
+      set_error("gprhip_predict: invalid arguments");
+      throw HipFail{ST_BAD_ARG};
+    }
+    if (p->f32) do_predict<float>(p, test_inputs, ld, nt, predictive, means, variances);
+    else do_predict<double>(p, test_inputs, ld, nt, predictive, means, variances);
   });
 }
 

@@ -87,6 +87,15 @@ struct Pass2RowArgs {
 template <typename TS>
 void launch_pass2_rows(const Pass2RowArgs<TS>& a, hipStream_t s);
 
+// Per row of M [rows_p][mp]: sumsq[row] = sum_c M^2, dot[row] = sum_c M*b (either output may be null).
+// Prediction path: Means.calc / Variances.calc (lib/fitc_gp.ml:418-425, :498-518).
+template <typename TS>
+void launch_row_sumsq_dot(const TS* M, const double* b, int rows, int mp, double* sumsq, double* dot,
+                          hipStream_t s);
+// var[r] = sf2 - k[r] + b[r] (+ sigma2 if predictive)   lib/fitc_gp.ml:509-517, :520-526
+void launch_variance_combine(const double* k, const double* b, int rows, double sf2, double add,
+                             double* var, hipStream_t s);
+
 // partial[slab][col] = sum_{rows of slab} K[row][col] * x[row]; slab = 256 rows
 template <typename TS>
 void launch_gemv_t_partial(const TS* K, int rows_p, int mp, const double* x, double* partial,

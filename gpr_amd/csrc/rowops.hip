@@ -166,6 +166,57 @@ void launch_pass2_rows(const Pass2RowArgs<TS>& a, hipStream_t s) {
 template void launch_pass2_rows<double>(const Pass2RowArgs<double>&, hipStream_t);
 template void launch_pass2_rows<float>(const Pass2RowArgs<float>&, hipStream_t);
 
+template <typename TS>
+__global__ __launch_bounds__(256) void row_sumsq_dot_kernel(const TS* __restrict__ M,
+                                                            const double* __restrict__ b, int rows, int mp,
+                                                            double* __restrict__ sumsq,
+                                                            double* __restrict__ dot) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int row = blockIdx.x * 4 + wv;
+  if (row >= rows) return;
+  const TS* mr = M + (int64_t)row * mp;
+  constexpr int NV = RowVec<TS>::N;
+  double s2 = 0.0, sb = 0.0;
+  for (int c = lane * NV; c < mp; c += 64 * NV) {
+    double x[NV];
+    RowVec<TS>::load(mr + c, x);
+#pragma unroll
+    for (int e = 0; e < NV; ++e) {
+      s2 += x[e] * x[e];
+      if (b) sb += x[e] * b[c + e];
+    }
+  }
+  s2 = wave_sum(s2);
+  sb = wave_sum(sb);
+  if (lane == 0) {
+    if (sumsq) sumsq[row] = s2;
+    if (dot) dot[row] = sb;
+  }
+}
+
+template <typename TS>
+void launch_row_sumsq_dot(const TS* M, const double* b, int rows, int mp, double* sumsq, double* dot,
+                          hipStream_t s) {
+  hipLaunchKernelGGL(row_sumsq_dot_kernel<TS>, dim3((rows + 3) / 4), dim3(256), 0, s, M, b, rows, mp, sumsq,
+                     dot);
+  GPR_HIP(hipGetLastError());
+}
+template void launch_row_sumsq_dot<double>(const double*, const double*, int, int, double*, double*, hipStream_t);
+template void launch_row_sumsq_dot<float>(const float*, const double*, int, int, double*, double*, hipStream_t);
+
+__global__ void variance_combine_kernel(const double* __restrict__ k, const double* __restrict__ b, int rows,
+                                        double sf2, double add, double* __restrict__ var) {
+  const int r = blockIdx.x * 256 + threadIdx.x;
+  if (r < rows) var[r] = (sf2 - (k[r] - b[r])) + add;  // prior_variance -. (k -. b), lib/fitc_gp.ml:475
+}
+
+void launch_variance_combine(const double* k, const double* b, int rows, double sf2, double add,
+                             double* var, hipStream_t s) {
+  hipLaunchKernelGGL(variance_combine_kernel, dim3((rows + 255) / 256), dim3(256), 0, s, k, b, rows, sf2, add,
+                     var);
+  GPR_HIP(hipGetLastError());
+}
+
 // partial[slab][col] = sum_{r in slab} K[r][col] * x[r]
 template <typename TS>
 __global__ __launch_bounds__(256) void gemv_t_partial_kernel(const TS* __restrict__ K, int rows_p,

@@ -18,8 +18,8 @@ stage by stage; the device path is a two-pass streaming evaluation, so these obj
 the whole evaluation runs when the first number (log evidence, gradient entry) is requested.
 Only scalars, m-vectors and the gradient ever cross back to the host.
 
-Not on this path: prediction, sampling, stats, the GSL/SGD/SMD optimisers,
-FIC covariances.  `FIC` / `Variational_FIC` are provided as aliases because their *evidence* is
+Beyond the hot path, posterior means and variances at new inputs are provided (SURVEY.md 8(f) rank 1:
+`Eval.Means`, `Eval.Variances`).  Not provided: sampling, stats, the GSL/SGD/SMD optimisers, FIC covariances.  `FIC` / `Variational_FIC` are provided as aliases because their *evidence* is
 the FITC one (they differ only in predictive covariances, lib/fitc_gp.ml:565-624).
 """
 from __future__ import annotations
@@ -38,10 +38,20 @@ class _Inducing:
 
 
 class _Inputs:
-    def __init__(self, inducing, points, problem):
+    """Eval/Deriv Inputs.t: binds points to an inducing set; the device copy is made on first use
+    (training inputs) and never for points that are only predicted at."""
+
+    def __init__(self, inducing, points, make_problem):
         self.inducing = inducing
         self.points = points
-        self.problem = problem
+        self._make_problem = make_problem
+        self._problem = None
+
+    @property
+    def problem(self):
+        if self._problem is None:
+            self._problem = self._make_problem()
+        return self._problem
 
 
 class _Model:
@@ -105,17 +115,22 @@ def _make_variant(spec, variational, functor):
             raise ValueError("Inputs.calc: inducing points have dimension %d, kernel space has %d"
                              % (inducing.points.shape[0], d))
         key = (id(points), points.shape, m, d, device)
-        prob = functor._problems.get(key)
-        if prob is None:
-            D, n = points.shape
-            prob = Problem(spec.COV_KIND, n, D, d, m, device=device, chunk_rows=chunk_rows)
-            prob.set_inputs(points)
-            prob._spec, prob._jitter = spec, functor.jitter
-            prob._points_ref = points  # keep the id() stable
-            if len(functor._problems) >= 4:  # resident copies are large; keep a handful
-                functor._problems.pop(next(iter(functor._problems))).close()
-            functor._problems[key] = prob
-        return _Inputs(inducing, points, prob)
+
+        def make_problem():
+            prob = functor._problems.get(key)
+            if prob is None:
+                D, n = points.shape
+                prob = Problem(spec.COV_KIND, n, D, d, m, device=device, chunk_rows=chunk_rows,
+                               precision=functor.precision)
+                prob.set_inputs(points)
+                prob._spec, prob._jitter = spec, functor.jitter
+                prob._points_ref = points  # keep the id() stable
+                if len(functor._problems) >= 4:  # resident copies are large; keep a handful
+                    functor._problems.pop(next(iter(functor._problems))).close()
+                functor._problems[key] = prob
+            return prob
+
+        return _Inputs(inducing, points, make_problem)
 
     def model_calc(inputs, sigma2):
         return _Model(inputs, sigma2, variational)
@@ -144,6 +159,38 @@ def _make_variant(spec, variational, functor):
             calc_mean_coeffs=lambda trained: trained.evaluation().coeffs,  # :294
             get_model=lambda trained: trained.model, get_targets=lambda trained: trained.targets),
     )
+
+    # ---- prediction (lib/fitc_gp.ml:377-531): means and variances at new inputs, on the device that
+    # holds the trained model's state
+    def _predict(model_or_trained, inputs, predictive, want_variances):
+        owner = model_or_trained
+        if inputs.inducing.points is not _model_of(owner).inputs.inducing.points:
+            # phys_equal check of the reference, lib/fitc_gp.ml:419-424, :499-506
+            raise ValueError("Means.calc: trained and inputs disagree about inducing points")
+        owner.evaluation() if isinstance(owner, _Trained) else owner.evaluation(False)
+        return _model_of(owner).inputs.problem.predict(inputs.points, predictive=predictive,
+                                                       want_variances=want_variances)
+
+    def _model_of(obj):
+        return obj.model if isinstance(obj, _Trained) else obj
+
+    Eval.Mean_predictor = SimpleNamespace(calc_trained=lambda trained: trained)            # :380-384
+    Eval.Means = SimpleNamespace(
+        calc=lambda mean_predictor, inputs: _predict(mean_predictor, inputs, False, False)[0],  # :418-425
+        get=lambda means: means)
+    Eval.Co_variance_predictor = SimpleNamespace(calc_model=lambda model: model)             # :438-444
+
+    class _Variances:
+        def __init__(self, variances, sigma2):
+            self.variances, self.sigma2 = variances, sigma2
+
+    def variances_calc(cvp, sigma2, inputs):
+        # the state (chol_km, r_mat) comes from an evaluation of `cvp` (a model or a trained model)
+        return _Variances(_predict(cvp, inputs, False, True)[1], sigma2)
+
+    Eval.Variances = SimpleNamespace(
+        calc=variances_calc,                                                                   # :498-518
+        get=lambda v, predictive=True: v.variances + v.sigma2 if predictive else v.variances)  # :520-529
 
     def prepare_hyper_model(model):
         return _HyperT(model.evaluation(True), model.inputs.inducing.kernel, model.inputs.inducing.points, spec)
@@ -213,9 +260,10 @@ def _make_variant(spec, variational, functor):
 class Make_deriv:
     """Fitc_gp.Make_deriv (lib/fitc_gp.mli:120-135).  `spec` is gpr_amd.cov_se_iso or gpr_amd.cov_se_fat."""
 
-    def __init__(self, spec, jitter=CHOLESKY_JITTER):
+    def __init__(self, spec, jitter=CHOLESKY_JITTER, precision=0):
         self.spec = spec
         self.jitter = jitter  # read once at functor application, like lib/fitc_gp.ml:33
+        self.precision = precision  # gpr_amd.F64 (reference parity) or gpr_amd.F32_BULK
         self._problems = {}
         self.FITC = _make_variant(spec, False, self)
         self.Variational_FITC = _make_variant(spec, True, self)

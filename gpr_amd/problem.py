@@ -109,6 +109,20 @@ class Problem:
         return Evaluation(res.l1, res.l2, res.l, res.dl_dsigma2 if want_grad else None,
                           grad[:res.n_hypers] if want_grad else None, coeffs)
 
+    # ---- prediction
+    def predict(self, test_inputs, predictive=True, want_variances=True):
+        """Means.calc / Variances.calc (lib/fitc_gp.ml:418-425, :498-518) at test points (D x nt), using
+        the model state of the last evaluation.  Returns (means, variances or None)."""
+        xt = np.asfortranarray(test_inputs, dtype=np.float64)
+        if xt.ndim != 2 or xt.shape[0] != self.D:
+            raise ValueError("predict: expected test inputs of shape (%d, nt)" % self.D)
+        nt = xt.shape[1]
+        means = np.empty(nt, dtype=np.float64)
+        var = np.empty(nt, dtype=np.float64) if want_variances else None
+        _lib.check(self._lib.gprhip_predict(self._h, _f64_ptr(xt), self.D, nt, int(predictive), _f64_ptr(means),
+                                            _f64_ptr(var) if want_variances else None))
+        return means, var
+
     # ---- staged evaluation (row-sharded across devices; see gpr_amd/dist.py)
     def ar1_len(self):
         return int(self._lib.gprhip_ar1_len(self._h))

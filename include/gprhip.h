@@ -133,6 +133,16 @@ int gprhip_sync(gprhip_problem* p);
 /* The HIP stream (hipStream_t) the problem enqueues on, for callers that order other work after it. */
 void* gprhip_stream(gprhip_problem* p);
 
+/* Posterior prediction at test points with the model state left by the last evaluation on `p`
+ * (kernel, inducing points, U = chol_km, R = r_mat, mean coefficients):
+ *   means[i]     = K_tm[i,:] . coeffs                          Means.calc     lib/fitc_gp.ml:418-425
+ *   variances[i] = k_ii - |K_tm U^-1|_i^2 + |K_tm R^-1|_i^2    Variances.calc lib/fitc_gp.ml:498-518
+ *                  (+ sigma2 when predictive != 0: Variances.get ?predictive, :520-529)
+ * test_inputs: Fortran D x nt (ld >= D), host.  means / variances: nt doubles, host; either may be NULL.
+ * The last evaluation must have had targets (model_only = 0) for the means to be meaningful. */
+int gprhip_predict(gprhip_problem* p, const double* test_inputs, int64_t ld, int64_t nt, int predictive,
+                   double* means, double* variances);
+
 /* Intermediates of the last evaluation, for parity tests (copied to host; sizes in doubles):
  *   "r" n, "is" n, "v" n, "w" n, "t" m.  Returns GPRHIP_EBADARG for an unknown name. */
 int gprhip_debug_fetch(gprhip_problem* p, const char* name, double* out, int64_t len);

@@ -528,6 +528,27 @@ def shared_calc_log_evidence(hyper_t, shared, hyper):
 
 
 # ---------------------------------------------------------------------------
+# Prediction
+# ---------------------------------------------------------------------------
+def predict_means(k, inducing_points, coeffs, test_inputs):
+    """Means.calc lib/fitc_gp.ml:418-425: gemv knm coeffs with knm = calc_cross at the test points."""
+    ktm, _ = spec_calc_shared_cross(k, test_inputs, inducing_points)
+    return ktm @ coeffs
+
+
+def predict_variances(k, inducing_points, model, test_inputs, predictive=True):
+    """Variances.calc lib/fitc_gp.ml:498-518 (+ get ?predictive :520-529): two dtrsm `R and two
+    Mat.syrk_diag on the test cross-covariance."""
+    ktm, _ = spec_calc_shared_cross(k, test_inputs, inducing_points)
+    y = spec_calc_diag(k, ktm.shape[0])
+    tmp = _F(blas.dtrsm(1.0, model["inducing"]["chol_km"], ktm, side=1, lower=0, trans_a=0))
+    y = y - np.einsum("ij,ij->i", tmp, tmp)
+    tmp = _F(blas.dtrsm(1.0, model["r_mat"], ktm, side=1, lower=0, trans_a=0))
+    var = y + np.einsum("ij,ij->i", tmp, tmp)
+    return var + model["sigma2"] if predictive else var
+
+
+# ---------------------------------------------------------------------------
 # One full evaluation, the reference way (multim_dcommon lib/fitc_gp.ml:1612-1636)
 # ---------------------------------------------------------------------------
 def evaluate(k, inducing_points, inputs, targets, sigma2, variational=False,

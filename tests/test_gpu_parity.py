@@ -205,6 +205,45 @@ def test_fp32_bulk_fat_ard_config3_shape():
         p.close()
 
 
+def test_prediction_means_and_variances():
+    """Means.calc / Variances.calc (lib/fitc_gp.ml:418-425, :498-518) on the device
+    against the oracle, directly and through the mirrored module surface; test set larger than a chunk."""
+    n, m, d, nt = 4000, 150, 3, 1300
+    X, y, Z = synth(21, n, m, d)
+    rng = np.random.default_rng(5)
+    Xt = np.asfortranarray(rng.normal(size=(d, nt)))
+    k = O.SeIsoKernel(0.4, 0.2)
+    ref = O.evaluate(k, Z, X, y, 0.15, want_grad=False, keep=True)
+    mean_ref = O.predict_means(k, Z, ref["coeffs"], Xt)
+    var_ref = O.predict_variances(k, Z, ref["model"], Xt, predictive=False)
+    p = gpr_amd.Problem(gpr_amd.COV_SE_ISO, n, d, d, m, chunk_rows=512)
+    p.set_inputs(X)
+    p.set_targets(y)
+    p.eval(log_ell=0.4, log_sf2=0.2, sigma2=0.15, inducing=Z, want_grad=False)
+    mean, var = p.predict(Xt, predictive=False)
+    assert relinf(mean, mean_ref) <= 1e-8
+    assert np.max(np.abs(var - var_ref)) <= 1e-8 * np.max(np.abs(var_ref))
+    _, varp = p.predict(Xt, predictive=True)
+    assert np.allclose(varp, var + 0.15, rtol=0, atol=1e-12)
+    p.close()
+    GP = fitc_gp.Make_deriv(cov_se_iso)
+    F = GP.FITC
+    kernel = cov_se_iso.Kernel.create(cov_se_iso.Params(0.4, 0.2))
+    inducing = F.Eval.Inducing.calc(kernel, Z)
+    model = F.Eval.Model.calc(F.Eval.Inputs.calc(X, inducing), sigma2=0.15)
+    trained = F.Eval.Trained.calc(model, targets=y)
+    test_inputs = F.Eval.Inputs.calc(Xt, inducing)
+    means = F.Eval.Means.get(F.Eval.Means.calc(F.Eval.Mean_predictor.calc_trained(trained), test_inputs))
+    variances = F.Eval.Variances.calc(F.Eval.Co_variance_predictor.calc_model(model), 0.15, test_inputs)
+    assert relinf(means, mean_ref) <= 1e-8
+    assert relinf(F.Eval.Variances.get(variances, predictive=False), var_ref) <= 1e-8
+    assert relinf(F.Eval.Variances.get(variances), var_ref + 0.15) <= 1e-8
+    other = F.Eval.Inputs.calc(Xt, F.Eval.Inducing.calc(kernel, Z.copy()))
+    with pytest.raises(ValueError, match="disagree about inducing points"):   # lib/fitc_gp.ml:419-424
+        F.Eval.Means.calc(trained, other)
+    GP.close()
+
+
 def test_functor_mirror_and_reference_self_test_recipe():
     """test/test_derivatives.ml's recipe through the mirrored module surface: finite differences at
     the reference's eps=1e-8 / tol=1e-2 for sigma2 and every hyper (n=10, m=5, D=3)."""

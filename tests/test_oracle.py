@@ -176,6 +176,29 @@ def test_golden_fixtures_reproduce(name):
     assert relinf(fast["grad"], g["grad"]) < 1e-9
 
 
+def test_prediction_against_dense_fitc_posterior():
+    """Means/Variances (lib/fitc_gp.ml:418-425, :498-518) against the textbook FITC predictive equations
+    mean = k*^T B^-1 K_mn S^-1 y,  var = k** - k*^T (K_m^-1 - B^-1) k*."""
+    X, y, Z = synth(13, 150, 9, 2)
+    k = O.SeIsoKernel(0.3, 0.1)
+    out = O.evaluate(k, Z, X, y, 0.2, want_grad=False, keep=True)
+    rng = np.random.default_rng(0)
+    Xt = np.asfortranarray(rng.normal(size=(2, 17)))
+    mean = O.predict_means(k, Z, out["coeffs"], Xt)
+    var = O.predict_variances(k, Z, out["model"], Xt, predictive=False)
+    km, _ = O.spec_calc_shared_upper(k, Z)
+    km = np.triu(km) + np.triu(km, 1).T + O.CHOLESKY_JITTER * np.eye(9)
+    knm, _ = O.spec_calc_shared_cross(k, X, Z)
+    ktm, _ = O.spec_calc_shared_cross(k, Xt, Z)
+    s = k.sf2 - np.einsum("ij,ji->i", knm, np.linalg.solve(km, knm.T)) + 0.2
+    B = km + (knm / s[:, None]).T @ knm
+    mean_ref = ktm @ np.linalg.solve(B, knm.T @ (y / s))
+    var_ref = k.sf2 - np.einsum("ij,ji->i", ktm, (np.linalg.inv(km) - np.linalg.inv(B)) @ ktm.T)
+    assert np.max(np.abs(mean - mean_ref)) < 1e-9 * np.max(np.abs(mean_ref))
+    assert np.max(np.abs(var - var_ref)) < 1e-7
+    assert np.allclose(O.predict_variances(k, Z, out["model"], Xt), var + 0.2)
+
+
 def test_hyper_order():
     assert O.se_iso_hypers(2, 2) == [("log_ell",), ("log_sf2",), ("inducing", 1, 1), ("inducing", 1, 2),
                                      ("inducing", 2, 1), ("inducing", 2, 2)]      # lib/cov_se_iso.ml:188-202
