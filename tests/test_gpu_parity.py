@@ -244,6 +244,48 @@ def test_prediction_means_and_variances():
     GP.close()
 
 
+def test_save_data_recipe_training_improves_evidence_and_fits_noise():
+    """test/save_data.ml + test/gen_data.ml:23-44 recipe: 1-D f(x) = sin(3x)/x + |x-3|/(x^2+1), noise
+    sigma 0.7, n=1000, m=10, Cov_se_iso FITC; evidence maximisation must raise the log evidence and the
+    fit's RMSE against the noisy targets must sit near the noise level."""
+    from gpr_amd import optim
+    g = load_golden("iso_gen_data")
+    X, y, Z = g["X"], g["y"], g["Z"]
+    GP = fitc_gp.Make_deriv(cov_se_iso)
+    kernel = cov_se_iso.Kernel.create(cov_se_iso.create_default_kernel_params())
+    F = GP.FITC
+    ind0 = F.Deriv.Inducing.calc(kernel, Z)
+    tr0 = F.Eval.Trained.calc(F.Eval.Model.calc(F.Eval.Inputs.calc(X, ind0), sigma2=float(y @ y) / 1000), y)
+    le0 = F.Eval.Trained.calc_log_evidence(tr0)
+    k1, z1, s2, le1, nev = optim.train(F, cov_se_iso, kernel, Z, X, y, max_iter=60)
+    assert le1 > le0 + 50.0
+    assert 0.3 < s2 < 0.8                      # true noise variance 0.49
+    ind1 = F.Eval.Inducing.calc(k1, z1)
+    trained = F.Eval.Trained.calc(F.Eval.Model.calc(F.Eval.Inputs.calc(X, ind1), sigma2=s2), y)
+    means = F.Eval.Means.calc(trained, F.Eval.Inputs.calc(X, ind1))
+    rmse = float(np.sqrt(np.mean((means - y) ** 2)))
+    assert 0.55 < rmse < 0.85                  # noise sigma 0.7
+    GP.close()
+
+
+@pytest.mark.parametrize("n,m,d", [(1, 1, 1), (3, 3, 2), (2, 5, 3), (129, 128, 4), (128, 129, 1)])
+def test_degenerate_and_tile_edge_sizes(n, m, d):
+    """Single point, m == n, m > n, and sizes straddling the 128-tile boundary."""
+    rng = np.random.default_rng(n * 1000 + m)
+    X = np.asfortranarray(rng.normal(size=(d, n)))
+    y = rng.normal(size=n)
+    Z = np.asfortranarray(rng.normal(size=(d, m)))
+    ref = O.evaluate_fast(O.SeIsoKernel(0.2, -0.3), Z, X, y, 0.5)
+    p = gpr_amd.Problem(gpr_amd.COV_SE_ISO, n, d, d, m)
+    p.set_inputs(X)
+    p.set_targets(y)
+    ev = p.eval(log_ell=0.2, log_sf2=-0.3, sigma2=0.5, inducing=Z)
+    assert abs(ev.l - ref["l"]) <= TOL_L * abs(ref["l"])
+    assert relinf(ev.grad, ref["grad"]) <= TOL_GRAD
+    assert abs(ev.dl_dsigma2 - ref["dl_dsigma2"]) <= TOL_DS2 * max(abs(ref["dl_dsigma2"]), 1e-3)
+    p.close()
+
+
 def test_functor_mirror_and_reference_self_test_recipe():
     """test/test_derivatives.ml's recipe through the mirrored module surface: finite differences at
     the reference's eps=1e-8 / tol=1e-2 for sigma2 and every hyper (n=10, m=5, D=3)."""
