@@ -43,7 +43,7 @@ void launch_to_float(const double* src, float* dst, int64_t n, hipStream_t s) {
 
 // Whitened W:  W = T - t t^T - U_mat^T diag(v) U_mat  (lib/fitc_gp.ml:1196-1203, T = K_m^-1 - B^-1 :1040-1041)
 // equals U^-1 W~ U^-T with  W~ = I - B~^-1 - t~ t~^T - V^T diag(v) V,  B~ = I + V^T diag(is) V, t~ = U t.
-// Written as a full symmetric matrix (upper tiles are the computed ones; the rest is mirrored).
+// Written as a full symmetric matrix (the inputs' upper triangles are the computed part; the rest is mirrored).
 __global__ __launch_bounds__(256) void build_w_kernel(const double* __restrict__ binv,
                                                       const double* __restrict__ t,
                                                       const double* __restrict__ G, int mp,
@@ -52,7 +52,7 @@ __global__ __launch_bounds__(256) void build_w_kernel(const double* __restrict__
   const int r = blockIdx.y;
   if (c >= mp) return;
   int rr = r, cc = c;
-  if (r / TILE > c / TILE) {  // mirror from the computed upper tile
+  if (r > c) {  // symmetric inputs are valid in the upper triangle only: mirror
     rr = c;
     cc = r;
   }

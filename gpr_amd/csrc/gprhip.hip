@@ -299,13 +299,14 @@ void upload_hypers(gprhip_problem* p, const gprhip_hypers* h) {
 
 // Split-K factor of the SYRK-shaped accumulations over training points.  Slices are dealt to the
 // 8 XCDs (mfma_gemm.hip), so the factor is a multiple of 8.  Blocks of one slice share their operand
-// rows through the XCD's L2 only while they run in step; measured, that holds for a few hundred
-// k-stages, so slices are kept near 4096 rows (256 stages).  Among nearby factors the one whose
-// (tiles x slices / 8) fills whole residency rounds of an XCD (32 CUs x 2 blocks) is taken.
+// rows through the XCD's L2 while they run in step.  Throughput is flat in the slice length (measured
+// 4k..125k rows), so slices are kept near 16384 rows -- few enough that summing the partial m x m
+// results stays negligible.  Among nearby factors the one whose (tiles x slices / 8) fills whole
+// residency rounds of an XCD (32 CUs x 2 blocks) is taken.
 int pick_kslices(int mp, int64_t rows_p, int max_slices) {
   const int nt = mp / TILE, tiles = nt * (nt + 1) / 2;
   const int slots = 64;
-  int target = (int)((rows_p / 4096 + 7) / 8 * 8);
+  int target = (int)((rows_p / 16384 + 7) / 8 * 8);
   target = std::max(8, std::min(target, max_slices / 8 * 8));
   int best = target;
   double best_eff = 0.0;
@@ -752,9 +753,9 @@ int gprhip_problem_create_ex(int device, int cov_kind, int precision, int64_t n,
     chunk = round_up(std::min<int64_t>(chunk, round_up(n, TILE)), TILE);
     p->chunk = chunk;
     p->nchunks = (int)((n + chunk - 1) / chunk);
-    // partial-sum buffers of the split-K SYRK launches: one m x m slice per 4096 training points,
+    // partial-sum buffers of the split-K SYRK launches: one m x m slice per ~16384 training points,
     // capped at 40 GB
-    p->kslices = (int)std::max<int64_t>(8, std::min<int64_t>((round_up(n, 4096) / 4096 + 23) / 8 * 8,
+    p->kslices = (int)std::max<int64_t>(8, std::min<int64_t>((round_up(n, 16384) / 16384 + 23) / 8 * 8,
                                                               (40LL << 30) / (p->mp * (int64_t)p->mp * 8) / 8 * 8));
     if (const char* e = getenv("GPRHIP_KSLICES")) p->kslices = std::max(8, atoi(e) / 8 * 8);
     if (const char* e = getenv("GPRHIP_TIMING")) p->timer.on = atoi(e) != 0;

@@ -237,7 +237,11 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgsT<T> g) {
   const int diag_first = (g.tri == TRI_KHI_BN && k_hi == (bn + 1) * TILE) ? nk - TILE / BK
                          : (g.tri == TRI_KLO_BN && k_lo == bn * TILE) ? 0 : -(1 << 30);
   const int cj0 = wc * 4;
+  // symmetric product on a diagonal tile: the lower-left 64 x 64 wave tile mirrors the upper-right one
+  // and nobody reads it (consumers take the upper triangle), so that wavefront skips its MFMAs
+  const bool mirror_idle = (OP == OP_TN) && g.upper_only && g.A == g.B && bm == bn && wr == 1 && wc == 0;
   auto compute = [&](int stage, int t) {
+    if (mirror_idle) return;
     const T* As = smem + stage * 2 * STAGE;
     const T* Bs = As + STAGE;
     int jlo = 0, jhi = 7;  // live column sub-tiles of this stage
