@@ -37,6 +37,7 @@ class Hypers(C.Structure):
         ("variational", C.c_int),
         ("model_only", C.c_int),
         ("jitter", C.c_double),
+        ("log_hetero_skedasticity", C.POINTER(C.c_double)),
     ]
 
 

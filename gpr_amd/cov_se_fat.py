@@ -1,6 +1,6 @@
 """Host-side mirror of Gpr.Cov_se_fat (reference lib/cov_se_fat.ml, lib/cov_se_fat.mli),
-projection-only sub-case: `tproj` optional, heteroskedastic noise and multiscales must be None
-(SURVEY.md section 8(f) rank 3 -- the next rows to widen into).
+`tproj` and heteroskedastic noise optional; multiscales must be None
+(SURVEY.md section 8(f) rank 3 -- the next row to widen into).
 """
 from __future__ import annotations
 
@@ -31,10 +31,11 @@ class Params:
             if tproj.shape[1] != d:  # lib/cov_se_fat.ml:38-48
                 raise ValueError("Cov_se_fat.Params.create: tproj projection (%d) disagrees with "
                                  "target dimension d (%d)" % (tproj.shape[1], d))
-        if log_hetero_skedasticity is not None or log_multiscales_m05 is not None:
-            raise NotImplementedError(
-                "gpr_amd.cov_se_fat: heteroskedastic noise / multiscales are not on the device path yet")
-        return Params(int(d), float(log_sf2), tproj, None, None)
+        if log_multiscales_m05 is not None:
+            raise NotImplementedError("gpr_amd.cov_se_fat: multiscales are not on the device path yet")
+        if log_hetero_skedasticity is not None:
+            log_hetero_skedasticity = np.ascontiguousarray(log_hetero_skedasticity, dtype=np.float64)
+        return Params(int(d), float(log_sf2), tproj, log_hetero_skedasticity, None)
 
 
 @dataclass(frozen=True, eq=False)
@@ -62,7 +63,12 @@ class Proj_hyper(NamedTuple):
     small_dim: int
 
 
-Hyper = Union[str, Inducing_hyper, Proj_hyper]
+class Log_hetero_skedasticity(NamedTuple):
+    """`Log_hetero_skedasticity dim` (lib/cov_se_fat.ml:279), 1-based inducing index."""
+    dim: int
+
+
+Hyper = Union[str, Inducing_hyper, Proj_hyper, Log_hetero_skedasticity]
 LOG_SF2 = "Log_sf2"
 
 
@@ -90,6 +96,9 @@ class HyperModule:
             for big in range(1, tproj.shape[0] + 1):
                 for small in range(1, d + 1):
                     hypers.append(Proj_hyper(big, small))
+        if kernel.params.log_hetero_skedasticity is not None:
+            for i in range(1, m + 1):
+                hypers.append(Log_hetero_skedasticity(i))
         return hypers
 
     @staticmethod
@@ -100,6 +109,10 @@ class HyperModule:
             if kernel.params.tproj is None:  # lib/cov_se_fat.ml:344-347
                 raise RuntimeError("Deriv.Hyper.option_get_value: tproj not supported")
             return float(kernel.params.tproj[hyper.big_dim - 1, hyper.small_dim - 1])
+        if isinstance(hyper, Log_hetero_skedasticity):
+            if kernel.params.log_hetero_skedasticity is None:
+                raise RuntimeError("Deriv.Hyper.option_get_value: log_hetero_skedasticity not supported")
+            return float(kernel.params.log_hetero_skedasticity[hyper.dim - 1])
         return float(inducing[hyper.dim - 1, hyper.ind - 1])
 
     @staticmethod
@@ -107,9 +120,16 @@ class HyperModule:
         log_sf2 = kernel.params.log_sf2
         tproj = None
         new_inducing = None
+        log_het = None
         for h, v in zip(hypers, values):
             if h == LOG_SF2:
                 log_sf2 = float(v)
+            elif isinstance(h, Log_hetero_skedasticity):
+                if log_het is None:
+                    if kernel.params.log_hetero_skedasticity is None:
+                        raise RuntimeError("Deriv.Hyper.option_get_value: log_hetero_skedasticity not supported")
+                    log_het = np.array(kernel.params.log_hetero_skedasticity, dtype=np.float64, copy=True)
+                log_het[h.dim - 1] = v
             elif isinstance(h, Proj_hyper):
                 if tproj is None:
                     if kernel.params.tproj is None:
@@ -120,7 +140,8 @@ class HyperModule:
                 if new_inducing is None:
                     new_inducing = np.array(inducing, dtype=np.float64, order="F", copy=True)
                 new_inducing[h.dim - 1, h.ind - 1] = v
-        params = Params(kernel.params.d, log_sf2, kernel.params.tproj if tproj is None else tproj)
+        params = Params(kernel.params.d, log_sf2, kernel.params.tproj if tproj is None else tproj,
+                        kernel.params.log_hetero_skedasticity if log_het is None else log_het)
         return Kernel.create(params), (inducing if new_inducing is None else new_inducing), inputs
 
     @staticmethod
@@ -129,10 +150,14 @@ class HyperModule:
         m = inducing.shape[1]
         if hyper == LOG_SF2:
             return 0
+        nproj = 0 if kernel.params.tproj is None else kernel.params.tproj.shape[0] * d
         if isinstance(hyper, Proj_hyper):
             return 1 + d * m + (hyper.big_dim - 1) * d + (hyper.small_dim - 1)
+        if isinstance(hyper, Log_hetero_skedasticity):
+            return 1 + d * m + nproj + (hyper.dim - 1)
         return 1 + (hyper.ind - 1) * d + (hyper.dim - 1)
 
 
 def eval_args(kernel: Kernel):
-    return dict(log_ell=0.0, log_sf2=kernel.params.log_sf2, tproj=kernel.params.tproj)
+    return dict(log_ell=0.0, log_sf2=kernel.params.log_sf2, tproj=kernel.params.tproj,
+                log_hetero_skedasticity=kernel.params.log_hetero_skedasticity)

@@ -49,6 +49,7 @@ __global__ __launch_bounds__(256) void cov_cross_kernel(CovParams cp, const doub
 template <int DT>
 __global__ __launch_bounds__(256) void cov_upper_kernel(CovParams cp, const double* __restrict__ Z,
                                                         int m, int mp, int d, double jitter,
+                                                        const double* __restrict__ het,
                                                         double* __restrict__ km,
                                                         double* __restrict__ kj) {
   const int c = blockIdx.x * 256 + threadIdx.x;
@@ -64,7 +65,7 @@ __global__ __launch_bounds__(256) void cov_upper_kernel(CovParams cp, const doub
     if (r < m && c < m) {
       if (r == c) {
         val = cp.sf2;  // lib/cov_se_iso.ml:82, lib/cov_se_fat.ml:98
-        valj = cp.sf2 + jitter;
+        valj = (het ? cp.sf2 + het[c] : cp.sf2) + jitter;  // hetero first, then jitter (fitc_gp.ml:54-55)
       } else {
         const double* x = Z + (int64_t)r * d;
         double acc = 0.0;
@@ -117,11 +118,11 @@ static void dispatch_dt(int d, F&& f) {
 }
 
 void launch_cov_upper(const CovParams& cp, const double* Z, int m, int mp, int d, double jitter,
-                      double* km, double* kj, hipStream_t s) {
+                      const double* het, double* km, double* kj, hipStream_t s) {
   dim3 grid(mp / 256 + (mp % 256 ? 1 : 0), (mp + 31) / 32);
   dispatch_dt(d, [&](auto dt) {
     hipLaunchKernelGGL((cov_upper_kernel<decltype(dt)::value>), grid, dim3(256), 0, s, cp, Z, m, mp, d,
-                       jitter, km, kj);
+                       jitter, het, km, kj);
   });
   GPR_HIP(hipGetLastError());
 }

@@ -114,7 +114,8 @@ struct gprhip_problem {
   int stage = 0;  // 0 idle, 1 pass1 done, 2 pass2 done
   bool have_inputs = false, have_targets = false;
   std::vector<double> hZ;  // host copy of inducing (padded point-major) for the gradient assembly
-  std::vector<double> hTproj;
+  std::vector<double> hTproj, hHet;   // host copies: projection, exp(log_hetero_skedasticity)
+  double* het = nullptr;              // device copy of hHet
   Timer timer;
   std::vector<std::string> tnames;
   std::vector<float> tms;
@@ -137,6 +138,7 @@ struct gprhip_problem {
   // Cov_se_fat `Proj hypers: rows of the exchange-2 column block beyond d+1, and the D x d second term
   int dbig() const { return kind == GPRHIP_COV_SE_FAT ? D : 0; }
   bool has_proj() const { return kind == GPRHIP_COV_SE_FAT && h.tproj != nullptr; }
+  bool has_het() const { return kind == GPRHIP_COV_SE_FAT && h.log_hetero_skedasticity != nullptr; }
   int64_t col_rows() const { return d + 1 + dbig(); }
 };
 
@@ -270,8 +272,20 @@ void upload_hypers(gprhip_problem* p, const gprhip_hypers* h) {
     set_error("gprhip: Cov_se_fat without tproj needs D == d");
     throw HipFail{ST_BAD_ARG};
   }
+  if (p->kind == GPRHIP_COV_SE_ISO && h->log_hetero_skedasticity) {
+    set_error("gprhip: log_hetero_skedasticity given for Cov_se_iso");
+    throw HipFail{ST_BAD_ARG};
+  }
   p->h = *h;
   p->h.inducing = nullptr;  // borrowed; the padded copy lives in hZ
+  if (h->log_hetero_skedasticity) {  // Kernel.create: Vec.map exp, lib/cov_se_fat.ml:63-65
+    p->hHet.resize(p->m);
+    for (int i = 0; i < p->m; ++i) p->hHet[i] = std::exp(h->log_hetero_skedasticity[i]);
+    p->h.log_hetero_skedasticity = p->hHet.data();  // only used as a presence flag from here on
+    if (!p->het) p->het = p->alloc<double>(p->m);
+    GPR_HIP(hipMemcpyAsync(p->het, p->hHet.data(), (size_t)p->m * sizeof(double), hipMemcpyHostToDevice,
+                           p->stream));
+  }
   CovParams& cp = p->cp;
   cp.kind = p->kind;
   cp.log_sf2 = h->log_sf2;
@@ -355,7 +369,7 @@ void do_pass1(gprhip_problem* p, const gprhip_hypers* h, int want_grad, int64_t 
   GPR_HIP(hipMemsetAsync(p->info, 0, 2 * sizeof(int), s));
   GPR_HIP(hipMemsetAsync(p->scal, 0, NSCAL * sizeof(double), s));
   GPR_HIP(hipMemsetAsync(ar1_c, 0, (size_t)(mp + A1_TAIL) * sizeof(double), s));
-  launch_cov_upper(p->cp, p->Z, p->m, mp, p->d, h->jitter, p->km, p->kj, s);
+  launch_cov_upper(p->cp, p->Z, p->m, mp, p->d, h->jitter, p->has_het() ? p->het : nullptr, p->km, p->kj, s);
   GPR_HIP(hipMemcpyAsync(p->umat, p->kj, (size_t)mm * sizeof(double), hipMemcpyDeviceToDevice, s));
   potrf_upper(p, p->umat, p->info);  // U = chol(K_m + jitter), lib/fitc_gp.ml:53-57
   trtri_upper(p, p->umat, p->uinv, p->wmat);
@@ -554,6 +568,12 @@ void do_finish(gprhip_problem* p, const double* ar2, gprhip_result* res, double*
     GPR_HIP(hipMemcpyAsync(hcol.data(), ar2_col, hcol.size() * sizeof(double), hipMemcpyDeviceToHost, s));
     GPR_HIP(hipMemcpyAsync(hkm.data(), p->kmred, hkm.size() * sizeof(double), hipMemcpyDeviceToHost, s));
   }
+  std::vector<double> hwdiag;
+  if (p->want_grad && p->has_het()) {  // W_ii for the `Diag_vec derivative
+    hwdiag.resize(m);
+    GPR_HIP(hipMemcpy2DAsync(hwdiag.data(), sizeof(double), p->wmat, (size_t)(mp + 1) * sizeof(double),
+                             sizeof(double), (size_t)m, hipMemcpyDeviceToHost, s));
+  }
   // scalar tail of the (reduced) exchange-1 buffer, kept in p->ar1 by pass 2
   GPR_HIP(hipMemcpyAsync(ha1tail.data(), p->ar1 + mm + mp, A1_TAIL * sizeof(double),
                          hipMemcpyDeviceToHost, s));
@@ -629,6 +649,10 @@ void do_finish(gprhip_problem* p, const double* ar2, gprhip_result* res, double*
       }
     }
   }
+  // Log_hetero_skedasticity i (lib/cov_se_fat.ml:430-440): dkm `Diag_vec het_i e_i, the other two `Const 0.
+  //   -> dl = 1/2 het_i W_ii   (lib/fitc_gp.ml:962-967)
+  if (p->has_het())
+    for (int i = 0; i < m; ++i) grad[pos++] = 0.5 * p->hHet[i] * hwdiag[i];
   res->n_hypers = pos;
 }
 
@@ -873,10 +897,10 @@ int gprhip_set_targets_device(gprhip_problem* p, const double* d_targets) {
   });
 }
 
-int64_t gprhip_n_hypers(const gprhip_problem* p, int has_tproj) {
+int64_t gprhip_n_hypers(const gprhip_problem* p, int flags) {
   if (!p) return 0;
   if (p->kind == GPRHIP_COV_SE_ISO) return 2 + (int64_t)p->d * p->m;
-  return 1 + (int64_t)p->d * p->m + (has_tproj ? (int64_t)p->D * p->d : 0);
+  return 1 + (int64_t)p->d * p->m + ((flags & 1) ? (int64_t)p->D * p->d : 0) + ((flags & 2) ? p->m : 0);
 }
 
 int64_t gprhip_ar1_len(const gprhip_problem* p) { return (int64_t)p->mp * p->mp + p->mp + A1_TAIL; }

@@ -19,9 +19,10 @@ struct CovParams {
 };
 
 // K_m (lib/cov_se_iso.ml:56-87, lib/cov_se_fat.ml:85-100): km = covariance (padding rows/cols 0),
-// kj = km + jitter*I on the real diagonal and exactly 1 on the padded diagonal.
+// kj = km + (het + jitter) on the real diagonal (het = heteroskedastic noise, may be null,
+// lib/cov_se_fat.ml:136-142) and exactly 1 on the padded diagonal.
 void launch_cov_upper(const CovParams& cp, const double* Z, int m, int mp, int d, double jitter,
-                      double* km, double* kj, hipStream_t s);
+                      const double* het, double* km, double* kj, hipStream_t s);
 
 // K_nm rows [0, rows) of a chunk (lib/cov_se_iso.ml:128-159, lib/cov_se_fat.ml:224-240);
 // rows in [rows, rows_p) and columns in [m, mp) are written as 0.

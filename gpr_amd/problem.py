@@ -76,10 +76,11 @@ class Problem:
         _lib.check(self._lib.gprhip_set_targets_device(self._h, C.c_void_p(ptr)))
 
     # ---- evaluation
-    def n_hypers(self, has_tproj=False):
-        return int(self._lib.gprhip_n_hypers(self._h, int(has_tproj)))
+    def n_hypers(self, has_tproj=False, has_hetero=False):
+        return int(self._lib.gprhip_n_hypers(self._h, int(has_tproj) | (int(has_hetero) << 1)))
 
-    def _hypers(self, log_ell, log_sf2, sigma2, inducing, tproj, variational, model_only, jitter):
+    def _hypers(self, log_ell, log_sf2, sigma2, inducing, tproj, variational, model_only, jitter,
+                log_hetero_skedasticity=None):
         z = np.asfortranarray(inducing, dtype=np.float64)
         if z.shape != (self.d, self.m):
             raise ValueError("inducing: expected shape (%d, %d), got %s" % (self.d, self.m, z.shape))
@@ -94,13 +95,20 @@ class Problem:
             h.tproj = _f64_ptr(tp)
             keep.append(tp)
         h.variational, h.model_only, h.jitter = int(variational), int(model_only), float(jitter)
+        if log_hetero_skedasticity is not None:
+            lh = np.ascontiguousarray(log_hetero_skedasticity, dtype=np.float64)
+            if lh.shape != (self.m,):
+                raise ValueError("log_hetero_skedasticity: expected %d entries" % self.m)
+            h.log_hetero_skedasticity = _f64_ptr(lh)
+            keep.append(lh)
         return h, keep
 
     def eval(self, *, log_sf2, sigma2, inducing, log_ell=0.0, tproj=None, variational=False,
-             model_only=False, want_grad=True, jitter=CHOLESKY_JITTER):
-        h, keep = self._hypers(log_ell, log_sf2, sigma2, inducing, tproj, variational, model_only, jitter)
+             model_only=False, want_grad=True, jitter=CHOLESKY_JITTER, log_hetero_skedasticity=None):
+        h, keep = self._hypers(log_ell, log_sf2, sigma2, inducing, tproj, variational, model_only, jitter,
+                               log_hetero_skedasticity)
         res = Result()
-        nh = self.n_hypers(tproj is not None)
+        nh = self.n_hypers(tproj is not None, log_hetero_skedasticity is not None)
         grad = np.empty(nh if want_grad else 1, dtype=np.float64)
         coeffs = np.empty(self.m, dtype=np.float64)
         _lib.check(self._lib.gprhip_eval(self._h, C.byref(h), int(want_grad), C.byref(res),
@@ -131,10 +139,13 @@ class Problem:
         return int(self._lib.gprhip_ar2_len(self._h))
 
     def eval_pass1(self, ar1_ptr, n_total, *, log_sf2, sigma2, inducing, log_ell=0.0, tproj=None,
-                   variational=False, model_only=False, want_grad=True, jitter=CHOLESKY_JITTER):
-        h, keep = self._hypers(log_ell, log_sf2, sigma2, inducing, tproj, variational, model_only, jitter)
+                   variational=False, model_only=False, want_grad=True, jitter=CHOLESKY_JITTER,
+                   log_hetero_skedasticity=None):
+        h, keep = self._hypers(log_ell, log_sf2, sigma2, inducing, tproj, variational, model_only, jitter,
+                               log_hetero_skedasticity)
         self._want_grad = bool(want_grad)
         self._has_tproj = tproj is not None
+        self._has_het = log_hetero_skedasticity is not None
         _lib.check(self._lib.gprhip_eval_pass1(self._h, C.byref(h), int(want_grad), int(n_total),
                                                C.c_void_p(ar1_ptr)))
         del keep  # the library copies borrowed host buffers before returning
@@ -144,7 +155,7 @@ class Problem:
 
     def eval_finish(self, ar2_ptr):
         res = Result()
-        nh = self.n_hypers(self._has_tproj)
+        nh = self.n_hypers(self._has_tproj, self._has_het)
         grad = np.empty(nh if self._want_grad else 1, dtype=np.float64)
         coeffs = np.empty(self.m, dtype=np.float64)
         _lib.check(self._lib.gprhip_eval_finish(self._h, C.c_void_p(ar2_ptr), C.byref(res),

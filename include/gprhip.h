@@ -79,7 +79,9 @@ int gprhip_set_targets_device(gprhip_problem* p, const double* d_targets);
  *   tproj      : Fortran D x d projection (Cov_se_fat.Params.tproj) or NULL
  *   variational: 0 = Make_FITC_deriv (Standard), 1 = Make_variational_FITC_deriv  lib/fitc_gp.ml:262-263
  *   model_only : 1 = evidence/gradient of the model without targets (Deriv.Model.*), 0 = Trained.*
- *   jitter     : Utils.cholesky_jitter (lib/utils.ml:35); pass 1e-6 for the reference behaviour */
+ *   jitter     : Utils.cholesky_jitter (lib/utils.ml:35); pass 1e-6 for the reference behaviour
+ *   log_hetero_skedasticity : Cov_se_fat.Params.log_hetero_skedasticity (m entries) or NULL:
+ *                exp() of it is added to diag(K_m)                             lib/cov_se_fat.ml:136-142 */
 typedef struct {
   double log_ell;
   double log_sf2;
@@ -89,11 +91,13 @@ typedef struct {
   int variational;
   int model_only;
   double jitter;
+  const double* log_hetero_skedasticity;
 } gprhip_hypers;
 
 /* Results.  Gradient order is the reference's Hyper.get_all order:
  *   Cov_se_iso: [Log_ell; Log_sf2; Inducing_hyper{ind=1,dim=1..d}; {ind=2,..}; ...]   lib/cov_se_iso.ml:188-202
- *   Cov_se_fat: [Log_sf2; Inducing_hyper (ind-major); Proj{big_dim,small_dim} (big-major)] lib/cov_se_fat.ml:290-342
+ *   Cov_se_fat: [Log_sf2; Inducing_hyper (ind-major); Proj{big_dim,small_dim} (big-major);
+ *                Log_hetero_skedasticity 1..m]                                  lib/cov_se_fat.ml:290-342
  * l1 = Model.calc_log_evidence, l = Trained.calc_log_evidence, dl_dsigma2 = calc_log_evidence_sigma2. */
 typedef struct {
   double l1;
@@ -103,7 +107,8 @@ typedef struct {
   int64_t n_hypers;
 } gprhip_result;
 
-int64_t gprhip_n_hypers(const gprhip_problem* p, int has_tproj);
+/* flags: bit 0 = tproj given, bit 1 = log_hetero_skedasticity given */
+int64_t gprhip_n_hypers(const gprhip_problem* p, int flags);
 
 /* One complete evaluation on one device (shard == whole problem).
  *   want_grad = 0: log evidence only (multim_f, lib/fitc_gp.ml:1601-1610)

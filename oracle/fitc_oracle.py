@@ -121,16 +121,21 @@ def se_iso_hypers(d, m):
 # ---------------------------------------------------------------------------
 @dataclass
 class SeFatKernel:
-    """lib/cov_se_fat.ml:55-75 with log_hetero_skedasticity = None and
-    log_multiscales_m05 = None (the sub-case on the hot path)."""
+    """lib/cov_se_fat.ml:55-75 with log_multiscales_m05 = None; heteroskedastic noise on
+    diag(K_m) optional (lib/cov_se_fat.ml:136-142)."""
 
     d: int
     log_sf2: float
     tproj: Optional[np.ndarray]  # big_dim x d, or None
+    log_hetero_skedasticity: Optional[np.ndarray] = None  # m, or None
     sf2: float = field(init=False)
+    hetero_skedasticity: Optional[np.ndarray] = field(init=False, default=None)
 
     def __post_init__(self):
         self.sf2 = math.exp(self.log_sf2)
+        if self.log_hetero_skedasticity is not None:
+            self.log_hetero_skedasticity = np.asarray(self.log_hetero_skedasticity, dtype=np.float64)
+            self.hetero_skedasticity = np.exp(self.log_hetero_skedasticity)  # lib/cov_se_fat.ml:63-65
         if self.tproj is not None:
             self.tproj = _F(self.tproj)
             if self.tproj.shape[1] != self.d:  # lib/cov_se_fat.ml:38-48
@@ -168,7 +173,7 @@ def se_fat_calc_cross_with_projections(k: SeFatKernel, projections, inducing):
 
 
 def se_fat_hypers(k: SeFatKernel, m):
-    """lib/cov_se_fat.ml:290-342: [Log_sf2; inducing (ind-major); Proj (big_dim-major)]."""
+    """lib/cov_se_fat.ml:290-342: [Log_sf2; inducing (ind-major); Proj (big_dim-major); hetero]."""
     hypers = [("log_sf2",)]
     for ind in range(1, m + 1):
         for dim in range(1, k.d + 1):
@@ -177,6 +182,9 @@ def se_fat_hypers(k: SeFatKernel, m):
         for big in range(1, k.tproj.shape[0] + 1):
             for small in range(1, k.d + 1):
                 hypers.append(("proj", big, small))
+    if k.hetero_skedasticity is not None:
+        for i in range(1, len(k.hetero_skedasticity) + 1):
+            hypers.append(("log_hetero", i))
     return hypers
 
 
@@ -192,6 +200,8 @@ def spec_calc_shared_upper(k, inducing):
         km = se_iso_calc_upper_with_sqr_diff(k, sq)
         return km, dict(kernel=k, inducing=inducing, sqr_diff_mat=sq, eval_mat=km)
     km = se_fat_calc_upper_vanilla(k, inducing)
+    if k.hetero_skedasticity is not None:  # lib/cov_se_fat.ml:136-142
+        km[np.diag_indices(km.shape[0])] += k.hetero_skedasticity
     return km, dict(kernel=k, inducing=inducing, eval_mat=km)
 
 
@@ -228,7 +238,19 @@ def spec_calc_deriv_upper(shared_upper, hyper):
     iso = isinstance(k, SeIsoKernel)
     kind = hyper[0]
     if kind == "log_sf2":
-        return ("factor", 1.0)
+        het = None if iso else k.hetero_skedasticity
+        if het is None:
+            return ("factor", 1.0)
+        res = eval_mat.copy(order="F")  # lib/cov_se_fat.ml:423-428
+        res[np.diag_indices(m)] -= het
+        return ("dense", res)
+    if kind == "log_hetero":  # `Diag_vec, lib/cov_se_fat.ml:430-440
+        if k.hetero_skedasticity is None:
+            raise RuntimeError("Cov_se_fat.Deriv.Inducing.calc_deriv_upper: heteroskedastic modeling "
+                               "disabled, cannot calculate derivative")
+        deriv = np.zeros(m)
+        deriv[hyper[1] - 1] = k.hetero_skedasticity[hyper[1] - 1]
+        return ("diag_vec", deriv)
     if kind == "log_ell":
         res = eval_mat * shared_upper["sqr_diff_mat"] * k.inv_ell2
         res[np.diag_indices(m)] = 0.0
@@ -266,6 +288,8 @@ def spec_calc_deriv_cross(shared_cross, hyper):
     kind = hyper[0]
     if kind == "log_sf2":
         return ("factor", 1.0)
+    if kind == "log_hetero":  # lib/cov_se_fat.ml:597
+        return ("const", 0.0)
     if kind == "log_ell":
         return ("dense", _F(eval_mat * shared_cross["sqr_diff_mat"] * k.inv_ell2))
     if kind == "inducing":
@@ -511,6 +535,8 @@ def shared_calc_log_evidence(hyper_t, shared, hyper):
         dkm_term = symm2_trace(w_mat, dk[1])
     elif dk[0] == "sparse_rows":
         dkm_term = symm2_sparse_trace_single(w_mat, dk[1], dk[2])
+    elif dk[0] == "diag_vec":  # lib/fitc_gp.ml:962-967
+        dkm_term = float(np.sum(dk[1] * np.diag(w_mat)))
     elif dk[0] == "const":
         dkm_term = 0.0 if dk[1] == 0.0 else dk[1] * sum_symm_mat(w_mat)
     else:  # factor
@@ -616,9 +642,11 @@ def evaluate_fast(k, inducing_points, inputs, targets, sigma2, variational=False
     iso = isinstance(k, SeIsoKernel)
     scale = k.inv_ell2 if iso else 1.0
     wfull = _upper_to_full(w_mat)
-    kmfull = _upper_to_full(km)
+    het = None if iso else k.hetero_skedasticity
+    km_nohet = km if het is None else km - np.diag(het)
+    kmfull = _upper_to_full(km_nohet)
     e_mat = x_mat * knm                       # X .* K_nm
-    g_sf2 = -0.5 * (k.sf2 * float(np.sum(v_vec)) - symm2_trace(w_mat, km)) - float(np.sum(e_mat))
+    g_sf2 = -0.5 * (k.sf2 * float(np.sum(v_vec)) - symm2_trace(w_mat, km_nohet)) - float(np.sum(e_mat))
     wk = wfull * kmfull
     np.fill_diagonal(wk, 0.0)
     # inducing hyper (ind=c, dim=kk): 0.5*dkm_term - dknm_term
@@ -639,6 +667,8 @@ def evaluate_fast(k, inducing_points, inputs, targets, sigma2, variational=False
             rs = np.sum(e_mat, axis=1)[:, None] * pts.T          # n x d : rowsum(E)_r p_small,r
             g_proj = -(shared_cross["inputs"] @ (ez - rs))      # big x small
             parts.append(g_proj.reshape(-1))
+        if het is not None:
+            parts.append(0.5 * het * np.diag(w_mat))            # `Diag_vec: 1/2 het_i W_ii
         out["grad"] = np.concatenate(parts)
     return out
 
@@ -655,7 +685,7 @@ def dense_fitc_log_evidence(k, inducing_points, inputs, targets, sigma2, variati
     km, _ = spec_calc_shared_upper(k, inducing_points)
     km = _upper_to_full(np.nan_to_num(km, nan=0.0)) + CHOLESKY_JITTER * np.eye(km.shape[0])
     knm, _ = spec_calc_shared_cross(k, inputs, inducing_points)
-    qnn = knm @ np.linalg.solve(km, knm.T)
+    qnn = knm @ np.linalg.solve(km, knm.T)  # km already carries the heteroskedastic diagonal
     r = k.sf2 - np.diag(qnn)
     cov = qnn + np.diag(r + sigma2)
     sign, logdet = np.linalg.slogdet(cov)

@@ -82,6 +82,10 @@ def main():
     ka = O.SeFatKernel(4, 0.0, Pd)
     Za = np.asfortranarray(O.se_fat_project(ka, Xa[:, :16]) + 0.01 * rng.normal(size=(4, 16)))
     save("fat_ard", ka, Xa, ya, Za, 0.1, False, dict(kind="fat", d=4, log_sf2=0.0, tproj=Pd))
+    # heteroskedastic noise on diag(K_m) together with a projection (lib/cov_se_fat.ml:136-142)
+    lh = rng.normal(size=20) - 3.0
+    kh = O.SeFatKernel(3, 0.2, P, lh)
+    save("fat_hetero", kh, Xb, yb, Zf, 0.1, False, dict(kind="fat", d=3, log_sf2=0.2, tproj=P, log_hetero=lh))
     # Cov_se_fat without projection
     kn = O.SeFatKernel(4, -0.1, None)
     save("fat_noproj", kn, Xa, ya, np.asfortranarray(Xa[:, :16] + 0.01), 0.2, False,

@@ -38,8 +38,11 @@ def _eval_golden(p, g, **kw):
                 variational=bool(g["variational"]))
     if g["kind"] == "iso":
         args["log_ell"] = float(g["log_ell"])
-    elif "tproj" in g:
-        args["tproj"] = g["tproj"]
+    else:
+        if "tproj" in g:
+            args["tproj"] = g["tproj"]
+        if "log_hetero" in g:
+            args["log_hetero_skedasticity"] = g["log_hetero"]
     args.update(kw)
     return p.eval(**args)
 
@@ -99,12 +102,13 @@ def test_fat_functor_mirror_self_test():
     X = np.asfortranarray(rng.uniform(size=(3, 10)))
     y = rng.uniform(size=10)
     P = np.asfortranarray(rng.uniform(-1, 1, size=(3, 2)))
-    kernel = cov_se_fat.Kernel.create(cov_se_fat.Params.create(2, 0.3, P))
+    # projection and heteroskedastic noise on, as create_default_kernel_params does (lib/cov_se_fat.ml:191-213)
+    kernel = cov_se_fat.Kernel.create(cov_se_fat.Params.create(2, 0.3, P, np.full(5, -5.0)))
     Z = np.asfortranarray((P.T @ X)[:, :5].copy())
     GP = fitc_gp.Make_deriv(cov_se_fat)
     FITC = GP.FITC
     hypers = FITC.Deriv.Spec.HyperModule.get_all(kernel, Z, X)
-    assert len(hypers) == 1 + 2 * 5 + 3 * 2
+    assert len(hypers) == 1 + 2 * 5 + 3 * 2 + 5
     FITC.Deriv.Test.self_test(kernel, Z, X, sigma2=1.0, targets=y, hyper="Sigma2")
     for h in hypers:
         FITC.Deriv.Test.self_test(kernel, Z, X, sigma2=1.0, targets=y, hyper=h)

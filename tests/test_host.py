@@ -44,7 +44,11 @@ def test_fat_hypers_and_param_checks():
     with pytest.raises(ValueError, match="disagrees with target dimension"):
         cov_se_fat.Params.create(3, 0.0, tproj=np.ones((5, 2)))
     with pytest.raises(NotImplementedError):
-        cov_se_fat.Params.create(3, 0.0, log_hetero_skedasticity=np.zeros(4))
+        cov_se_fat.Params.create(3, 0.0, log_multiscales_m05=np.zeros((3, 4)))
+    kh = cov_se_fat.Kernel.create(cov_se_fat.Params.create(2, 0.0, np.ones((3, 2)), np.zeros(2)))
+    hh = cov_se_fat.HyperModule.get_all(kh, np.zeros((2, 2), order="F"))
+    assert hh[-2:] == [cov_se_fat.Log_hetero_skedasticity(1), cov_se_fat.Log_hetero_skedasticity(2)]
+    assert [cov_se_fat.HyperModule.index_of(kh, np.zeros((2, 2)), h) for h in hh] == list(range(len(hh)))
     P = np.ones((3, 2))
     k = cov_se_fat.Kernel.create(cov_se_fat.Params.create(2, 0.1, P))
     Z = np.zeros((2, 2), order="F")
