@@ -38,6 +38,7 @@ class Hypers(C.Structure):
         ("model_only", C.c_int),
         ("jitter", C.c_double),
         ("log_hetero_skedasticity", C.POINTER(C.c_double)),
+        ("log_multiscales_m05", C.POINTER(C.c_double)),
     ]
 
 

@@ -1,6 +1,5 @@
-"""Host-side mirror of Gpr.Cov_se_fat (reference lib/cov_se_fat.ml, lib/cov_se_fat.mli),
-`tproj` and heteroskedastic noise optional; multiscales must be None
-(SURVEY.md section 8(f) rank 3 -- the next row to widen into).
+"""Host-side mirror of Gpr.Cov_se_fat (reference lib/cov_se_fat.ml, lib/cov_se_fat.mli): projection,
+heteroskedastic noise and multiscales, each optional, with all their hyper-parameters.
 """
 from __future__ import annotations
 
@@ -32,10 +31,13 @@ class Params:
                 raise ValueError("Cov_se_fat.Params.create: tproj projection (%d) disagrees with "
                                  "target dimension d (%d)" % (tproj.shape[1], d))
         if log_multiscales_m05 is not None:
-            raise NotImplementedError("gpr_amd.cov_se_fat: multiscales are not on the device path yet")
+            log_multiscales_m05 = np.asfortranarray(log_multiscales_m05, dtype=np.float64)
+            if log_multiscales_m05.shape[0] != d:
+                raise ValueError("Cov_se_fat.Params.create: log_multiscales_m05 has %d rows, d = %d"
+                                 % (log_multiscales_m05.shape[0], d))
         if log_hetero_skedasticity is not None:
             log_hetero_skedasticity = np.ascontiguousarray(log_hetero_skedasticity, dtype=np.float64)
-        return Params(int(d), float(log_sf2), tproj, log_hetero_skedasticity, None)
+        return Params(int(d), float(log_sf2), tproj, log_hetero_skedasticity, log_multiscales_m05)
 
 
 @dataclass(frozen=True, eq=False)
@@ -68,7 +70,13 @@ class Log_hetero_skedasticity(NamedTuple):
     dim: int
 
 
-Hyper = Union[str, Inducing_hyper, Proj_hyper, Log_hetero_skedasticity]
+class Log_multiscale_m05(NamedTuple):
+    """`Log_multiscale_m05 {ind; dim}` (lib/cov_se_fat.ml:280), 1-based."""
+    ind: int
+    dim: int
+
+
+Hyper = Union[str, Inducing_hyper, Proj_hyper, Log_hetero_skedasticity, Log_multiscale_m05]
 LOG_SF2 = "Log_sf2"
 
 
@@ -99,6 +107,10 @@ class HyperModule:
         if kernel.params.log_hetero_skedasticity is not None:
             for i in range(1, m + 1):
                 hypers.append(Log_hetero_skedasticity(i))
+        if kernel.params.log_multiscales_m05 is not None:
+            for ind in range(1, m + 1):
+                for dim in range(1, d + 1):
+                    hypers.append(Log_multiscale_m05(ind, dim))
         return hypers
 
     @staticmethod
@@ -113,6 +125,10 @@ class HyperModule:
             if kernel.params.log_hetero_skedasticity is None:
                 raise RuntimeError("Deriv.Hyper.option_get_value: log_hetero_skedasticity not supported")
             return float(kernel.params.log_hetero_skedasticity[hyper.dim - 1])
+        if isinstance(hyper, Log_multiscale_m05):
+            if kernel.params.log_multiscales_m05 is None:
+                raise RuntimeError("Deriv.Hyper.option_get_value: log_multiscales_m05 not supported")
+            return float(kernel.params.log_multiscales_m05[hyper.dim - 1, hyper.ind - 1])
         return float(inducing[hyper.dim - 1, hyper.ind - 1])
 
     @staticmethod
@@ -121,9 +137,16 @@ class HyperModule:
         tproj = None
         new_inducing = None
         log_het = None
+        log_ms = None
         for h, v in zip(hypers, values):
             if h == LOG_SF2:
                 log_sf2 = float(v)
+            elif isinstance(h, Log_multiscale_m05):
+                if log_ms is None:
+                    if kernel.params.log_multiscales_m05 is None:
+                        raise RuntimeError("Deriv.Hyper.option_get_value: log_multiscales_m05 not supported")
+                    log_ms = np.array(kernel.params.log_multiscales_m05, dtype=np.float64, order="F", copy=True)
+                log_ms[h.dim - 1, h.ind - 1] = v
             elif isinstance(h, Log_hetero_skedasticity):
                 if log_het is None:
                     if kernel.params.log_hetero_skedasticity is None:
@@ -141,7 +164,8 @@ class HyperModule:
                     new_inducing = np.array(inducing, dtype=np.float64, order="F", copy=True)
                 new_inducing[h.dim - 1, h.ind - 1] = v
         params = Params(kernel.params.d, log_sf2, kernel.params.tproj if tproj is None else tproj,
-                        kernel.params.log_hetero_skedasticity if log_het is None else log_het)
+                        kernel.params.log_hetero_skedasticity if log_het is None else log_het,
+                        kernel.params.log_multiscales_m05 if log_ms is None else log_ms)
         return Kernel.create(params), (inducing if new_inducing is None else new_inducing), inputs
 
     @staticmethod
@@ -155,9 +179,13 @@ class HyperModule:
             return 1 + d * m + (hyper.big_dim - 1) * d + (hyper.small_dim - 1)
         if isinstance(hyper, Log_hetero_skedasticity):
             return 1 + d * m + nproj + (hyper.dim - 1)
+        if isinstance(hyper, Log_multiscale_m05):
+            nhet = 0 if kernel.params.log_hetero_skedasticity is None else m
+            return 1 + d * m + nproj + nhet + (hyper.ind - 1) * d + (hyper.dim - 1)
         return 1 + (hyper.ind - 1) * d + (hyper.dim - 1)
 
 
 def eval_args(kernel: Kernel):
     return dict(log_ell=0.0, log_sf2=kernel.params.log_sf2, tproj=kernel.params.tproj,
-                log_hetero_skedasticity=kernel.params.log_hetero_skedasticity)
+                log_hetero_skedasticity=kernel.params.log_hetero_skedasticity,
+                log_multiscales_m05=kernel.params.log_multiscales_m05)

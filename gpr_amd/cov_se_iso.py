@@ -115,4 +115,4 @@ class HyperModule:
 def eval_args(kernel: Kernel):
     """Scalar hyper-parameters handed to the device evaluation."""
     return dict(log_ell=kernel.params.log_ell, log_sf2=kernel.params.log_sf2, tproj=None,
-                log_hetero_skedasticity=None)
+                log_hetero_skedasticity=None, log_multiscales_m05=None)

@@ -46,6 +46,93 @@ __global__ __launch_bounds__(256) void cov_cross_kernel(CovParams cp, const doub
   }
 }
 
+// Multiscale variants (lib/cov_se_fat.ml:102-103, :115-134, :241-251): per inducing point and dimension a
+// scale ms >= 0.5; the exponent accumulates diff*(diff/scale) + log(scale).
+template <int DT, typename TS>
+__global__ __launch_bounds__(256) void cov_cross_ms_kernel(CovParams cp, const double* __restrict__ pts,
+                                                           int rows, int rows_p,
+                                                           const double* __restrict__ Z, int m, int mp,
+                                                           int d, TS* __restrict__ K) {
+  __shared__ double xs[32][DT];
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  const int r0 = blockIdx.y * 32;
+  for (int idx = threadIdx.x; idx < 32 * DT; idx += 256) {
+    const int r = idx / DT, k = idx % DT;
+    xs[r][k] = (k < d && r0 + r < rows) ? pts[(int64_t)(r0 + r) * d + k] : 0.0;
+  }
+  __syncthreads();
+  if (j >= mp) return;
+  double z[DT], sc[DT], lsc[DT];
+#pragma unroll
+  for (int k = 0; k < DT; ++k) {
+    const bool live = (k < d && j < m);
+    z[k] = live ? Z[(int64_t)j * d + k] : 0.0;
+    sc[k] = live ? cp.ms[(int64_t)j * d + k] : 1.0;
+    lsc[k] = log(sc[k]);
+  }
+  const bool live_col = j < m;
+  const int nr = min(32, rows_p - r0);
+  for (int i = 0; i < nr; ++i) {
+    double acc = 0.0;
+#pragma unroll
+    for (int k = 0; k < DT; ++k) {
+      const double diff = xs[i][k] - z[k];
+      acc = (acc + diff * (diff / sc[k])) + lsc[k];
+    }
+    const double val = (r0 + i < rows && live_col) ? exp(cp.log_sf2 + cp.inv_ell2_05 * acc) : 0.0;
+    K[(int64_t)(r0 + i) * mp + j] = (TS)val;
+  }
+}
+
+template <int DT>
+__global__ __launch_bounds__(256) void cov_upper_ms_kernel(CovParams cp, const double* __restrict__ Z,
+                                                           int m, int mp, int d, double jitter,
+                                                           const double* __restrict__ het,
+                                                           double* __restrict__ km,
+                                                           double* __restrict__ kj) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= mp) return;
+  const int r0 = blockIdx.y * 32;
+  double z[DT], msc[DT];
+#pragma unroll
+  for (int k = 0; k < DT; ++k) {
+    z[k] = (k < d && c < m) ? Z[(int64_t)c * d + k] : 0.0;
+    msc[k] = (k < d && c < m) ? cp.ms[(int64_t)c * d + k] : 1.0;
+  }
+  for (int i = 0; i < 32; ++i) {
+    const int r = r0 + i;
+    if (r >= mp) break;
+    double val = 0.0, valj = 0.0;
+    if (r < m && c < m) {
+      double acc = 0.0;
+      if (r == c) {
+#pragma unroll
+        for (int k = 0; k < DT; ++k)
+          if (k < d) acc = acc + log(msc[k] + msc[k] - 1.0);   // lib/cov_se_fat.ml:128-131
+        val = exp(cp.log_sf2 + cp.inv_ell2_05 * acc);
+        valj = (het ? val + het[c] : val) + jitter;
+      } else {
+        const double* x = Z + (int64_t)r * d;
+        const double* msr = cp.ms + (int64_t)r * d;
+#pragma unroll
+        for (int k = 0; k < DT; ++k) {
+          if (k < d) {
+            const double diff = x[k] - z[k];
+            const double scale = (msr[k] + msc[k]) - 1.0;
+            acc = (acc + diff * (diff / scale)) + log(scale);
+          }
+        }
+        val = exp(cp.log_sf2 + cp.inv_ell2_05 * acc);
+        valj = val;
+      }
+    } else if (r == c) {
+      valj = 1.0;
+    }
+    km[(int64_t)r * mp + c] = val;
+    kj[(int64_t)r * mp + c] = valj;
+  }
+}
+
 template <int DT>
 __global__ __launch_bounds__(256) void cov_upper_kernel(CovParams cp, const double* __restrict__ Z,
                                                         int m, int mp, int d, double jitter,
@@ -121,8 +208,12 @@ void launch_cov_upper(const CovParams& cp, const double* Z, int m, int mp, int d
                       const double* het, double* km, double* kj, hipStream_t s) {
   dim3 grid(mp / 256 + (mp % 256 ? 1 : 0), (mp + 31) / 32);
   dispatch_dt(d, [&](auto dt) {
-    hipLaunchKernelGGL((cov_upper_kernel<decltype(dt)::value>), grid, dim3(256), 0, s, cp, Z, m, mp, d,
-                       jitter, het, km, kj);
+    if (cp.ms)
+      hipLaunchKernelGGL((cov_upper_ms_kernel<decltype(dt)::value>), grid, dim3(256), 0, s, cp, Z, m, mp,
+                         d, jitter, het, km, kj);
+    else
+      hipLaunchKernelGGL((cov_upper_kernel<decltype(dt)::value>), grid, dim3(256), 0, s, cp, Z, m, mp, d,
+                         jitter, het, km, kj);
   });
   GPR_HIP(hipGetLastError());
 }
@@ -132,8 +223,12 @@ void launch_cov_cross(const CovParams& cp, const double* pts, int rows, int rows
                       int m, int mp, int d, TS* K, hipStream_t s) {
   dim3 grid(mp / 256 + (mp % 256 ? 1 : 0), (rows_p + 31) / 32);
   dispatch_dt(d, [&](auto dt) {
-    hipLaunchKernelGGL((cov_cross_kernel<decltype(dt)::value, TS>), grid, dim3(256), 0, s, cp, pts, rows,
-                       rows_p, Z, m, mp, d, K);
+    if (cp.ms)
+      hipLaunchKernelGGL((cov_cross_ms_kernel<decltype(dt)::value, TS>), grid, dim3(256), 0, s, cp, pts,
+                         rows, rows_p, Z, m, mp, d, K);
+    else
+      hipLaunchKernelGGL((cov_cross_kernel<decltype(dt)::value, TS>), grid, dim3(256), 0, s, cp, pts, rows,
+                         rows_p, Z, m, mp, d, K);
   });
   GPR_HIP(hipGetLastError());
 }

@@ -114,6 +114,70 @@ __global__ __launch_bounds__(256) void km_traces_kernel(const double* __restrict
     if (k < d) p[(int64_t)(2 + k) * mp + c] = g[k];
 }
 
+template <int DT>
+__global__ __launch_bounds__(256) void km_traces_ms_kernel(const double* __restrict__ W,
+                                                           const double* __restrict__ km,
+                                                           const double* __restrict__ Z,
+                                                           const double* __restrict__ ms, int m, int mp, int d,
+                                                           double* __restrict__ part) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= mp) return;
+  const bool live = c < m;
+  double z[DT], msc[DT], g[DT], gm[DT];
+#pragma unroll
+  for (int k = 0; k < DT; ++k) {
+    z[k] = (k < d && live) ? Z[(int64_t)c * d + k] : 0.0;
+    msc[k] = (k < d && live) ? ms[(int64_t)c * d + k] : 1.0;
+    g[k] = 0.0;
+    gm[k] = 0.0;
+  }
+  double s0 = 0.0;
+  const int r0 = blockIdx.y * 256, r1 = min(m, r0 + 256);
+  if (live) {
+    for (int r = r0; r < r1; ++r) {
+      const double wk = W[(int64_t)r * mp + c] * km[(int64_t)r * mp + c];
+      s0 += wk;
+      if (r == c) continue;
+      const double* zr = Z + (int64_t)r * d;
+      const double* msr = ms + (int64_t)r * d;
+#pragma unroll
+      for (int k = 0; k < DT; ++k) {
+        if (k < d) {
+          const double iscale = 1.0 / ((msr[k] + msc[k]) - 1.0);
+          const double sdiff = (zr[k] - z[k]) * iscale;
+          g[k] += wk * sdiff;
+          gm[k] += wk * (iscale - sdiff * sdiff);
+        }
+      }
+    }
+  }
+  double* p = part + (int64_t)blockIdx.y * (2 * d + 2) * mp;
+  p[c] = s0;
+  p[(int64_t)mp + c] = 0.0;
+#pragma unroll
+  for (int k = 0; k < DT; ++k) {
+    if (k < d) {
+      p[(int64_t)(2 + k) * mp + c] = g[k];
+      p[(int64_t)(2 + d + k) * mp + c] = gm[k];
+    }
+  }
+}
+
+void launch_km_traces_ms(const double* W, const double* km, const double* Z, const double* ms, int m, int mp,
+                         int d, double* part, hipStream_t s) {
+  dim3 grid((mp + 255) / 256, (m + 255) / 256);
+  auto go = [&](auto dt) {
+    hipLaunchKernelGGL((km_traces_ms_kernel<decltype(dt)::value>), grid, dim3(256), 0, s, W, km, Z, ms, m, mp,
+                       d, part);
+  };
+  if (d <= 4) go(std::integral_constant<int, 4>{});
+  else if (d <= 8) go(std::integral_constant<int, 8>{});
+  else if (d <= 16) go(std::integral_constant<int, 16>{});
+  else if (d <= 32) go(std::integral_constant<int, 32>{});
+  else go(std::integral_constant<int, 64>{});
+  GPR_HIP(hipGetLastError());
+}
+
 void launch_km_traces(const double* W, const double* km, const double* Z, int m, int mp, int d,
                       double* part, double* /*unused*/, hipStream_t s) {
   dim3 grid((mp + 255) / 256, (m + 255) / 256);

@@ -114,8 +114,9 @@ struct gprhip_problem {
   int stage = 0;  // 0 idle, 1 pass1 done, 2 pass2 done
   bool have_inputs = false, have_targets = false;
   std::vector<double> hZ;  // host copy of inducing (padded point-major) for the gradient assembly
-  std::vector<double> hTproj, hHet;   // host copies: projection, exp(log_hetero_skedasticity)
-  double* het = nullptr;              // device copy of hHet
+  std::vector<double> hTproj, hHet, hMs;  // host copies: projection, exp(log_hetero), multiscales [mp][d]
+  double* het = nullptr;                  // device copy of hHet
+  double *ms = nullptr, *rowes = nullptr, *es2 = nullptr;  // multiscales [mp][d]; per-row E/ms partials
   Timer timer;
   std::vector<std::string> tnames;
   std::vector<float> tms;
@@ -139,7 +140,10 @@ struct gprhip_problem {
   int dbig() const { return kind == GPRHIP_COV_SE_FAT ? D : 0; }
   bool has_proj() const { return kind == GPRHIP_COV_SE_FAT && h.tproj != nullptr; }
   bool has_het() const { return kind == GPRHIP_COV_SE_FAT && h.log_hetero_skedasticity != nullptr; }
-  int64_t col_rows() const { return d + 1 + dbig(); }
+  bool has_ms() const { return kind == GPRHIP_COV_SE_FAT && h.log_multiscales_m05 != nullptr; }
+  int64_t km_rows() const { return d + 2 + (kind == GPRHIP_COV_SE_FAT ? d : 0); }
+  // exchange-2 column block: sum E, sum p_k E (d), sum x_big E (D), and for Cov_se_fat sum p_k^2 E (d)
+  int64_t col_rows() const { return d + 1 + dbig() + (kind == GPRHIP_COV_SE_FAT ? d : 0); }
 };
 
 namespace {
@@ -286,8 +290,22 @@ void upload_hypers(gprhip_problem* p, const gprhip_hypers* h) {
     GPR_HIP(hipMemcpyAsync(p->het, p->hHet.data(), (size_t)p->m * sizeof(double), hipMemcpyHostToDevice,
                            p->stream));
   }
+  if (h->log_multiscales_m05) {
+    if (p->kind == GPRHIP_COV_SE_ISO) {
+      set_error("gprhip: log_multiscales_m05 given for Cov_se_iso");
+      throw HipFail{ST_BAD_ARG};
+    }
+    // Kernel.create: exp v +. 0.5, lib/cov_se_fat.ml:66-69 ; Fortran d x m == [m][d]; padding rows 1
+    p->hMs.assign((size_t)p->mp * p->d, 1.0);
+    for (int64_t i = 0; i < (int64_t)p->m * p->d; ++i) p->hMs[i] = std::exp(h->log_multiscales_m05[i]) + 0.5;
+    p->h.log_multiscales_m05 = p->hMs.data();  // presence flag from here on
+    if (!p->ms) p->ms = p->alloc<double>((int64_t)p->mp * p->d);
+    GPR_HIP(hipMemcpyAsync(p->ms, p->hMs.data(), p->hMs.size() * sizeof(double), hipMemcpyHostToDevice,
+                           p->stream));
+  }
   CovParams& cp = p->cp;
   cp.kind = p->kind;
+  cp.ms = h->log_multiscales_m05 ? p->ms : nullptr;
   cp.log_sf2 = h->log_sf2;
   cp.sf2 = std::exp(h->log_sf2);
   if (p->kind == GPRHIP_COV_SE_ISO) {
@@ -502,12 +520,28 @@ void do_pass2(gprhip_problem* p, const double* ar1, double* ar2) {
       ga.log_sf2 = p->cp.log_sf2; ga.inv_ell2_05 = p->cp.inv_ell2_05;
       ga.colpart = p->colpart; ga.scalpart = p->scalpart;
       ga.big = proj ? p->X + base * p->D : nullptr; ga.D = proj ? p->D : 0;
+      ga.ms = p->cp.ms; ga.rowes = nullptr;
+      ga.col_rows = p->d + 1 + ga.D + (ga.ms ? p->d : 0);  // rows this launch produces (tightly packed)
+      const int nslots = 4 * ((mp + 255) / 256);
+      if (ga.ms && proj) {
+        if (!p->rowes) {
+          p->rowes = p->alloc<double>(p->chunk * nslots * p->d);
+          p->es2 = p->alloc<double>(p->chunk * p->d);
+        }
+        ga.rowes = p->rowes;
+      }
       launch_grad_fused(ga, s);
       const int nslabs = (int)((rows + grad_slab_rows() - 1) / grad_slab_rows());
-      launch_reduce_rows(p->colpart, nslabs, (p->d + 1 + ga.D) * mp, ar2_col, 1, s);
+      launch_reduce_rows(p->colpart, nslabs, ga.col_rows * mp, ar2_col, 1, s);
       if (proj) {
-        launch_proj_term2(p->X + base * p->D, p->P + base * p->d, p->es + base, (int)rows, p->D, p->d,
-                          p->projpart, s);
+        if (ga.ms) {
+          launch_reduce_rowes(p->rowes, (int)rows, nslots, p->d, p->es2, s);
+          launch_proj_term2(p->X + base * p->D, p->P + base * p->d, p->es2, p->d, (int)rows, p->D, p->d,
+                            p->projpart, s);
+        } else {
+          launch_proj_term2(p->X + base * p->D, p->P + base * p->d, p->es + base, 1, (int)rows, p->D, p->d,
+                            p->projpart, s);
+        }
         launch_reduce_rows(p->projpart, (int)((rows + 255) / 256), p->D * p->d, ar2_proj, 1, s);
       }
       launch_reduce_rows(p->scalpart, nslabs * ((mp + 255) / 256), 2, ar2_tail + A2_SUME, 1, s);
@@ -551,8 +585,13 @@ void do_finish(gprhip_problem* p, const double* ar2, gprhip_result* res, double*
     w.A = p->uinv; w.lda = mp; w.B = p->bmat; w.ldb = mp; w.C = p->wmat; w.ldc = mp;
     w.M = mp; w.N = mp; w.K = mp; w.tri = TRI_KLO_BM;
     launch_gemm(OP_NN, w, s);
-    launch_km_traces(p->wmat, p->km, p->Z, m, mp, d, p->kmpart, nullptr, s);
-    launch_reduce_rows(p->kmpart, nkslab, (d + 2) * mp, p->kmred, 0, s);
+    if (p->has_ms()) {
+      launch_km_traces_ms(p->wmat, p->km, p->Z, p->ms, m, mp, d, p->kmpart, s);
+      launch_reduce_rows(p->kmpart, nkslab, (2 * d + 2) * mp, p->kmred, 0, s);
+    } else {
+      launch_km_traces(p->wmat, p->km, p->Z, m, mp, d, p->kmpart, nullptr, s);
+      launch_reduce_rows(p->kmpart, nkslab, (d + 2) * mp, p->kmred, 0, s);
+    }
     tstop(p);
   }
   std::vector<double> hscal(NSCAL), htail(A2_TAIL), ha1tail(A1_TAIL), ht(mp);
@@ -564,12 +603,12 @@ void do_finish(gprhip_problem* p, const double* ar2, gprhip_result* res, double*
   GPR_HIP(hipMemcpyAsync(hinfo, p->info, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
   if (p->want_grad) {
     hcol.resize((size_t)(p->col_rows() * mp + (int64_t)p->dbig() * d));  // column block + Proj second term
-    hkm.resize((size_t)(d + 2) * mp);
+    hkm.resize((size_t)p->km_rows() * mp);
     GPR_HIP(hipMemcpyAsync(hcol.data(), ar2_col, hcol.size() * sizeof(double), hipMemcpyDeviceToHost, s));
     GPR_HIP(hipMemcpyAsync(hkm.data(), p->kmred, hkm.size() * sizeof(double), hipMemcpyDeviceToHost, s));
   }
   std::vector<double> hwdiag;
-  if (p->want_grad && p->has_het()) {  // W_ii for the `Diag_vec derivative
+  if (p->want_grad && (p->has_het() || p->has_ms())) {  // W_ii for the `Diag_vec / multiscale diagonal terms
     hwdiag.resize(m);
     GPR_HIP(hipMemcpy2DAsync(hwdiag.data(), sizeof(double), p->wmat, (size_t)(mp + 1) * sizeof(double),
                              sizeof(double), (size_t)m, hipMemcpyDeviceToHost, s));
@@ -626,17 +665,22 @@ void do_finish(gprhip_problem* p, const double* ar2, gprhip_result* res, double*
     grad[pos++] = g_sf2;
   }
   // Inducing_hyper {ind; dim}: dkm `Sparse_rows -> 2*scale*sum_{r!=c} W_rc K_rc (z_kr - z_kc)
-  // (lib/utils.ml:196-220); dknm `Sparse_cols -> scale*sum_r (x_kr - z_kc) E_rc
+  // (lib/utils.ml:196-220); dknm `Sparse_cols -> scale*sum_r (x_kr - z_kc) E_rc.  With multiscales the
+  // row entries carry 1/(ms_kr + ms_kc - 1) (already inside the trace kernel) and the column 1/ms_kc
+  // (lib/cov_se_fat.ml:501-513, :633-638).
+  const bool msm = p->has_ms();
+  const int Dp = p->has_proj() ? p->D : 0;
   for (int c = 0; c < m; ++c) {
     for (int k = 0; k < d; ++k) {
       const double zk = p->hZ[(size_t)c * d + k];
       const double dkm_half = scale * hkm[(size_t)(2 + k) * mp + c];
-      const double dknm = scale * (hcol[(size_t)(k + 1) * mp + c] - zk * hcol[c]);
+      double dknm = scale * (hcol[(size_t)(k + 1) * mp + c] - zk * hcol[c]);
+      if (msm) dknm /= p->hMs[(size_t)c * d + k];
       grad[pos++] = dkm_half - dknm;
     }
   }
   // Proj {big_dim; small_dim} (lib/cov_se_fat.ml:429, :531, :570-596): dkm, dkn_diag `Const 0.;
-  // dknm `Dense x_big,r (z_small,c - p_small,r) K_rc
+  // dknm `Dense x_big,r (z_small,c - p_small,r) [/ ms_small,c] K_rc
   if (p->has_proj()) {
     const int D = p->D;
     const double* m1 = hcol.data() + (size_t)(d + 1) * mp;       // [big][c] = sum_r x_big,r E_rc
@@ -644,7 +688,11 @@ void do_finish(gprhip_problem* p, const double* ar2, gprhip_result* res, double*
     for (int big = 0; big < D; ++big) {
       for (int small = 0; small < d; ++small) {
         double term1 = 0.0;
-        for (int c = 0; c < m; ++c) term1 += p->hZ[(size_t)c * d + small] * m1[(size_t)big * mp + c];
+        for (int c = 0; c < m; ++c) {
+          double zz = p->hZ[(size_t)c * d + small];
+          if (msm) zz /= p->hMs[(size_t)c * d + small];
+          term1 += zz * m1[(size_t)big * mp + c];
+        }
         grad[pos++] = -(term1 - term2[(size_t)big * d + small]);
       }
     }
@@ -653,6 +701,25 @@ void do_finish(gprhip_problem* p, const double* ar2, gprhip_result* res, double*
   //   -> dl = 1/2 het_i W_ii   (lib/fitc_gp.ml:962-967)
   if (p->has_het())
     for (int i = 0; i < m; ++i) grad[pos++] = 0.5 * p->hHet[i] * hwdiag[i];
+  // Log_multiscale_m05 {ind; dim} (lib/cov_se_fat.ml:441-485, :598-622), theta = log(ms - 1/2):
+  //   dkm `Sparse_rows: inner_i K_i,ind for i != ind, (1/2 - ms)/(2 ms - 1) K_ind,ind on the diagonal
+  //   dknm `Sparse_cols: inner_r K_r,ind with inner = (1/ms - ((p_kr - z_kc)/ms)^2) * (1/2)(1/2 - ms)
+  if (msm) {
+    const double* gxx = hcol.data() + (size_t)(d + 1 + Dp) * mp;   // [k][c] = sum_r p_kr^2 E_rc
+    for (int c = 0; c < m; ++c) {
+      double lsum = 0.0;  // K_cc without heteroskedastic noise: exp(log_sf2 - 1/2 sum log(2 ms - 1))
+      for (int k = 0; k < d; ++k) lsum += std::log(2.0 * p->hMs[(size_t)c * d + k] - 1.0);
+      const double kcc = std::exp(p->cp.log_sf2 - 0.5 * lsum);
+      for (int k = 0; k < d; ++k) {
+        const double msk = p->hMs[(size_t)c * d + k], zk = p->hZ[(size_t)c * d + k];
+        const double mh = 0.5 - msk, factor = 0.5 * mh;
+        const double dkm = 2.0 * factor * hkm[(size_t)(2 + d + k) * mp + c] + hwdiag[c] * mh / (2.0 * msk - 1.0) * kcc;
+        const double colE = hcol[c], gx = hcol[(size_t)(k + 1) * mp + c], g2 = gxx[(size_t)k * mp + c];
+        const double dknm = factor * (colE / msk - (g2 - 2.0 * zk * gx + zk * zk * colE) / (msk * msk));
+        grad[pos++] = 0.5 * dkm - dknm;
+      }
+    }
+  }
   res->n_hypers = pos;
 }
 
@@ -821,8 +888,8 @@ int gprhip_problem_create_ex(int device, int cov_kind, int precision, int64_t n,
     const int64_t nslab = (chunk + grad_slab_rows() - 1) / grad_slab_rows();
     p->colpart = p->alloc<double>(nslab * p->col_rows() * mp);
     p->scalpart = p->alloc<double>(nslab * ((mp + 255) / 256) * 2);
-    p->kmpart = p->alloc<double>((int64_t)((m + 255) / 256) * (d + 2) * mp);
-    p->kmred = p->alloc<double>((int64_t)(d + 2) * mp);
+    p->kmpart = p->alloc<double>((int64_t)((m + 255) / 256) * p->km_rows() * mp);
+    p->kmred = p->alloc<double>(p->km_rows() * mp);
     p->ar1 = p->alloc<double>(mm + mp + A1_TAIL);
     p->ar2 = p->alloc<double>(gprhip_ar2_len(p));
     GPR_HIP(hipMemsetAsync(p->y, 0, (size_t)npad * sizeof(double), p->stream));
@@ -900,7 +967,8 @@ int gprhip_set_targets_device(gprhip_problem* p, const double* d_targets) {
 int64_t gprhip_n_hypers(const gprhip_problem* p, int flags) {
   if (!p) return 0;
   if (p->kind == GPRHIP_COV_SE_ISO) return 2 + (int64_t)p->d * p->m;
-  return 1 + (int64_t)p->d * p->m + ((flags & 1) ? (int64_t)p->D * p->d : 0) + ((flags & 2) ? p->m : 0);
+  return 1 + (int64_t)p->d * p->m + ((flags & 1) ? (int64_t)p->D * p->d : 0) + ((flags & 2) ? p->m : 0) +
+         ((flags & 4) ? (int64_t)p->d * p->m : 0);
 }
 
 int64_t gprhip_ar1_len(const gprhip_problem* p) { return (int64_t)p->mp * p->mp + p->mp + A1_TAIL; }

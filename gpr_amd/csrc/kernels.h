@@ -16,6 +16,7 @@ struct CovParams {
   double log_sf2, sf2;  // lib/cov_se_iso.ml:41-44 / lib/cov_se_fat.ml:62-75
   double inv_ell2;      // iso: exp(-2 log_ell); fat: 1
   double inv_ell2_05;   // iso: -0.5*inv_ell2;   fat: -0.5
+  const double* ms;     // Cov_se_fat multiscales exp(log_multiscales_m05)+0.5 as [mp][d] (padding 1), or null
 };
 
 // K_m (lib/cov_se_iso.ml:56-87, lib/cov_se_fat.ml:85-100): km = covariance (padding rows/cols 0),
@@ -114,13 +115,19 @@ struct GradArgs {
   double log_sf2, inv_ell2_05;  // K_rc = exp(log_sf2 + inv_ell2_05*|x_r - z_c|^2) is recomputed on the fly
   const double* big;     // [rows][D] original inputs of the chunk (Cov_se_fat with tproj), else null
   int D;                 // big dimension (0 when big == null)
-  double* colpart;       // out [nslabs][(d+1+D)][mp]: row 0 = column sums of E, rows 1..d = sum_r p_kr E_rc,
-                         //     rows d+1.. = sum_r x_big,r E_rc
+  double* colpart;       // out [nslabs][col_rows][mp]: row 0 = column sums of E, rows 1..d = sum_r p_kr E_rc,
+                         //     rows d+1..d+D = sum_r x_big,r E_rc, then (multiscales) d rows sum_r p_kr^2 E_rc
+  int col_rows;          // rows of one slab of colpart
   double* scalpart;      // out [nslabs][nbx][2]: sum E, sum E*sqr_diff
+  const double* ms;      // multiscales [mp][d] or null (Cov_se_fat)
+  double* rowes;         // multiscales + tproj: out [rows][nslots][d] partial sum_c E_rc / ms_kc, nslots = 4*gridDim.x
 };
 // part[slab][big*d + small] = sum_{r in slab} x_big,r * p_small,r * es_r   (slab = 256 rows)
-void launch_proj_term2(const double* X, const double* P, const double* es, int rows, int D, int d,
+// es_ld == 1: one weight per row; es_ld == d: one per (row, small) (multiscales)
+void launch_proj_term2(const double* X, const double* P, const double* es, int es_ld, int rows, int D, int d,
                        double* part, hipStream_t s);
+// es[row][k] = sum_slot rowes[row][slot][k]
+void launch_reduce_rowes(const double* rowes, int rows, int nslots, int d, double* es, hipStream_t s);
 int grad_slab_rows();
 template <typename TS>
 void launch_grad_fused(const GradArgs<TS>& a, hipStream_t s);
@@ -141,5 +148,10 @@ void launch_build_w(const double* binv, const double* t, const double* G, int mp
 // q = 1: sum_r W_rc K_rc |z_r - z_c|^2, q = 2+k: sum_r W_rc K_rc (z_kr - z_kc).  W, km full symmetric.
 void launch_km_traces(const double* W, const double* km, const double* Z, int m, int mp, int d,
                       double* part, double* unused, hipStream_t s);
+// Multiscale variant (lib/cov_se_fat.ml:441-516): part[slab][q][c] with q = 0: sum_r W_rc K_rc,
+// q = 2+k: sum_{r!=c} W_rc K_rc (z_kr - z_kc)/(ms_kr + ms_kc - 1),
+// q = 2+d+k: sum_{r!=c} W_rc K_rc (iscale - sdiff^2), iscale = 1/(ms_kr + ms_kc - 1), sdiff = (z_kr - z_kc) iscale
+void launch_km_traces_ms(const double* W, const double* km, const double* Z, const double* ms, int m, int mp,
+                         int d, double* part, hipStream_t s);
 
 }  // namespace gprhip

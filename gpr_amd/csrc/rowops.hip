@@ -341,7 +341,7 @@ __global__ __launch_bounds__(256) void grad_fused_kernel(GradArgs<TS> a) {
     }
   }
   if (j < a.mp) {
-    double* cp = a.colpart + (int64_t)blockIdx.y * (a.d + 1 + a.D) * a.mp;
+    double* cp = a.colpart + (int64_t)blockIdx.y * a.col_rows * a.mp;
     cp[j] = cs;
 #pragma unroll
     for (int k = 0; k < DT; ++k)
@@ -366,30 +366,161 @@ __global__ __launch_bounds__(256) void grad_fused_kernel(GradArgs<TS> a) {
   }
 }
 
+// Multiscale variant of the fused gradient pass (Cov_se_fat with log_multiscales_m05):
+//   K_rc = exp(log_sf2 - 1/2 sum_k [(p_kr - z_kc)^2 / ms_kc + log ms_kc])        lib/cov_se_fat.ml:241-251
+// extra column accumulators sum_r p_kr^2 E_rc (for `Log_multiscale_m05, :598-622) and, when a projection is
+// optimised too, per-row partial sums of E_rc / ms_kc over this wavefront's columns (`Proj with
+// multiscales, :585-595), reduced across wavefronts by launch_reduce_rowes.
+template <int DT, int DBT, typename TS>
+__global__ __launch_bounds__(256) void grad_fused_ms_kernel(GradArgs<TS> a) {
+  __shared__ double red[4];
+  __shared__ double xs[32][DT];
+  __shared__ double xbs[32][DBT > 0 ? DBT : 1];
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  const int jj = min(j, a.mp - 1);
+  const bool live = (j < a.m);
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int nslots = 4 * gridDim.x, slot = 4 * blockIdx.x + wv;
+  double z[DT], isc[DT], gx[DT], gxx[DT];
+  double gb[DBT > 0 ? DBT : 1];
+  double lsum = 0.0;
+#pragma unroll
+  for (int k = 0; k < DT; ++k) {
+    const bool lk = (k < a.d && live);
+    z[k] = lk ? a.Z[(int64_t)jj * a.d + k] : 0.0;
+    const double sc = lk ? a.ms[(int64_t)jj * a.d + k] : 1.0;
+    isc[k] = 1.0 / sc;
+    lsum += log(sc);
+    gx[k] = 0.0;
+    gxx[k] = 0.0;
+  }
+#pragma unroll
+  for (int k = 0; k < DBT; ++k) gb[k] = 0.0;
+  double cs = 0.0, sE = 0.0;
+  const int r0 = blockIdx.y * GRAD_SLAB;
+  const int r1 = min(a.rows, r0 + GRAD_SLAB);
+  for (int rb = r0; rb < r1; rb += 32) {
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < 32 * DT; idx += 256) {
+      const int r = idx / DT, k = idx % DT;
+      xs[r][k] = (k < a.d && rb + r < r1) ? a.pts[(int64_t)(rb + r) * a.d + k] : 0.0;
+    }
+    if (DBT > 0) {
+      for (int idx = threadIdx.x; idx < 32 * DBT; idx += 256) {
+        const int r = idx / DBT, k = idx % DBT;
+        xbs[r][k] = (k < a.D && rb + r < r1) ? a.big[(int64_t)(rb + r) * a.D + k] : 0.0;
+      }
+    }
+    __syncthreads();
+    const int nr = min(32, r1 - rb);
+    for (int i = 0; i < nr; ++i) {
+      const double xv = (double)a.X[(int64_t)(rb + i) * a.mp + jj];
+      double dist = lsum;
+#pragma unroll
+      for (int k = 0; k < DT; ++k) {
+        const double df = xs[i][k] - z[k];
+        dist += df * df * isc[k];
+      }
+      const double e = live ? xv * exp(a.log_sf2 + a.inv_ell2_05 * dist) : 0.0;
+#pragma unroll
+      for (int k = 0; k < DT; ++k) {
+        gx[k] += xs[i][k] * e;
+        gxx[k] += xs[i][k] * xs[i][k] * e;
+      }
+#pragma unroll
+      for (int k = 0; k < DBT; ++k) gb[k] += xbs[i][k] * e;
+      if (DBT > 0) {
+        double* ro = a.rowes + ((int64_t)(rb + i) * nslots + slot) * a.d;
+#pragma unroll
+        for (int k = 0; k < DT; ++k) {
+          if (k < a.d) {
+            const double t = wave_sum(e * isc[k]);
+            if (lane == 0) ro[k] = t;
+          }
+        }
+      }
+      cs += e;
+      sE += e;
+    }
+  }
+  if (j < a.mp) {
+    double* cp = a.colpart + (int64_t)blockIdx.y * a.col_rows * a.mp;
+    cp[j] = cs;
+#pragma unroll
+    for (int k = 0; k < DT; ++k) {
+      if (k < a.d) {
+        cp[(int64_t)(k + 1) * a.mp + j] = gx[k];
+        cp[(int64_t)(a.d + 1 + a.D + k) * a.mp + j] = gxx[k];
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < DBT; ++k)
+      if (k < a.D) cp[(int64_t)(a.d + 1 + k) * a.mp + j] = gb[k];
+  }
+  sE = wave_sum(sE);
+  __syncthreads();
+  if (lane == 0) red[wv] = sE;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double* sp = a.scalpart + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 2;
+    sp[0] = (red[0] + red[1]) + (red[2] + red[3]);
+    sp[1] = 0.0;
+  }
+}
+
+__global__ __launch_bounds__(256) void reduce_rowes_kernel(const double* __restrict__ rowes, int rows,
+                                                           int nslots, int d, double* __restrict__ es) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (int64_t)rows * d) return;
+  const int64_t r = idx / d;
+  const int k = (int)(idx % d);
+  double acc = 0.0;
+  for (int sl = 0; sl < nslots; ++sl) acc += rowes[(r * nslots + sl) * d + k];
+  es[idx] = acc;
+}
+
+void launch_reduce_rowes(const double* rowes, int rows, int nslots, int d, double* es, hipStream_t s) {
+  hipLaunchKernelGGL(reduce_rowes_kernel, dim3((unsigned)(((int64_t)rows * d + 255) / 256)), dim3(256), 0, s,
+                     rowes, rows, nslots, d, es);
+  GPR_HIP(hipGetLastError());
+}
+
 // Cov_se_fat `Proj {big; small}` (lib/cov_se_fat.ml:570-596): second term of
 //   -tr(X^T dK) = -[ sum_c z_small,c sum_r x_big,r E_rc  -  sum_r x_big,r p_small,r rowsum(E)_r ]
 __global__ __launch_bounds__(256) void proj_term2_kernel(const double* __restrict__ X,
                                                          const double* __restrict__ P,
-                                                         const double* __restrict__ es, int rows, int D,
-                                                         int d, double* __restrict__ part) {
+                                                         const double* __restrict__ es, int es_ld, int rows,
+                                                         int D, int d, double* __restrict__ part) {
   const int r0 = blockIdx.y * 256, r1 = min(rows, r0 + 256);
   for (int idx = blockIdx.x * 256 + threadIdx.x; idx < D * d; idx += gridDim.x * 256) {
     const int big = idx / d, small = idx % d;
     double acc = 0.0;
-    for (int r = r0; r < r1; ++r) acc += X[(int64_t)r * D + big] * P[(int64_t)r * d + small] * es[r];
+    const int eo = es_ld > 1 ? small : 0;
+    for (int r = r0; r < r1; ++r)
+      acc += X[(int64_t)r * D + big] * P[(int64_t)r * d + small] * es[(int64_t)r * es_ld + eo];
     part[(int64_t)blockIdx.y * D * d + idx] = acc;
   }
 }
 
-void launch_proj_term2(const double* X, const double* P, const double* es, int rows, int D, int d,
+void launch_proj_term2(const double* X, const double* P, const double* es, int es_ld, int rows, int D, int d,
                        double* part, hipStream_t s) {
   dim3 grid((D * d + 255) / 256, (rows + 255) / 256);
-  hipLaunchKernelGGL(proj_term2_kernel, grid, dim3(256), 0, s, X, P, es, rows, D, d, part);
+  hipLaunchKernelGGL(proj_term2_kernel, grid, dim3(256), 0, s, X, P, es, es_ld, rows, D, d, part);
   GPR_HIP(hipGetLastError());
 }
 
 template <int DT, typename TS>
 static void grad_dispatch_big(const GradArgs<TS>& a, dim3 grid, hipStream_t s) {
+  if (a.ms) {
+    if (!a.big) hipLaunchKernelGGL((grad_fused_ms_kernel<DT, 0, TS>), grid, dim3(256), 0, s, a);
+    else if (a.D <= 8) hipLaunchKernelGGL((grad_fused_ms_kernel<DT, 8, TS>), grid, dim3(256), 0, s, a);
+    else if (a.D <= 32) hipLaunchKernelGGL((grad_fused_ms_kernel<DT, 32, TS>), grid, dim3(256), 0, s, a);
+    else {
+      set_error("gprhip: Cov_se_fat multiscales with tproj support input dimension D <= 32");
+      throw HipFail{ST_BAD_ARG};
+    }
+    return;
+  }
   if (!a.big) hipLaunchKernelGGL((grad_fused_kernel<DT, 0, TS>), grid, dim3(256), 0, s, a);
   else if (a.D <= 8) hipLaunchKernelGGL((grad_fused_kernel<DT, 8, TS>), grid, dim3(256), 0, s, a);
   else if (a.D <= 32) hipLaunchKernelGGL((grad_fused_kernel<DT, 32, TS>), grid, dim3(256), 0, s, a);

@@ -76,11 +76,12 @@ class Problem:
         _lib.check(self._lib.gprhip_set_targets_device(self._h, C.c_void_p(ptr)))
 
     # ---- evaluation
-    def n_hypers(self, has_tproj=False, has_hetero=False):
-        return int(self._lib.gprhip_n_hypers(self._h, int(has_tproj) | (int(has_hetero) << 1)))
+    def n_hypers(self, has_tproj=False, has_hetero=False, has_multiscale=False):
+        flags = int(has_tproj) | (int(has_hetero) << 1) | (int(has_multiscale) << 2)
+        return int(self._lib.gprhip_n_hypers(self._h, flags))
 
     def _hypers(self, log_ell, log_sf2, sigma2, inducing, tproj, variational, model_only, jitter,
-                log_hetero_skedasticity=None):
+                log_hetero_skedasticity=None, log_multiscales_m05=None):
         z = np.asfortranarray(inducing, dtype=np.float64)
         if z.shape != (self.d, self.m):
             raise ValueError("inducing: expected shape (%d, %d), got %s" % (self.d, self.m, z.shape))
@@ -101,14 +102,21 @@ class Problem:
                 raise ValueError("log_hetero_skedasticity: expected %d entries" % self.m)
             h.log_hetero_skedasticity = _f64_ptr(lh)
             keep.append(lh)
+        if log_multiscales_m05 is not None:
+            lm = np.asfortranarray(log_multiscales_m05, dtype=np.float64)
+            if lm.shape != (self.d, self.m):
+                raise ValueError("log_multiscales_m05: expected shape (%d, %d)" % (self.d, self.m))
+            h.log_multiscales_m05 = _f64_ptr(lm)
+            keep.append(lm)
         return h, keep
 
     def eval(self, *, log_sf2, sigma2, inducing, log_ell=0.0, tproj=None, variational=False,
-             model_only=False, want_grad=True, jitter=CHOLESKY_JITTER, log_hetero_skedasticity=None):
+             model_only=False, want_grad=True, jitter=CHOLESKY_JITTER, log_hetero_skedasticity=None,
+             log_multiscales_m05=None):
         h, keep = self._hypers(log_ell, log_sf2, sigma2, inducing, tproj, variational, model_only, jitter,
-                               log_hetero_skedasticity)
+                               log_hetero_skedasticity, log_multiscales_m05)
         res = Result()
-        nh = self.n_hypers(tproj is not None, log_hetero_skedasticity is not None)
+        nh = self.n_hypers(tproj is not None, log_hetero_skedasticity is not None, log_multiscales_m05 is not None)
         grad = np.empty(nh if want_grad else 1, dtype=np.float64)
         coeffs = np.empty(self.m, dtype=np.float64)
         _lib.check(self._lib.gprhip_eval(self._h, C.byref(h), int(want_grad), C.byref(res),
@@ -140,9 +148,10 @@ class Problem:
 
     def eval_pass1(self, ar1_ptr, n_total, *, log_sf2, sigma2, inducing, log_ell=0.0, tproj=None,
                    variational=False, model_only=False, want_grad=True, jitter=CHOLESKY_JITTER,
-                   log_hetero_skedasticity=None):
+                   log_hetero_skedasticity=None, log_multiscales_m05=None):
         h, keep = self._hypers(log_ell, log_sf2, sigma2, inducing, tproj, variational, model_only, jitter,
-                               log_hetero_skedasticity)
+                               log_hetero_skedasticity, log_multiscales_m05)
+        self._has_ms = log_multiscales_m05 is not None
         self._want_grad = bool(want_grad)
         self._has_tproj = tproj is not None
         self._has_het = log_hetero_skedasticity is not None
@@ -155,7 +164,7 @@ class Problem:
 
     def eval_finish(self, ar2_ptr):
         res = Result()
-        nh = self.n_hypers(self._has_tproj, self._has_het)
+        nh = self.n_hypers(self._has_tproj, self._has_het, self._has_ms)
         grad = np.empty(nh if self._want_grad else 1, dtype=np.float64)
         coeffs = np.empty(self.m, dtype=np.float64)
         _lib.check(self._lib.gprhip_eval_finish(self._h, C.c_void_p(ar2_ptr), C.byref(res),

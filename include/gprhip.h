@@ -81,7 +81,9 @@ int gprhip_set_targets_device(gprhip_problem* p, const double* d_targets);
  *   model_only : 1 = evidence/gradient of the model without targets (Deriv.Model.*), 0 = Trained.*
  *   jitter     : Utils.cholesky_jitter (lib/utils.ml:35); pass 1e-6 for the reference behaviour
  *   log_hetero_skedasticity : Cov_se_fat.Params.log_hetero_skedasticity (m entries) or NULL:
- *                exp() of it is added to diag(K_m)                             lib/cov_se_fat.ml:136-142 */
+ *                exp() of it is added to diag(K_m)                             lib/cov_se_fat.ml:136-142
+ *   log_multiscales_m05 : Cov_se_fat.Params.log_multiscales_m05 (Fortran d x m) or NULL: per inducing point
+ *                and dimension a length scale exp(.)+0.5                        lib/cov_se_fat.ml:66-69, :115-134 */
 typedef struct {
   double log_ell;
   double log_sf2;
@@ -92,12 +94,13 @@ typedef struct {
   int model_only;
   double jitter;
   const double* log_hetero_skedasticity;
+  const double* log_multiscales_m05;
 } gprhip_hypers;
 
 /* Results.  Gradient order is the reference's Hyper.get_all order:
  *   Cov_se_iso: [Log_ell; Log_sf2; Inducing_hyper{ind=1,dim=1..d}; {ind=2,..}; ...]   lib/cov_se_iso.ml:188-202
  *   Cov_se_fat: [Log_sf2; Inducing_hyper (ind-major); Proj{big_dim,small_dim} (big-major);
- *                Log_hetero_skedasticity 1..m]                                  lib/cov_se_fat.ml:290-342
+ *                Log_hetero_skedasticity 1..m; Log_multiscale_m05 (ind-major)]  lib/cov_se_fat.ml:290-342
  * l1 = Model.calc_log_evidence, l = Trained.calc_log_evidence, dl_dsigma2 = calc_log_evidence_sigma2. */
 typedef struct {
   double l1;
@@ -107,7 +110,7 @@ typedef struct {
   int64_t n_hypers;
 } gprhip_result;
 
-/* flags: bit 0 = tproj given, bit 1 = log_hetero_skedasticity given */
+/* flags: bit 0 = tproj given, bit 1 = log_hetero_skedasticity given, bit 2 = log_multiscales_m05 given */
 int64_t gprhip_n_hypers(const gprhip_problem* p, int flags);
 
 /* One complete evaluation on one device (shard == whole problem).

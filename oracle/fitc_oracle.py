@@ -121,21 +121,26 @@ def se_iso_hypers(d, m):
 # ---------------------------------------------------------------------------
 @dataclass
 class SeFatKernel:
-    """lib/cov_se_fat.ml:55-75 with log_multiscales_m05 = None; heteroskedastic noise on
-    diag(K_m) optional (lib/cov_se_fat.ml:136-142)."""
+    """lib/cov_se_fat.ml:55-75: projection, heteroskedastic noise on diag(K_m) (:136-142) and
+    multiscales (:115-134, :241-251) are all optional."""
 
     d: int
     log_sf2: float
     tproj: Optional[np.ndarray]  # big_dim x d, or None
     log_hetero_skedasticity: Optional[np.ndarray] = None  # m, or None
+    log_multiscales_m05: Optional[np.ndarray] = None      # d x m, or None
     sf2: float = field(init=False)
     hetero_skedasticity: Optional[np.ndarray] = field(init=False, default=None)
+    multiscales: Optional[np.ndarray] = field(init=False, default=None)
 
     def __post_init__(self):
         self.sf2 = math.exp(self.log_sf2)
         if self.log_hetero_skedasticity is not None:
             self.log_hetero_skedasticity = np.asarray(self.log_hetero_skedasticity, dtype=np.float64)
             self.hetero_skedasticity = np.exp(self.log_hetero_skedasticity)  # lib/cov_se_fat.ml:63-65
+        if self.log_multiscales_m05 is not None:
+            self.log_multiscales_m05 = _F(self.log_multiscales_m05)
+            self.multiscales = _F(np.exp(self.log_multiscales_m05) + 0.5)    # lib/cov_se_fat.ml:66-69
         if self.tproj is not None:
             self.tproj = _F(self.tproj)
             if self.tproj.shape[1] != self.d:  # lib/cov_se_fat.ml:38-48
@@ -163,17 +168,40 @@ def se_fat_calc_upper_vanilla(k: SeFatKernel, mat):
     return _F(res)
 
 
+def se_fat_calc_upper_multiscale(k: SeFatKernel, inducing):
+    """lib/cov_se_fat.ml:115-134: off-diagonal sum_i diff*(diff/scale) + log scale with
+    scale = ms[i,r] + ms[i,c] - 1; diagonal sum_i log(2 ms[i,c] - 1)."""
+    ms = k.multiscales
+    m = inducing.shape[1]
+    acc = np.zeros((m, m), order="F")
+    for i in range(k.d):
+        diff = inducing[i, :][:, None] - inducing[i, :][None, :]
+        scale = ms[i, :][:, None] + ms[i, :][None, :] - 1.0
+        acc = acc + diff * (diff / scale) + np.log(scale)
+    res = np.exp(k.log_sf2 - 0.5 * acc)
+    dacc = np.zeros(m)
+    for i in range(k.d):
+        dacc = dacc + np.log(ms[i, :] + ms[i, :] - 1.0)
+    res[np.diag_indices(m)] = np.exp(k.log_sf2 - 0.5 * dacc)
+    res[np.tril_indices(m, -1)] = np.nan
+    return _F(res)
+
+
 def se_fat_calc_cross_with_projections(k: SeFatKernel, projections, inducing):
-    """lib/cov_se_fat.ml:224-240 (multiscales = None branch)."""
+    """lib/cov_se_fat.ml:224-252."""
     acc = np.zeros((projections.shape[1], inducing.shape[1]), order="F")
     for i in range(k.d):
         diff = projections[i, :][:, None] - inducing[i, :][None, :]
-        acc += diff * diff
+        if k.multiscales is None:
+            acc += diff * diff
+        else:  # update_tmp_sum, lib/cov_se_fat.ml:102-103
+            scale = k.multiscales[i, :][None, :]
+            acc = acc + diff * (diff / scale) + np.log(scale)
     return _F(np.exp(k.log_sf2 - 0.5 * acc))
 
 
 def se_fat_hypers(k: SeFatKernel, m):
-    """lib/cov_se_fat.ml:290-342: [Log_sf2; inducing (ind-major); Proj (big_dim-major); hetero]."""
+    """lib/cov_se_fat.ml:290-342: [Log_sf2; inducing (ind-major); Proj (big_dim-major); hetero; multiscale]."""
     hypers = [("log_sf2",)]
     for ind in range(1, m + 1):
         for dim in range(1, k.d + 1):
@@ -185,6 +213,10 @@ def se_fat_hypers(k: SeFatKernel, m):
     if k.hetero_skedasticity is not None:
         for i in range(1, len(k.hetero_skedasticity) + 1):
             hypers.append(("log_hetero", i))
+    if k.multiscales is not None:
+        for ind in range(1, k.multiscales.shape[1] + 1):
+            for dim in range(1, k.d + 1):
+                hypers.append(("log_multiscale", ind, dim))
     return hypers
 
 
@@ -199,7 +231,8 @@ def spec_calc_shared_upper(k, inducing):
         sq = se_iso_calc_sqr_diff_upper(inducing)
         km = se_iso_calc_upper_with_sqr_diff(k, sq)
         return km, dict(kernel=k, inducing=inducing, sqr_diff_mat=sq, eval_mat=km)
-    km = se_fat_calc_upper_vanilla(k, inducing)
+    km = (se_fat_calc_upper_vanilla(k, inducing) if k.multiscales is None
+          else se_fat_calc_upper_multiscale(k, inducing))
     if k.hetero_skedasticity is not None:  # lib/cov_se_fat.ml:136-142
         km[np.diag_indices(km.shape[0])] += k.hetero_skedasticity
     return km, dict(kernel=k, inducing=inducing, eval_mat=km)
@@ -257,6 +290,31 @@ def spec_calc_deriv_upper(shared_upper, hyper):
         return ("dense", _F(res))
     if kind == "proj":
         return ("const", 0.0)
+    ms = None if iso else k.multiscales
+    if kind == "log_multiscale":  # lib/cov_se_fat.ml:441-485
+        _, ind, dim = hyper
+        if ms is None:
+            raise RuntimeError("Cov_se_fat.Deriv.Inducing.calc_deriv_upper: multiscale modeling disabled, "
+                               "cannot calculate derivative")
+        res = np.zeros(m)
+        zc = inducing[dim - 1, ind - 1]
+        multiscale = ms[dim - 1, ind - 1]
+        multiscale_const = multiscale - 1.0
+        multiscale_h = 0.5 - multiscale
+        multiscale_factor = 0.5 * multiscale_h
+        for i in range(1, m + 1):
+            if i == ind:
+                dval = eval_mat[ind - 1, ind - 1]
+                if k.hetero_skedasticity is not None:
+                    dval = dval - k.hetero_skedasticity[ind - 1]
+                res[i - 1] = multiscale_h / (multiscale + multiscale_const) * dval
+                continue
+            kel = eval_mat[i - 1, ind - 1] if i < ind else eval_mat[ind - 1, i - 1]
+            diff = inducing[dim - 1, i - 1] - zc
+            iscale = 1.0 / (ms[dim - 1, i - 1] + multiscale_const)
+            sdiff = diff * iscale
+            res[i - 1] = (iscale - sdiff * sdiff) * multiscale_factor * kel
+        return ("sparse_rows", res, ind)
     if kind == "inducing":
         _, ind, dim = hyper
         scale = k.inv_ell2 if iso else 1.0
@@ -268,8 +326,11 @@ def spec_calc_deriv_upper(shared_upper, hyper):
             kel = eval_mat[i - 1, ind - 1] if i < ind else eval_mat[ind - 1, i - 1]
             if iso:
                 res[i - 1] = scale * (inducing[dim - 1, i - 1] - zc) * kel
-            else:
+            elif ms is None:
                 res[i - 1] = (inducing[dim - 1, i - 1] - zc) * kel
+            else:  # lib/cov_se_fat.ml:501-513
+                sc = ms[dim - 1, i - 1] + (ms[dim - 1, ind - 1] - 1.0)
+                res[i - 1] = (inducing[dim - 1, i - 1] - zc) / sc * kel
         return ("sparse_rows", res, ind)
     raise ValueError(hyper)
 
@@ -290,6 +351,18 @@ def spec_calc_deriv_cross(shared_cross, hyper):
         return ("factor", 1.0)
     if kind == "log_hetero":  # lib/cov_se_fat.ml:597
         return ("const", 0.0)
+    ms = None if iso else k.multiscales
+    if kind == "log_multiscale":  # lib/cov_se_fat.ml:598-622
+        _, ind, dim = hyper
+        if ms is None:
+            raise RuntimeError("Cov_se_fat.Deriv.Inputs.calc_deriv_cross: multiscale modeling disabled, "
+                               "cannot calculate derivative")
+        multiscale = ms[dim - 1, ind - 1]
+        multiscale_factor = 0.5 * (0.5 - multiscale)
+        diff = shared_cross["projections"][dim - 1, :] - inducing[dim - 1, ind - 1]
+        iscale = 1.0 / multiscale
+        sdiff = diff * iscale
+        return ("sparse_cols", (iscale - sdiff * sdiff) * multiscale_factor * eval_mat[:, ind - 1], ind)
     if kind == "log_ell":
         return ("dense", _F(eval_mat * shared_cross["sqr_diff_mat"] * k.inv_ell2))
     if kind == "inducing":
@@ -297,8 +370,10 @@ def spec_calc_deriv_cross(shared_cross, hyper):
         zc = inducing[dim - 1, ind - 1]
         if iso:
             col = k.inv_ell2 * (shared_cross["inputs"][dim - 1, :] - zc) * eval_mat[:, ind - 1]
-        else:
+        elif ms is None:
             col = (shared_cross["projections"][dim - 1, :] - zc) * eval_mat[:, ind - 1]
+        else:  # lib/cov_se_fat.ml:633-638
+            col = (1.0 / ms[dim - 1, ind - 1]) * (shared_cross["projections"][dim - 1, :] - zc) * eval_mat[:, ind - 1]
         return ("sparse_cols", col, ind)
     if kind == "proj":
         _, big, small = hyper
@@ -308,7 +383,9 @@ def spec_calc_deriv_cross(shared_cross, hyper):
         alpha = shared_cross["inputs"][big - 1, :][:, None]
         proj = shared_cross["projections"][small - 1, :][:, None]
         ind_el = inducing[small - 1, :][None, :]
-        return ("dense", _F(alpha * (ind_el - proj) * eval_mat))
+        if ms is None:
+            return ("dense", _F(alpha * (ind_el - proj) * eval_mat))
+        return ("dense", _F(alpha * ((ind_el - proj) / ms[small - 1, :][None, :]) * eval_mat))  # :585-595
     raise ValueError(hyper)
 
 
@@ -651,8 +728,17 @@ def evaluate_fast(k, inducing_points, inputs, targets, sigma2, variational=False
     np.fill_diagonal(wk, 0.0)
     # inducing hyper (ind=c, dim=kk): 0.5*dkm_term - dknm_term
     pts = shared_cross["inputs"] if iso else shared_cross["projections"]
-    dkm = 2.0 * scale * (inducing_points @ wk - inducing_points * np.sum(wk, axis=0)[None, :])
-    dknm = scale * (pts @ e_mat - inducing_points * np.sum(e_mat, axis=0)[None, :])
+    ms = None if iso else k.multiscales
+    if ms is None:
+        dkm = 2.0 * scale * (inducing_points @ wk - inducing_points * np.sum(wk, axis=0)[None, :])
+        dknm = scale * (pts @ e_mat - inducing_points * np.sum(e_mat, axis=0)[None, :])
+    else:
+        dkm = np.empty((d, m))
+        for kk in range(d):
+            zdiff = inducing_points[kk, :][:, None] - inducing_points[kk, :][None, :]      # z_r - z_c
+            sc = ms[kk, :][:, None] + ms[kk, :][None, :] - 1.0
+            dkm[kk] = 2.0 * np.sum(wk * zdiff / sc, axis=0)
+        dknm = (pts @ e_mat - inducing_points * np.sum(e_mat, axis=0)[None, :]) / ms
     g_ind = (0.5 * dkm - dknm).T.reshape(-1)  # ind-major, dim fastest
     if iso:
         sq_u = np.nan_to_num(shared_upper["sqr_diff_mat"], nan=0.0)
@@ -663,12 +749,31 @@ def evaluate_fast(k, inducing_points, inputs, targets, sigma2, variational=False
     else:
         parts = [[g_sf2], g_ind]
         if k.tproj is not None:
-            ez = e_mat @ inducing_points.T                      # n x d : sum_c E_rc z_small,c
-            rs = np.sum(e_mat, axis=1)[:, None] * pts.T          # n x d : rowsum(E)_r p_small,r
+            if ms is None:
+                ez = e_mat @ inducing_points.T                      # n x d : sum_c E_rc z_small,c
+                rs = np.sum(e_mat, axis=1)[:, None] * pts.T          # n x d : rowsum(E)_r p_small,r
+            else:
+                ez = e_mat @ (inducing_points / ms).T                # sum_c E_rc z_small,c / ms_small,c
+                rs = (e_mat @ (1.0 / ms).T) * pts.T
             g_proj = -(shared_cross["inputs"] @ (ez - rs))      # big x small
             parts.append(g_proj.reshape(-1))
         if het is not None:
             parts.append(0.5 * het * np.diag(w_mat))            # `Diag_vec: 1/2 het_i W_ii
+        if ms is not None:
+            g_ms = np.empty((m, d))
+            kdiag = np.diag(km_nohet)
+            for kk in range(d):
+                zdiff = inducing_points[kk, :][:, None] - inducing_points[kk, :][None, :]
+                isc = 1.0 / (ms[kk, :][:, None] + ms[kk, :][None, :] - 1.0)
+                inner = isc - (zdiff * isc) ** 2
+                np.fill_diagonal(inner, 0.0)
+                factor = 0.5 * (0.5 - ms[kk, :])
+                dkm_ms = 2.0 * factor * np.sum(wk * inner, axis=0) + \
+                    np.diag(w_mat) * (0.5 - ms[kk, :]) / (2.0 * ms[kk, :] - 1.0) * kdiag
+                pd = pts[kk, :][:, None] - inducing_points[kk, :][None, :]
+                dknm_ms = factor * np.sum(e_mat * (1.0 / ms[kk, :][None, :] - (pd / ms[kk, :][None, :]) ** 2), axis=0)
+                g_ms[:, kk] = 0.5 * dkm_ms - dknm_ms
+            parts.append(g_ms.reshape(-1))
         out["grad"] = np.concatenate(parts)
     return out
 

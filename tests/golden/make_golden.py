@@ -86,6 +86,16 @@ def main():
     lh = rng.normal(size=20) - 3.0
     kh = O.SeFatKernel(3, 0.2, P, lh)
     save("fat_hetero", kh, Xb, yb, Zf, 0.1, False, dict(kind="fat", d=3, log_sf2=0.2, tproj=P, log_hetero=lh))
+    # everything on, as Cov_se_fat.Eval.Inputs.create_default_kernel_params does (lib/cov_se_fat.ml:191-213)
+    lms = 0.3 * rng.normal(size=(3, 20))
+    kall = O.SeFatKernel(3, 0.2, P, lh, lms)
+    save("fat_all", kall, Xb, yb, Zf, 0.1, False,
+         dict(kind="fat", d=3, log_sf2=0.2, tproj=P, log_hetero=lh, log_multiscales=lms))
+    # multiscales without projection
+    lms4 = 0.2 * rng.normal(size=(4, 16))
+    kms = O.SeFatKernel(4, 0.0, None, None, lms4)
+    save("fat_multiscale", kms, Xa, ya, np.asfortranarray(Xa[:, :16] + 0.01), 0.2, True,
+         dict(kind="fat", d=4, log_sf2=0.0, log_multiscales=lms4))
     # Cov_se_fat without projection
     kn = O.SeFatKernel(4, -0.1, None)
     save("fat_noproj", kn, Xa, ya, np.asfortranarray(Xa[:, :16] + 0.01), 0.2, False,

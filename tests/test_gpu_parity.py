@@ -43,6 +43,8 @@ def _eval_golden(p, g, **kw):
             args["tproj"] = g["tproj"]
         if "log_hetero" in g:
             args["log_hetero_skedasticity"] = g["log_hetero"]
+        if "log_multiscales" in g:
+            args["log_multiscales_m05"] = g["log_multiscales"]
     args.update(kw)
     return p.eval(**args)
 
@@ -102,13 +104,14 @@ def test_fat_functor_mirror_self_test():
     X = np.asfortranarray(rng.uniform(size=(3, 10)))
     y = rng.uniform(size=10)
     P = np.asfortranarray(rng.uniform(-1, 1, size=(3, 2)))
-    # projection and heteroskedastic noise on, as create_default_kernel_params does (lib/cov_se_fat.ml:191-213)
-    kernel = cov_se_fat.Kernel.create(cov_se_fat.Params.create(2, 0.3, P, np.full(5, -5.0)))
+    # projection, heteroskedastic noise and multiscales all on, as create_default_kernel_params does
+    # (lib/cov_se_fat.ml:191-213: log_hetero = -5, log_multiscales_m05 = 0)
+    kernel = cov_se_fat.Kernel.create(cov_se_fat.Params.create(2, 0.3, P, np.full(5, -5.0), np.zeros((2, 5))))
     Z = np.asfortranarray((P.T @ X)[:, :5].copy())
     GP = fitc_gp.Make_deriv(cov_se_fat)
     FITC = GP.FITC
     hypers = FITC.Deriv.Spec.HyperModule.get_all(kernel, Z, X)
-    assert len(hypers) == 1 + 2 * 5 + 3 * 2 + 5
+    assert len(hypers) == 1 + 2 * 5 + 3 * 2 + 5 + 2 * 5
     FITC.Deriv.Test.self_test(kernel, Z, X, sigma2=1.0, targets=y, hyper="Sigma2")
     for h in hypers:
         FITC.Deriv.Test.self_test(kernel, Z, X, sigma2=1.0, targets=y, hyper=h)

@@ -43,8 +43,12 @@ def test_iso_set_values_copies_inducing_lazily():
 def test_fat_hypers_and_param_checks():
     with pytest.raises(ValueError, match="disagrees with target dimension"):
         cov_se_fat.Params.create(3, 0.0, tproj=np.ones((5, 2)))
-    with pytest.raises(NotImplementedError):
-        cov_se_fat.Params.create(3, 0.0, log_multiscales_m05=np.zeros((3, 4)))
+    with pytest.raises(ValueError, match="log_multiscales_m05"):
+        cov_se_fat.Params.create(3, 0.0, log_multiscales_m05=np.zeros((2, 4)))
+    km = cov_se_fat.Kernel.create(cov_se_fat.Params.create(2, 0.0, np.ones((3, 2)), np.zeros(2), np.zeros((2, 2))))
+    hm = cov_se_fat.HyperModule.get_all(km, np.zeros((2, 2), order="F"))
+    assert hm[-4:] == [cov_se_fat.Log_multiscale_m05(i, d_) for i in (1, 2) for d_ in (1, 2)]   # lib/cov_se_fat.ml:334-341
+    assert [cov_se_fat.HyperModule.index_of(km, np.zeros((2, 2)), h) for h in hm] == list(range(len(hm)))
     kh = cov_se_fat.Kernel.create(cov_se_fat.Params.create(2, 0.0, np.ones((3, 2)), np.zeros(2)))
     hh = cov_se_fat.HyperModule.get_all(kh, np.zeros((2, 2), order="F"))
     assert hh[-2:] == [cov_se_fat.Log_hetero_skedasticity(1), cov_se_fat.Log_hetero_skedasticity(2)]

@@ -21,7 +21,7 @@ def load_golden(name):
 def oracle_kernel(g):
     if g["kind"] == "iso":
         return O.SeIsoKernel(float(g["log_ell"]), float(g["log_sf2"]))
-    return O.SeFatKernel(int(g["d"]), float(g["log_sf2"]), g.get("tproj"), g.get("log_hetero"))
+    return O.SeFatKernel(int(g["d"]), float(g["log_sf2"]), g.get("tproj"), g.get("log_hetero"), g.get("log_multiscales"))
 
 
 def synth(seed, n, m, d):
