@@ -39,6 +39,7 @@ class Hypers(C.Structure):
         ("jitter", C.c_double),
         ("log_hetero_skedasticity", C.POINTER(C.c_double)),
         ("log_multiscales_m05", C.POINTER(C.c_double)),
+        ("reuse_v", C.c_int),
     ]
 
 

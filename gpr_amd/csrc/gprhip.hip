@@ -383,6 +383,11 @@ void do_pass1(gprhip_problem* p, const gprhip_hypers* h, int want_grad, int64_t 
   TS* const bufA = static_cast<TS*>(p->bufA);
   TS* const slices = static_cast<TS*>(p->slices);
 
+  const bool reuse = h->reuse_v != 0;
+  if (reuse && !p->have_model) {
+    set_error("gprhip: reuse_v set but there is no previous evaluation on this problem");
+    throw HipFail{ST_STATE};
+  }
   tstart(p, "km_chol");
   GPR_HIP(hipMemsetAsync(p->info, 0, 2 * sizeof(int), s));
   GPR_HIP(hipMemsetAsync(p->scal, 0, NSCAL * sizeof(double), s));
@@ -399,18 +404,20 @@ void do_pass1(gprhip_problem* p, const gprhip_hypers* h, int want_grad, int64_t 
     const int rows_p = (int)round_up(rows, TILE);
     const int64_t base = (int64_t)c * p->chunk;
     TS* V = Vstore + base * mp;
-    tstart(p, "p1_cov");
-    cov_chunk<TS>(p, c, bufA);
-    tstop(p);
-    tstart(p, "p1_trmm_V");
-    GemmArgsT<TS> g;  // V = K U^-1   (dtrsm `R, lib/fitc_gp.ml:226-227)
-    g.A = bufA; g.lda = mp; g.B = inv_u<TS>(p); g.ldb = mp; g.C = V; g.ldc = mp;
-    g.M = rows_p; g.N = mp; g.K = mp; g.tri = TRI_KHI_BN; g.order = p->tile_order;
-    launch_gemm(OP_NN, g, s);
-    tstop(p);
+    if (!reuse) {
+      tstart(p, "p1_cov");
+      cov_chunk<TS>(p, c, bufA);
+      tstop(p);
+      tstart(p, "p1_trmm_V");
+      GemmArgsT<TS> g;  // V = K U^-1   (dtrsm `R, lib/fitc_gp.ml:226-227)
+      g.A = bufA; g.lda = mp; g.B = inv_u<TS>(p); g.ldb = mp; g.C = V; g.ldc = mp;
+      g.M = rows_p; g.N = mp; g.K = mp; g.tri = TRI_KHI_BN; g.order = p->tile_order;
+      launch_gemm(OP_NN, g, s);
+      tstop(p);
+    }
     tstart(p, "p1_rows");
     Pass1RowArgs<TS> ra;
-    ra.V = V; ra.y = h->model_only ? nullptr : p->y + base; ra.rows = (int)rows; ra.mp = mp;
+    ra.V = reuse ? nullptr : V; ra.y = h->model_only ? nullptr : p->y + base; ra.rows = (int)rows; ra.mp = mp;
     ra.sf2 = p->cp.sf2; ra.sigma2 = h->sigma2;
     ra.r = p->r + base; ra.is = p->is + base; ra.yis = p->yis + base; ra.partial = p->rowpart;
     launch_pass1_rows(ra, s);

@@ -59,7 +59,7 @@ void launch_triu_matvec(const double* A, int mp, const double* x, double* y, int
 // ---- row kernels (rowops.hip)
 template <typename TS>
 struct Pass1RowArgs {
-  const TS* V;           // [rows_p][mp]
+  const TS* V;           // [rows_p][mp]; null = keep r of the previous evaluation (update_sigma2)
   const double* y;       // [rows] targets of this chunk (may be null: model-only)
   int rows, mp;
   double sf2, sigma2;

@@ -45,19 +45,22 @@ __global__ __launch_bounds__(256) void pass1_rows_kernel(Pass1RowArgs<TS> a, int
   for (int q = 0; q < 4; ++q) {
     const int row = blockIdx.x * ROWS_PER_BLOCK + wv * 4 + q;
     if (row >= rows_p) break;
-    const TS* v = a.V + (int64_t)row * a.mp;
     double s2 = 0.0;
-    constexpr int NV = RowVec<TS>::N;
-    for (int c = lane * NV; c < a.mp; c += 64 * NV) {
-      double x[NV];
-      RowVec<TS>::load(v + c, x);
+    if (a.V) {
+      const TS* v = a.V + (int64_t)row * a.mp;
+      constexpr int NV = RowVec<TS>::N;
+      for (int c = lane * NV; c < a.mp; c += 64 * NV) {
+        double x[NV];
+        RowVec<TS>::load(v + c, x);
 #pragma unroll
-      for (int e = 0; e < NV; ++e) s2 += x[e] * x[e];
+        for (int e = 0; e < NV; ++e) s2 += x[e] * x[e];
+      }
+      s2 = wave_sum(s2);
     }
-    s2 = wave_sum(s2);
     if (lane == 0) {
       if (row < a.rows) {
-        const double r = a.sf2 - s2;
+        // V == null: Model.update_sigma2 (lib/fitc_gp.ml:234-236) -- r of the previous evaluation is kept
+        const double r = a.V ? a.sf2 - s2 : a.r[row];
         const double s = r + a.sigma2;
         const double is = 1.0 / s;
         const double y = a.y ? a.y[row] : 0.0;

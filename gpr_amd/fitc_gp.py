@@ -98,9 +98,16 @@ def _run(model, targets, want_grad):
     kernel = inputs.inducing.kernel
     if targets is not None:  # n doubles: cheap next to one evaluation, and never stale
         prob.set_targets(targets)
-    return prob.eval(sigma2=model.sigma2, inducing=inputs.inducing.points, variational=model.variational,
-                     model_only=targets is None, want_grad=want_grad, jitter=prob._jitter,
-                     **spec.eval_args(kernel))
+    # Model.update_sigma2 (lib/fitc_gp.ml:234-236, :1083-1090): when the problem's previous evaluation used
+    # this very kernel object and inducing matrix, only sigma2 changed -> K_nm, V, r stay on the device
+    sig = (id(kernel), id(inputs.inducing.points))
+    reuse = getattr(prob, "_last_sig", None) == sig
+    ev = prob.eval(sigma2=model.sigma2, inducing=inputs.inducing.points, variational=model.variational,
+                   model_only=targets is None, want_grad=want_grad, jitter=prob._jitter, reuse_v=reuse,
+                   **spec.eval_args(kernel))
+    prob._last_sig = sig
+    prob._last_refs = (kernel, inputs.inducing.points)  # keep the ids alive
+    return ev
 
 
 def _make_variant(spec, variational, functor):

@@ -81,7 +81,7 @@ class Problem:
         return int(self._lib.gprhip_n_hypers(self._h, flags))
 
     def _hypers(self, log_ell, log_sf2, sigma2, inducing, tproj, variational, model_only, jitter,
-                log_hetero_skedasticity=None, log_multiscales_m05=None):
+                log_hetero_skedasticity=None, log_multiscales_m05=None, reuse_v=False):
         z = np.asfortranarray(inducing, dtype=np.float64)
         if z.shape != (self.d, self.m):
             raise ValueError("inducing: expected shape (%d, %d), got %s" % (self.d, self.m, z.shape))
@@ -96,6 +96,7 @@ class Problem:
             h.tproj = _f64_ptr(tp)
             keep.append(tp)
         h.variational, h.model_only, h.jitter = int(variational), int(model_only), float(jitter)
+        h.reuse_v = int(reuse_v)
         if log_hetero_skedasticity is not None:
             lh = np.ascontiguousarray(log_hetero_skedasticity, dtype=np.float64)
             if lh.shape != (self.m,):
@@ -112,9 +113,11 @@ class Problem:
 
     def eval(self, *, log_sf2, sigma2, inducing, log_ell=0.0, tproj=None, variational=False,
              model_only=False, want_grad=True, jitter=CHOLESKY_JITTER, log_hetero_skedasticity=None,
-             log_multiscales_m05=None):
+             log_multiscales_m05=None, reuse_v=False):
+        """reuse_v=True: only sigma2/targets changed since the previous eval on this problem
+        (Model.update_sigma2, lib/fitc_gp.ml:234-236): K_nm, V and r are reused."""
         h, keep = self._hypers(log_ell, log_sf2, sigma2, inducing, tproj, variational, model_only, jitter,
-                               log_hetero_skedasticity, log_multiscales_m05)
+                               log_hetero_skedasticity, log_multiscales_m05, reuse_v)
         res = Result()
         nh = self.n_hypers(tproj is not None, log_hetero_skedasticity is not None, log_multiscales_m05 is not None)
         grad = np.empty(nh if want_grad else 1, dtype=np.float64)

@@ -83,7 +83,11 @@ int gprhip_set_targets_device(gprhip_problem* p, const double* d_targets);
  *   log_hetero_skedasticity : Cov_se_fat.Params.log_hetero_skedasticity (m entries) or NULL:
  *                exp() of it is added to diag(K_m)                             lib/cov_se_fat.ml:136-142
  *   log_multiscales_m05 : Cov_se_fat.Params.log_multiscales_m05 (Fortran d x m) or NULL: per inducing point
- *                and dimension a length scale exp(.)+0.5                        lib/cov_se_fat.ml:66-69, :115-134 */
+ *                and dimension a length scale exp(.)+0.5                        lib/cov_se_fat.ml:66-69, :115-134
+ *   reuse_v    : 1 = only sigma2 (and targets) changed since the previous evaluation on this problem:
+ *                K_nm, V = K_nm U^-1 and r are reused instead of recomputed -- Model.update_sigma2,
+ *                lib/fitc_gp.ml:234-236, :1083-1090.  The caller guarantees kernel parameters and inducing
+ *                points are unchanged (they are still passed and uploaded). */
 typedef struct {
   double log_ell;
   double log_sf2;
@@ -95,6 +99,7 @@ typedef struct {
   double jitter;
   const double* log_hetero_skedasticity;
   const double* log_multiscales_m05;
+  int reuse_v;
 } gprhip_hypers;
 
 /* Results.  Gradient order is the reference's Hyper.get_all order:

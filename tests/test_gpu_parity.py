@@ -212,6 +212,38 @@ def test_fp32_bulk_fat_ard_config3_shape():
         p.close()
 
 
+def test_update_sigma2_reuses_resident_v():
+    """Model.update_sigma2 (lib/fitc_gp.ml:234-236): re-evaluating with only sigma2 changed reuses K_nm, V, r
+    and gives the same numbers as a fresh evaluation."""
+    g = load_golden("iso_ragged")
+    p = _problem_for(g, chunk_rows=256)
+    _eval_golden(p, g)
+    fresh = _eval_golden(p, g, sigma2=0.37)
+    _eval_golden(p, g)
+    fast = _eval_golden(p, g, sigma2=0.37, reuse_v=True)
+    assert fast.l == fresh.l and fast.dl_dsigma2 == fresh.dl_dsigma2
+    assert np.array_equal(fast.grad, fresh.grad)
+    ref = O.evaluate_fast(oracle_kernel(g), g["Z"], g["X"], g["y"], 0.37)
+    assert abs(fast.l - ref["l"]) <= TOL_L * abs(ref["l"])
+    p.close()
+    q = _problem_for(g)
+    with pytest.raises(gpr_amd.GprHipError, match="no previous evaluation"):
+        _eval_golden(q, g, reuse_v=True)
+    q.close()
+    # through the mirror: update_sigma2 on a model whose kernel/inducing were just evaluated
+    GP = fitc_gp.Make_deriv(cov_se_iso)
+    F = GP.FITC
+    kernel = cov_se_iso.Kernel.create(cov_se_iso.Params(float(g["log_ell"]), float(g["log_sf2"])))
+    inducing = F.Deriv.Inducing.calc(kernel, g["Z"])
+    model = F.Deriv.Model.calc(F.Deriv.Inputs.calc(inducing, g["X"]), sigma2=float(g["sigma2"]))
+    tr = F.Deriv.Trained.calc(model, targets=g["y"])
+    assert abs(F.Eval.Trained.calc_log_evidence(tr) - float(g["l"])) <= TOL_L * abs(float(g["l"]))
+    tr2 = F.Deriv.Trained.calc(F.Deriv.Model.update_sigma2(model, 0.37), targets=g["y"])
+    assert abs(F.Eval.Trained.calc_log_evidence(tr2) - ref["l"]) <= TOL_L * abs(ref["l"])
+    assert abs(F.Deriv.Trained.calc_log_evidence_sigma2(tr2) - ref["dl_dsigma2"]) <= TOL_DS2 * abs(ref["dl_dsigma2"])
+    GP.close()
+
+
 def test_prediction_means_and_variances():
     """Means.calc / Variances.calc (lib/fitc_gp.ml:418-425, :498-518) on the device
     against the oracle, directly and through the mirrored module surface; test set larger than a chunk."""
