@@ -65,7 +65,7 @@ def measured_traffic():
     best = None
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_bench*.json"))):
         for r in json.load(open(path)):
-            if r["kernel"].startswith("gprhip::gemm_kernel<2>") and (best is None or r["avg_ms"] > best["avg_ms"]):
+            if r["kernel"].startswith("gprhip::gemm_kernel<double, 2>") and (best is None or r["avg_ms"] > best["avg_ms"]):
                 best = r
     if best is None:
         return None

@@ -135,6 +135,7 @@ struct gprhip_problem {
     return (int64_t)(nchunks - 1) * chunk + round_up(rows_of(nchunks - 1), TILE);
   }
   int ks_used = 8;
+  int64_t slice_rows = 4096;  // training points per split-K slice of the SYRK launches
   int tile_order = 0;
   // Cov_se_fat `Proj hypers: rows of the exchange-2 column block beyond d+1, and the D x d second term
   int dbig() const { return kind == GPRHIP_COV_SE_FAT ? D : 0; }
@@ -331,14 +332,15 @@ void upload_hypers(gprhip_problem* p, const gprhip_hypers* h) {
 
 // Split-K factor of the SYRK-shaped accumulations over training points.  Slices are dealt to the
 // 8 XCDs (mfma_gemm.hip), so the factor is a multiple of 8.  Blocks of one slice share their operand
-// rows through the XCD's L2 while they run in step.  Throughput is flat in the slice length (measured
-// 4k..125k rows), so slices are kept near 16384 rows -- few enough that summing the partial m x m
-// results stays negligible.  Among nearby factors the one whose (tiles x slices / 8) fills whole
-// residency rounds of an XCD (32 CUs x 2 blocks) is taken.
-int pick_kslices(int mp, int64_t rows_p, int max_slices) {
+// rows through the XCD's L2 while they run in step.  Run time is flat in the slice length (measured
+// 4k..125k rows) but the blocks of a long slice drift apart and re-fetch more (rocprofv3 FETCH_SIZE per
+// launch at n=1M, m=2048: 159 GB with 16k-row slices, 86 GB with 4k-row slices, against 16.4 GB of V), so
+// slices are kept near `slice_rows` (4096) rows.  Among nearby factors the one whose (tiles x slices / 8)
+// fills whole residency rounds of an XCD (32 CUs x 2 blocks) is taken.
+int pick_kslices(int mp, int64_t rows_p, int max_slices, int64_t slice_rows) {
   const int nt = mp / TILE, tiles = nt * (nt + 1) / 2;
   const int slots = 64;
-  int target = (int)((rows_p / 16384 + 7) / 8 * 8);
+  int target = (int)((rows_p / slice_rows + 7) / 8 * 8);
   target = std::max(8, std::min(target, max_slices / 8 * 8));
   int best = target;
   double best_eff = 0.0;
@@ -427,7 +429,7 @@ void do_pass1(gprhip_problem* p, const gprhip_hypers* h, int want_grad, int64_t 
   // one SYRK-shaped launch over all rows of the shard (V is resident): B~_part = V^T diag(is) V
   // (R~^T R~ replaces the stacked QR's R, lib/fitc_gp.ml:170-182), and c~ = V^T (is .* y)
   const int64_t ktot = p->rows_total_padded();
-  const int ks = pick_kslices(mp, ktot, p->kslices);
+  const int ks = pick_kslices(mp, ktot, p->kslices, p->slice_rows);
   tstart(p, "p1_syrk_B");
   GemmArgsT<TS> b;
   b.A = Vstore; b.lda = mp; b.B = Vstore; b.ldb = mp; b.C = slices; b.ldc = mp;
@@ -851,9 +853,10 @@ int gprhip_problem_create_ex(int device, int cov_kind, int precision, int64_t n,
     chunk = round_up(std::min<int64_t>(chunk, round_up(n, TILE)), TILE);
     p->chunk = chunk;
     p->nchunks = (int)((n + chunk - 1) / chunk);
-    // partial-sum buffers of the split-K SYRK launches: one m x m slice per ~16384 training points,
+    // partial-sum buffers of the split-K SYRK launches: one m x m slice per `slice_rows` training points,
     // capped at 40 GB
-    p->kslices = (int)std::max<int64_t>(8, std::min<int64_t>((round_up(n, 16384) / 16384 + 23) / 8 * 8,
+    if (const char* e = getenv("GPRHIP_SLICE_ROWS")) p->slice_rows = std::max<int64_t>(1024, atoll(e));
+    p->kslices = (int)std::max<int64_t>(8, std::min<int64_t>((round_up(n, p->slice_rows) / p->slice_rows + 23) / 8 * 8,
                                                               (40LL << 30) / (p->mp * (int64_t)p->mp * 8) / 8 * 8));
     if (const char* e = getenv("GPRHIP_KSLICES")) p->kslices = std::max(8, atoi(e) / 8 * 8);
     if (const char* e = getenv("GPRHIP_TIMING")) p->timer.on = atoi(e) != 0;
