@@ -223,10 +223,13 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgsT<T> g) {
 
   // fragment base offsets (elements) inside a stage
   const int a_frag = A_KMAJ ? (lq * KS + wr * 64 + l15) : ((wr * 64 + l15) * XS + lq);
-  const int b_frag = B_XMAJ ? ((wc * 64 + l15) * XS + lq) : (lq * KS + wc * 64 + l15);
+  // the 8 column sub-tiles (16 columns each) of the block tile are dealt alternately to the two wave
+  // columns (wave column wc owns sub-tiles wc, wc+2, wc+4, wc+6): inside the diagonal block of a
+  // triangular operand the live sub-tiles then split evenly between the two waves of a row
+  const int b_frag = B_XMAJ ? ((wc * 16 + l15) * XS + lq) : (lq * KS + wc * 16 + l15);
   constexpr int A_TM = A_KMAJ ? 16 : 16 * XS;  // advance per 16-row sub-tile
   constexpr int A_KK = A_KMAJ ? 4 * KS : 4;    // advance per k-step of 4
-  constexpr int B_TN = B_XMAJ ? 16 * XS : 16;
+  constexpr int B_TN = B_XMAJ ? 32 * XS : 32;  // advance per owned column sub-tile (every other one)
   constexpr int B_KK = B_XMAJ ? 4 : 4 * KS;
 
   // Inside the diagonal 128-block of a triangular B operand, column sub-tile cj (16 columns,
@@ -236,12 +239,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgsT<T> g) {
   // (sub-tile, stage) pairs multiply zeros and are skipped -- about half of that block's work.
   const int diag_first = (g.tri == TRI_KHI_BN && k_hi == (bn + 1) * TILE) ? nk - TILE / BK
                          : (g.tri == TRI_KLO_BN && k_lo == bn * TILE) ? 0 : -(1 << 30);
-  const int cj0 = wc * 4;
-  // symmetric product on a diagonal tile: the lower-left 64 x 64 wave tile mirrors the upper-right one
-  // and nobody reads it (consumers take the upper triangle), so that wavefront skips its MFMAs
-  const bool mirror_idle = (OP == OP_TN) && g.upper_only && g.A == g.B && bm == bn && wr == 1 && wc == 0;
+  const int cj0 = wc;  // first owned column sub-tile; sub-tile j of this wave is 2j + wc
   auto compute = [&](int stage, int t) {
-    if (mirror_idle) return;
     const T* As = smem + stage * 2 * STAGE;
     const T* Bs = As + STAGE;
     int jlo = 0, jhi = 7;  // live column sub-tiles of this stage
@@ -249,8 +248,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgsT<T> g) {
     if (u >= 0 && u < TILE / BK) {  // stage u of the diagonal block covers k in [BK*u, BK*u + BK)
       if (g.tri == TRI_KHI_BN) jlo = (BK * u) / 16; else jhi = (BK * u + BK - 1) / 16;
     }
-    if (jlo > cj0 + 3 || jhi < cj0) return;
-    if (jlo <= cj0 && jhi >= cj0 + 3) {
+    if (jlo > cj0 + 6 || jhi < cj0) return;
+    if (jlo <= cj0 && jhi >= cj0 + 6) {
       // every sub-tile live: the common case, one straight MFMA stream
 #pragma unroll
       for (int kk = 0; kk < BK / 4; ++kk) {
@@ -276,7 +275,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgsT<T> g) {
       for (int j = 0; j < 4; ++j) bf[j] = Bs[b_frag + j * B_TN + kk * B_KK];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        if (cj0 + j >= jlo && cj0 + j <= jhi) {
+        if (cj0 + 2 * j >= jlo && cj0 + 2 * j <= jhi) {
 #pragma unroll
           for (int i = 0; i < 4; ++i)
             acc[i][j] = G::mfma(af[i], bf[j], acc[i][j]);
@@ -303,7 +302,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgsT<T> g) {
   }
 
   // ---- epilogue
-  const int rowb = bm * TILE + wr * 64, col0 = bn * TILE + wc * 64 + l15;
+  const int rowb = bm * TILE + wr * 64, col0 = bn * TILE + wc * 16 + l15;  // + 32 per owned sub-tile
   T* Cp = g.C + (int64_t)slice * g.slice_stride + col0;
   const T alpha = (T)g.alpha, beta = (T)g.beta;
   if (g.epi_rows_a) {
@@ -312,7 +311,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgsT<T> g) {
     const T* Mp = g.epi_mat + col0;
     T cv[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) cv[j] = (T)g.epi_col[col0 + j * 16];
+    for (int j = 0; j < 4; ++j) cv[j] = (T)g.epi_col[col0 + j * 32];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -321,8 +320,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgsT<T> g) {
         const T ra = (T)g.epi_rows_a[row], rb = (T)g.epi_rows_b[row], rc = (T)g.epi_rows_c[row];
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-          Cp[(int64_t)row * g.ldc + j * 16] =
-              ra * acc[i][j][r] - rb * Mp[(int64_t)row * g.epi_ldm + j * 16] - rc * cv[j];
+          Cp[(int64_t)row * g.ldc + j * 32] =
+              ra * acc[i][j][r] - rb * Mp[(int64_t)row * g.epi_ldm + j * 32] - rc * cv[j];
       }
     return;
   }
@@ -332,7 +331,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgsT<T> g) {
     for (int j = 0; j < 4; ++j)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        T* p = Cp + (int64_t)(rowb + i * 16 + G::crow(lq, r)) * g.ldc + j * 16;
+        T* p = Cp + (int64_t)(rowb + i * 16 + G::crow(lq, r)) * g.ldc + j * 32;
         T v = alpha * acc[i][j][r];
         if (beta != (T)0) v += beta * (*p);
         *p = v;
