@@ -94,6 +94,7 @@ struct gprhip_problem {
   int* info = nullptr;
   double *r = nullptr, *is = nullptr, *yis = nullptr, *w = nullptr, *v = nullptr, *es = nullptr;
   double* projpart = nullptr;
+  double *rp1 = nullptr, *rp2 = nullptr;  // per-row partial sums from the GEMM epilogues [chunk][2*mp/128]
   double *xt = nullptr, *pt = nullptr, *prow = nullptr;  // prediction: test-point chunk, its projection, 3 row vectors
   bool have_model = false;
   // n x m storage: double, or float in the fp32-bulk mode (element size `esz`)
@@ -414,12 +415,13 @@ void do_pass1(gprhip_problem* p, const gprhip_hypers* h, int want_grad, int64_t 
       GemmArgsT<TS> g;  // V = K U^-1   (dtrsm `R, lib/fitc_gp.ml:226-227)
       g.A = bufA; g.lda = mp; g.B = inv_u<TS>(p); g.ldb = mp; g.C = V; g.ldc = mp;
       g.M = rows_p; g.N = mp; g.K = mp; g.tri = TRI_KHI_BN; g.order = p->tile_order;
+      g.rp_sumsq = p->rp1;  // r = k_diag - rowsum(V.^2) comes out of the epilogue (Mat.syrk_diag, :222-223)
       launch_gemm(OP_NN, g, s);
       tstop(p);
     }
     tstart(p, "p1_rows");
     Pass1RowArgs<TS> ra;
-    ra.V = reuse ? nullptr : V; ra.y = h->model_only ? nullptr : p->y + base; ra.rows = (int)rows; ra.mp = mp;
+    ra.V = nullptr; ra.part = reuse ? nullptr : p->rp1; ra.npart = 2 * (mp / TILE); ra.y = h->model_only ? nullptr : p->y + base; ra.rows = (int)rows; ra.mp = mp;
     ra.sf2 = p->cp.sf2; ra.sigma2 = h->sigma2;
     ra.r = p->r + base; ra.is = p->is + base; ra.yis = p->yis + base; ra.partial = p->rowpart;
     launch_pass1_rows(ra, s);
@@ -496,11 +498,12 @@ void do_pass2(gprhip_problem* p, const double* ar1, double* ar2) {
       GemmArgsT<TS> q;  // Q' = V R~^-1 = K R^-1  (Q_n = diag(sqrt is) Q', lib/fitc_gp.ml:176-182)
       q.A = V; q.lda = mp; q.B = inv_r<TS>(p); q.ldb = mp; q.C = bufA; q.ldc = mp;
       q.M = rows_p; q.N = mp; q.K = mp; q.tri = TRI_KHI_BN; q.order = p->tile_order;
+      q.rp_sumsq = p->rp1; q.rp_dot = p->rp2; q.rp_vec = p->bvec;  // q_diag and Q'b from the epilogue
       launch_gemm(OP_NN, q, s);
       tstop(p);
       tstart(p, "p2_rows");
       Pass2RowArgs<TS> ra;
-      ra.Q = bufA; ra.b = p->bvec;
+      ra.Q = nullptr; ra.part_sq = p->rp1; ra.part_dot = p->rp2; ra.npart = 2 * (mp / TILE); ra.b = p->bvec;
       ra.y = mo ? nullptr : p->y + base; ra.is = p->is + base; ra.r = p->r + base;
       ra.rows = (int)rows; ra.mp = mp; ra.variational = p->h.variational;
       ra.sf2 = p->cp.sf2; ra.es = proj ? p->es + base : nullptr;
@@ -887,6 +890,7 @@ int gprhip_problem_create_ex(int device, int cov_kind, int precision, int64_t n,
       p->es = p->alloc<double>(npad);
       p->projpart = p->alloc<double>(((chunk + 255) / 256) * (int64_t)D * d);
     }
+    p->rp1 = p->alloc<double>(chunk * 2 * (mp / TILE)); p->rp2 = p->alloc<double>(chunk * 2 * (mp / TILE));
     p->bufA = p->alloc<char>(chunk * mp * p->esz); p->bufB = p->alloc<char>(chunk * mp * p->esz);
     if (p->f32) {
       p->uinv_f = p->alloc<float>(mm);

@@ -60,6 +60,8 @@ void launch_triu_matvec(const double* A, int mp, const double* x, double* y, int
 template <typename TS>
 struct Pass1RowArgs {
   const TS* V;           // [rows_p][mp]; null = keep r of the previous evaluation (update_sigma2)
+  const double* part;    // alternative to V: [rows_p][npart] partial row sums of V^2 from the GEMM epilogue
+  int npart;
   const double* y;       // [rows] targets of this chunk (may be null: model-only)
   int rows, mp;
   double sf2, sigma2;
@@ -74,7 +76,10 @@ void launch_pass1_rows(const Pass1RowArgs<TS>& a, hipStream_t s);
 
 template <typename TS>
 struct Pass2RowArgs {
-  const TS* Q;           // [rows_p][mp]  K_chunk * Rinv
+  const TS* Q;           // [rows_p][mp]  K_chunk * Rinv (null when the partial sums below are given)
+  const double* part_sq;  // [rows_p][npart] partial row sums of Q'^2 from the GEMM epilogue, or null
+  const double* part_dot; // [rows_p][npart] partial row sums of Q' .* b
+  int npart;
   const double* b;       // [mp]          Rinv^T c  (= Q_n^T y~ of the reference)
   const double* y;       // [rows] or null
   const double* is;      // [rows_p]

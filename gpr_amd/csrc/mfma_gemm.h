@@ -54,6 +54,13 @@ struct GemmArgsT {
   const double* epi_col = nullptr;
   const T* epi_mat = nullptr;
   int64_t epi_ldm = 0;
+  // optional per-row reductions of the result tile, fused into the plain-store epilogue:
+  //   rp_sumsq[row*(2*N/128) + 2*bn + wc] = sum of C[row][c]^2 over the 64 columns wave column wc owns in tile bn
+  //   rp_dot  [same index]               = sum of C[row][c] * rp_vec[c] over the same columns
+  // (diag(Q_nn)-type row quantities without re-reading the n x m result: lib/fitc_gp.ml:222-223, :1048, :1164)
+  double* rp_sumsq = nullptr;
+  double* rp_dot = nullptr;
+  const double* rp_vec = nullptr;
 };
 using GemmArgs = GemmArgsT<double>;
 using GemmArgsF = GemmArgsT<float>;

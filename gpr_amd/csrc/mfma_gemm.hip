@@ -335,7 +335,53 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgsT<T> g) {
         T v = alpha * acc[i][j][r];
         if (beta != (T)0) v += beta * (*p);
         *p = v;
+        acc[i][j][r] = v;  // the stored value, for the row reductions below
       }
+  if (g.rp_sumsq) {
+    // wavefront row reductions over this wave's 64 columns: 4 values in-thread, then the 16 lanes of a
+    // row group by xor-shuffles; lane l15 == 0 writes one partial per (row, tile, wave column)
+    const int npart = 2 * nbn;
+    double bv[4] = {0.0, 0.0, 0.0, 0.0};
+    if (g.rp_dot) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bv[j] = g.rp_vec[col0 + j * 32];
+    }
+    double s2[16], sd[16];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        double x2 = 0.0, xd = 0.0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const double v = (double)acc[i][j][r];
+          x2 += v * v;
+          xd += v * bv[j];
+        }
+        s2[i * 4 + r] = x2;
+        sd[i * 4 + r] = xd;
+      }
+    // transposing butterfly over the 16 lanes of a row group: 8+4+2+1 exchanges leave lane l15 with the
+    // total of value k = l15 (i = l15 >> 2, r = l15 & 3)
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) {
+      const bool hi = (l15 & o) != 0;
+#pragma unroll
+      for (int k = 0; k < o; ++k) {
+        const double keep = hi ? s2[k + o] : s2[k];
+        const double send = hi ? s2[k] : s2[k + o];
+        s2[k] = keep + __shfl_xor(send, o);
+        if (g.rp_dot) {
+          const double keepd = hi ? sd[k + o] : sd[k];
+          const double sendd = hi ? sd[k] : sd[k + o];
+          sd[k] = keepd + __shfl_xor(sendd, o);
+        }
+      }
+    }
+    const int64_t idx = (int64_t)(rowb + (l15 >> 2) * 16 + G::crow(lq, l15 & 3)) * npart + 2 * bn + wc;
+    g.rp_sumsq[idx] = s2[0];
+    if (g.rp_dot) g.rp_dot[idx] = sd[0];
+  }
 }
 
 void gemm_init() {

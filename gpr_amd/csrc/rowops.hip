@@ -46,7 +46,11 @@ __global__ __launch_bounds__(256) void pass1_rows_kernel(Pass1RowArgs<TS> a, int
     const int row = blockIdx.x * ROWS_PER_BLOCK + wv * 4 + q;
     if (row >= rows_p) break;
     double s2 = 0.0;
-    if (a.V) {
+    if (a.part) {  // partial sums from the GEMM epilogue, combined in a fixed order
+      const double* pp = a.part + (int64_t)row * a.npart;
+      for (int c = lane; c < a.npart; c += 64) s2 += pp[c];
+      s2 = wave_sum(s2);
+    } else if (a.V) {
       const TS* v = a.V + (int64_t)row * a.mp;
       constexpr int NV = RowVec<TS>::N;
       for (int c = lane * NV; c < a.mp; c += 64 * NV) {
@@ -60,7 +64,7 @@ __global__ __launch_bounds__(256) void pass1_rows_kernel(Pass1RowArgs<TS> a, int
     if (lane == 0) {
       if (row < a.rows) {
         // V == null: Model.update_sigma2 (lib/fitc_gp.ml:234-236) -- r of the previous evaluation is kept
-        const double r = a.V ? a.sf2 - s2 : a.r[row];
+        const double r = (a.V || a.part) ? a.sf2 - s2 : a.r[row];
         const double s = r + a.sigma2;
         const double is = 1.0 / s;
         const double y = a.y ? a.y[row] : 0.0;
@@ -110,20 +114,31 @@ __global__ __launch_bounds__(256) void pass2_rows_kernel(Pass2RowArgs<TS> a, int
   for (int q = 0; q < 4; ++q) {
     const int row = blockIdx.x * ROWS_PER_BLOCK + wv * 4 + q;
     if (row >= rows_p) break;
-    const TS* qr = a.Q + (int64_t)row * a.mp;
     double s2 = 0.0, sb = 0.0;
-    constexpr int NV = RowVec<TS>::N;
-    for (int c = lane * NV; c < a.mp; c += 64 * NV) {
-      double x[NV];
-      RowVec<TS>::load(qr + c, x);
-#pragma unroll
-      for (int e = 0; e < NV; ++e) {
-        s2 += x[e] * x[e];
-        sb += x[e] * a.b[c + e];
+    if (a.part_sq) {
+      const double* p1 = a.part_sq + (int64_t)row * a.npart;
+      const double* p2 = a.part_dot + (int64_t)row * a.npart;
+      for (int c = lane; c < a.npart; c += 64) {
+        s2 += p1[c];
+        sb += p2[c];
       }
+      s2 = wave_sum(s2);
+      sb = wave_sum(sb);
+    } else {
+      const TS* qr = a.Q + (int64_t)row * a.mp;
+      constexpr int NV = RowVec<TS>::N;
+      for (int c = lane * NV; c < a.mp; c += 64 * NV) {
+        double x[NV];
+        RowVec<TS>::load(qr + c, x);
+#pragma unroll
+        for (int e = 0; e < NV; ++e) {
+          s2 += x[e] * x[e];
+          sb += x[e] * a.b[c + e];
+        }
+      }
+      s2 = wave_sum(s2);
+      sb = wave_sum(sb);
     }
-    s2 = wave_sum(s2);
-    sb = wave_sum(sb);
     if (lane == 0) {
       if (row < a.rows) {
         const double is = a.is[row];
