@@ -77,10 +77,15 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--n", type=int, default=1_000_000)
-    ap.add_argument("--m", type=int, default=2048)
-    ap.add_argument("--d", type=int, default=8)
+    # names chosen not to be prefixes of torch.distributed.run options (it rejects "--n", "--m" as ambiguous)
+    ap.add_argument("--points", dest="n", type=int, default=1_000_000)
+    ap.add_argument("--inducing", dest="m", type=int, default=2048)
+    ap.add_argument("--dims", dest="d", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    # validation aids (tests/test_gpu_parity.py runs the N=2 code path on a 1-GPU box with them); the
+    # driver's runs use the defaults: RCCL, one device per rank
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"])
+    ap.add_argument("--share-device", action="store_true", help="all ranks use cuda:0 (testing only)")
     args = ap.parse_args()
 
     os.environ.setdefault("GPRHIP_TIMING", "1")  # per-kernel HIP events on the library's own stream
@@ -97,10 +102,15 @@ def main():
                          % (args.gpus, world))
     if gpr_amd.device_count() < 1:
         raise SystemExit("bench.py: no HIP device; the HIP path has no CPU fallback")
+    if args.share_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo")
 
     n, m, d, seed = args.n, args.m, args.d, 2
     X, y, Z0 = synth(seed, n, m, d)
@@ -175,6 +185,8 @@ def main():
                              "frac": F / (dt / args.steps) * 1e-12 / world / PEAK_FP64_MFMA_TFLOPS,
                              "mfma_engine_ms_per_step": engine_ms},
             "stage_ms": {k_: float(np.mean(v_)) for k_, v_ in sorted(tim.items())},
+            "last_eval": {"l": float(ev.l), "dl_dsigma2": float(ev.dl_dsigma2),
+                          "grad_norm": float(np.linalg.norm(ev.grad))},
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(n, m, d, seed)

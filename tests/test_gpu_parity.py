@@ -4,6 +4,8 @@ Stated fp64 tolerances.  The device path is the whitened S
 formulation (B~ = I + V^T S^-1 V), whose rounding behaviour is of the same class as the reference's
 Householder QR of the stacked matrix; the remaining differences are summation order and exp() ulps.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -454,3 +456,38 @@ def test_headline_size_properties():
     analytic = a.grad[0] * dle + a.grad[1] * dls + a.dl_dsigma2 * ds2 + float(a.grad[2:] @ dz.T.reshape(-1))
     assert abs(fd - analytic) <= 1e-5 * max(abs(analytic), abs(a.l) * 1e-6)
     p.close()
+
+
+def _run_bench(extra, nproc):
+    import json
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    common = ["--steps", "2", "--warmup", "1", "--points", "20011", "--inducing", "200", "--dims", "4", "--no-cpu-baseline"]
+    if nproc == 1:
+        cmd = [sys.executable, "bench.py", "--gpus", "1"] + common
+    else:
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), "bench.py", "--gpus", str(nproc)] \
+            + common + extra
+    out = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout  # rank 0 prints exactly one JSON line
+    return json.loads(lines[0])
+
+
+def test_bench_two_ranks_on_one_device_match_single_rank():
+    """bench.py's N>1 code path (row shards + two all-reduces between the staged calls) on the one GPU a
+    test box has: two ranks share cuda:0 and reduce over gloo.  Same seeded hyper-parameter stream, so
+    the last evaluation must agree with the single-rank run."""
+    one = _run_bench([], 1)
+    two = _run_bench(["--backend", "gloo", "--share-device"], 2)
+    assert two["n_gpus"] == 2 and two["scaling"] == "strong"
+    for k in ("l", "dl_dsigma2", "grad_norm"):
+        a, b = one["last_eval"][k], two["last_eval"][k]
+        assert abs(a - b) <= TOL_SHARD * max(1.0, abs(a)), (k, a, b)
