@@ -77,6 +77,10 @@ SIGNATURES = {
     "gprhip_sync": (C.c_int, [_vp]),
     "gprhip_stream": (_vp, [_vp]),
     "gprhip_predict": (C.c_int, [_vp, _dp, C.c_int64, C.c_int64, C.c_int, _dp, _dp]),
+    "gprhip_train_stats": (C.c_int, [_vp, _dp, _dp]),
+    "gprhip_covariances": (C.c_int, [_vp, _dp, C.c_int64, C.c_int64, C.c_int, C.c_int, _dp]),
+    "gprhip_cov_samples": (C.c_int, [_vp, _dp, C.c_int64, C.c_int64, C.c_double, C.c_double, _dp, _dp,
+                                     C.c_int64, _dp]),
     "gprhip_debug_fetch": (C.c_int, [_vp, C.c_char_p, _dp, C.c_int64]),
     "gprhip_last_timings": (C.c_int, [_vp, C.POINTER(C.c_char_p), C.POINTER(C.c_float), C.c_int]),
     "gprhip_last_error": (C.c_char_p, []),

@@ -193,11 +193,10 @@ void tcollect(gprhip_problem* p) {
 
 // Blocked upper Cholesky A = U^T U in place (dpotrf `U; lib/fitc_gp.ml:56) -- diagonal blocks in
 // LDS, panel solve and trailing update on the MFMA engine.  dinv receives inv(U_jj) per block.
-void potrf_upper(gprhip_problem* p, double* A, int* info) {
-  const int mp = p->mp, nb = mp / TILE;
-  hipStream_t s = p->stream;
+void potrf_upper_n(hipStream_t s, double* A, int mp, double* dinv, int* info) {
+  const int nb = mp / TILE;
   for (int j = 0; j < nb; ++j) {
-    double* dj = p->dinv + (int64_t)j * TILE * TILE;
+    double* dj = dinv + (int64_t)j * TILE * TILE;
     launch_potrf_diag(A, mp, j, dj, info, s);
     if (j + 1 < nb) {
       const int rest = (nb - 1 - j) * TILE;
@@ -214,6 +213,7 @@ void potrf_upper(gprhip_problem* p, double* A, int* info) {
     }
   }
 }
+void potrf_upper(gprhip_problem* p, double* A, int* info) { potrf_upper_n(p->stream, A, p->mp, p->dinv, info); }
 
 // inv(U) for the upper-triangular factor by recursive doubling over the 128-blocks:
 //   inv([U11 U12; 0 U22]) = [X11, -X11 U12 X22; 0, X22]
@@ -793,6 +793,178 @@ void do_predict(gprhip_problem* p, const double* test_inputs, int64_t ld, int64_
   }
 }
 
+// Temporary device memory of one posterior call (sizes depend on the number of test points).
+struct DevBuf {
+  std::vector<void*> ptrs;
+  template <typename T>
+  T* get(int64_t count) {
+    void* q = nullptr;
+    hipError_t e = hipMalloc(&q, (size_t)std::max<int64_t>(count, 1) * sizeof(T));
+    if (e != hipSuccess) {
+      (void)hipGetLastError();
+      set_error("gprhip: device allocation failed (posterior buffers)");
+      throw HipFail{ST_OOM};
+    }
+    ptrs.push_back(q);
+    return static_cast<T*>(q);
+  }
+  ~DevBuf() {
+    for (void* q : ptrs) (void)hipFree(q);
+  }
+};
+
+void need_model(gprhip_problem* p, const char* who) {
+  if (!p->have_model || p->stage != 0) {
+    set_error(std::string(who) + ": no completed evaluation to work from");
+    throw HipFail{ST_STATE};
+  }
+}
+
+// Trained.calc_means (lib/fitc_gp.ml:296-297) over the resident training inputs, and the residual sums
+// Stats.calc needs (lib/fitc_gp.ml:353-373): sums = { sse, sum |y-mean|, max |y-mean|, sum y^2 }.
+template <typename TS>
+void do_train_stats(gprhip_problem* p, double* means, double* sums) {
+  need_model(p, "gprhip_train_stats");
+  if (!p->have_targets || p->h.model_only) {
+    set_error("gprhip_train_stats: the last evaluation had no targets");
+    throw HipFail{ST_STATE};
+  }
+  GPR_HIP(hipSetDevice(p->device));
+  hipStream_t s = p->stream;
+  DevBuf tmp;
+  double* rmean = tmp.get<double>(p->chunk);
+  int64_t nblocks = 0;
+  for (int c = 0; c < p->nchunks; ++c) nblocks += residual_stat_blocks((int)p->rows_of(c));
+  double* part = tmp.get<double>(nblocks * 4);
+  TS* const K = static_cast<TS*>(p->bufA);
+  int64_t b0 = 0;
+  for (int c = 0; c < p->nchunks; ++c) {
+    const int rows = (int)p->rows_of(c);
+    const int64_t lo = (int64_t)c * p->chunk;
+    cov_chunk<TS>(p, c, K);
+    launch_row_sumsq_dot<TS>(K, p->tvec, rows, p->mp, nullptr, rmean, s);
+    launch_residual_stats(p->y + lo, rmean, rows, part + b0 * 4, s);
+    b0 += residual_stat_blocks(rows);
+    if (means)
+      GPR_HIP(hipMemcpyAsync(means + lo, rmean, (size_t)rows * sizeof(double), hipMemcpyDeviceToHost, s));
+  }
+  std::vector<double> hp((size_t)nblocks * 4);
+  GPR_HIP(hipMemcpyAsync(hp.data(), part, hp.size() * sizeof(double), hipMemcpyDeviceToHost, s));
+  GPR_HIP(hipStreamSynchronize(s));
+  double sse = 0.0, sad = 0.0, mad = 0.0, sy2 = 0.0;
+  for (int64_t b = 0; b < nblocks; ++b) {
+    sse += hp[b * 4 + 0];
+    sad += hp[b * 4 + 1];
+    mad = std::max(mad, hp[b * 4 + 2]);
+    sy2 += hp[b * 4 + 3];
+  }
+  sums[0] = sse; sums[1] = sad; sums[2] = mad; sums[3] = sy2;
+}
+
+// FITC_covariances.calc / FIC_covariances.calc (lib/fitc_gp.ml:585-599, :617-627) at nt test points, fp64:
+//   V_t = K_tm U^-1, Q_t = K_tm R^-1 = V_t R~^-1
+//   FITC: K_tt - V_t V_t^T + Q_t Q_t^T          FIC: Q_t Q_t^T + diag(k_tt - rowsum(K_tm.^2))
+// (the FIC diagonal is what the reference computes at :620 -- from K_tm itself, not from V_t).
+void do_covariances(gprhip_problem* p, const double* test_inputs, int64_t ld, int64_t nt, int kind,
+                    int predictive, double* cov) {
+  need_model(p, "gprhip_covariances");
+  GPR_HIP(hipSetDevice(p->device));
+  hipStream_t s = p->stream;
+  const int mp = p->mp;
+  const int np = (int)round_up(nt, TILE);
+  DevBuf tmp;
+  double* xt = tmp.get<double>(nt * p->D);
+  double* Kt = tmp.get<double>((int64_t)np * mp);
+  double* Vt = tmp.get<double>((int64_t)np * mp);
+  double* C = tmp.get<double>((int64_t)np * np);
+  double* rv = tmp.get<double>(2 * (int64_t)np);
+  GPR_HIP(hipMemcpy2DAsync(xt, (size_t)p->D * sizeof(double), test_inputs, (size_t)ld * sizeof(double),
+                           (size_t)p->D * sizeof(double), (size_t)nt, hipMemcpyHostToDevice, s));
+  const double* pts = xt;
+  if (p->has_proj()) {
+    double* pt = tmp.get<double>(nt * p->d);
+    launch_project(xt, nt, p->D, p->d, p->tproj, pt, s);
+    pts = pt;
+  }
+  launch_cov_cross<double>(p->cp, pts, (int)nt, np, p->Z, p->m, mp, p->d, Kt, s);
+  GemmArgs g;  // trsm ~side:`R chol_km
+  g.A = Kt; g.lda = mp; g.B = p->uinv; g.ldb = mp; g.C = Vt; g.ldc = mp;
+  g.M = np; g.N = mp; g.K = mp; g.tri = TRI_KHI_BN;
+  launch_gemm(OP_NN, g, s);
+  if (kind == 0) {
+    // Inputs.calc_upper: the plain kernel between the (projected) test points, no multiscales
+    // (lib/cov_se_iso.ml:124, lib/cov_se_fat.ml:221 -> calc_upper_vanilla :85-100)
+    CovParams plain = p->cp;
+    plain.ms = nullptr;
+    launch_cov_cross<double>(plain, pts, (int)nt, np, pts, (int)nt, np, p->d, C, s);
+    GemmArgs a;  // syrk ~alpha:-1 tmp ~c:covariances
+    a.A = Vt; a.lda = mp; a.B = Vt; a.ldb = mp; a.C = C; a.ldc = np;
+    a.M = np; a.N = np; a.K = mp; a.alpha = -1.0; a.beta = 1.0;
+    launch_gemm(OP_NT, a, s);
+  } else {
+    launch_row_sumsq_dot<double>(Kt, nullptr, (int)nt, mp, rv, nullptr, s);
+    launch_const_minus(rv, (int)nt, p->cp.sf2, rv + np, s);
+  }
+  GemmArgs q;  // trsm ~side:`R r_mat  (R = R~ U)
+  q.A = Vt; q.lda = mp; q.B = p->rinv; q.ldb = mp; q.C = Kt; q.ldc = mp;
+  q.M = np; q.N = mp; q.K = mp; q.tri = TRI_KHI_BN;
+  launch_gemm(OP_NN, q, s);
+  GemmArgs b;  // syrk tmp ~c:covariances
+  b.A = Kt; b.lda = mp; b.B = Kt; b.ldb = mp; b.C = C; b.ldc = np;
+  b.M = np; b.N = np; b.K = mp; b.alpha = 1.0; b.beta = kind == 0 ? 1.0 : 0.0;
+  launch_gemm(OP_NT, b, s);
+  const double add = predictive ? p->h.sigma2 : 0.0;  // get ?predictive, :549-559
+  if (kind != 0 || add != 0.0) launch_add_diag(C, np, (int)nt, kind != 0 ? rv + np : nullptr, add, s);
+  // symmetric: row-major == column-major
+  GPR_HIP(hipMemcpy2DAsync(cov, (size_t)nt * sizeof(double), C, (size_t)np * sizeof(double),
+                           (size_t)nt * sizeof(double), (size_t)nt, hipMemcpyDeviceToHost, s));
+  GPR_HIP(hipStreamSynchronize(s));
+}
+
+// Common_cov_sampler.calc + samples (lib/fitc_gp.ml:656-697): cov_chol = chol(cov + add_diag I + jitter I)
+// (upper), samples[:, j] = means + cov_chol^T z[:, j].  z is supplied by the caller (the reference draws
+// it from GSL's ziggurat generator).
+void do_cov_samples(gprhip_problem* p, const double* cov, int64_t ld, int64_t nt, double add_diag,
+                    double jitter, const double* means, const double* z, int64_t ns, double* samples) {
+  GPR_HIP(hipSetDevice(p->device));
+  hipStream_t s = p->stream;
+  const int np = (int)round_up(nt, TILE);
+  const int nsp = (int)round_up(ns, TILE);
+  DevBuf tmp;
+  double* raw = tmp.get<double>(nt * nt);
+  double* A = tmp.get<double>((int64_t)np * np);
+  double* dinv = tmp.get<double>((int64_t)np * TILE);
+  double* Zd = tmp.get<double>((int64_t)nsp * np);
+  double* S = tmp.get<double>((int64_t)nsp * np);
+  double* mu = tmp.get<double>(nt);
+  int* info = tmp.get<int>(1);
+  GPR_HIP(hipMemcpy2DAsync(raw, (size_t)nt * sizeof(double), cov, (size_t)ld * sizeof(double),
+                           (size_t)nt * sizeof(double), (size_t)nt, hipMemcpyHostToDevice, s));
+  GPR_HIP(hipMemsetAsync(info, 0, sizeof(int), s));
+  launch_sym_from_upper(raw, nt, (int)nt, A, np, add_diag + jitter, s);
+  potrf_upper_n(s, A, np, dinv, info);
+  int hinfo = 0;
+  GPR_HIP(hipMemcpyAsync(&hinfo, info, sizeof(int), hipMemcpyDeviceToHost, s));
+  // z: Fortran nt x ns == row-major [ns][nt]
+  GPR_HIP(hipMemsetAsync(Zd, 0, (size_t)nsp * np * sizeof(double), s));
+  GPR_HIP(hipMemcpy2DAsync(Zd, (size_t)np * sizeof(double), z, (size_t)nt * sizeof(double),
+                           (size_t)nt * sizeof(double), (size_t)ns, hipMemcpyHostToDevice, s));
+  GPR_HIP(hipMemcpyAsync(mu, means, (size_t)nt * sizeof(double), hipMemcpyHostToDevice, s));
+  GemmArgs g;  // trmm ~transa:`T cov_chol samples  ==  (z^T U)^T
+  g.A = Zd; g.lda = np; g.B = A; g.ldb = np; g.C = S; g.ldc = np;
+  g.M = nsp; g.N = np; g.K = np; g.tri = TRI_KHI_BN;
+  launch_gemm(OP_NN, g, s);
+  launch_add_row_vector(S, np, (int)ns, (int)nt, mu, s);
+  GPR_HIP(hipMemcpy2DAsync(samples, (size_t)nt * sizeof(double), S, (size_t)np * sizeof(double),
+                           (size_t)nt * sizeof(double), (size_t)ns, hipMemcpyDeviceToHost, s));
+  GPR_HIP(hipStreamSynchronize(s));
+  if (hinfo != 0) {
+    set_error("Cov_sampler.calc: potrf: leading minor of order " + std::to_string(hinfo) +
+              " is not positive definite");
+    throw HipFail{ST_NOT_POSDEF};
+  }
+}
+
 template <typename F>
 int guarded(F&& f) {
   try {
@@ -1055,6 +1227,39 @@ int gprhip_predict(gprhip_problem* p, const double* test_inputs, int64_t ld, int
     }
     if (p->f32) do_predict<float>(p, test_inputs, ld, nt, predictive, means, variances);
     else do_predict<double>(p, test_inputs, ld, nt, predictive, means, variances);
+  });
+}
+
+int gprhip_train_stats(gprhip_problem* p, double* means, double* sums) {
+  return guarded([&] {
+    if (!p || !sums) {
+      set_error("gprhip_train_stats: invalid arguments");
+      throw HipFail{ST_BAD_ARG};
+    }
+    if (p->f32) do_train_stats<float>(p, means, sums);
+    else do_train_stats<double>(p, means, sums);
+  });
+}
+
+int gprhip_covariances(gprhip_problem* p, const double* test_inputs, int64_t ld, int64_t nt, int kind,
+                       int predictive, double* cov) {
+  return guarded([&] {
+    if (!p || !test_inputs || !cov || nt < 1 || ld < p->D || (kind != 0 && kind != 1) || nt > (1 << 20)) {
+      set_error("gprhip_covariances: invalid arguments");
+      throw HipFail{ST_BAD_ARG};
+    }
+    do_covariances(p, test_inputs, ld, nt, kind, predictive, cov);
+  });
+}
+
+int gprhip_cov_samples(gprhip_problem* p, const double* cov, int64_t ld, int64_t nt, double add_diag,
+                       double jitter, const double* means, const double* z, int64_t ns, double* samples) {
+  return guarded([&] {
+    if (!p || !cov || !means || !z || !samples || nt < 1 || ns < 1 || ld < nt || nt > (1 << 20)) {
+      set_error("gprhip_cov_samples: invalid arguments");
+      throw HipFail{ST_BAD_ARG};
+    }
+    do_cov_samples(p, cov, ld, nt, add_diag, jitter, means, z, ns, samples);
   });
 }
 

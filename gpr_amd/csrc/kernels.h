@@ -103,6 +103,19 @@ void launch_row_sumsq_dot(const TS* M, const double* b, int rows, int mp, double
 void launch_variance_combine(const double* k, const double* b, int rows, double sf2, double add,
                              double* var, hipStream_t s);
 
+// ---- posterior paths (posterior.hip)
+// partial[block][4] = { sum (y-mean)^2, sum |y-mean|, max |y-mean|, sum y^2 } per 256 rows  (Stats, lib/fitc_gp.ml:304-374)
+int residual_stat_blocks(int rows);
+void launch_residual_stats(const double* y, const double* mean, int rows, double* partial, hipStream_t s);
+// out (np x np row-major, symmetric, identity padding) from the upper triangle of a Fortran nt x nt matrix; diag += add
+void launch_sym_from_upper(const double* in, int64_t ld, int nt, double* out, int np, double add, hipStream_t s);
+// C[i][i] += (vec ? vec[i] : 0) + add
+void launch_add_diag(double* C, int64_t ld, int n, const double* vec, double add, hipStream_t s);
+// S[s][i] += v[i] for the ns rows of S
+void launch_add_row_vector(double* S, int64_t ld, int ns, int n, const double* v, hipStream_t s);
+// out[i] = a - x[i]
+void launch_const_minus(const double* x, int n, double a, double* out, hipStream_t s);
+
 // partial[slab][col] = sum_{rows of slab} K[row][col] * x[row]; slab = 256 rows
 template <typename TS>
 void launch_gemv_t_partial(const TS* K, int rows_p, int mp, const double* x, double* partial,

@@ -18,9 +18,13 @@ stage by stage; the device path is a two-pass streaming evaluation, so these obj
 the whole evaluation runs when the first number (log evidence, gradient entry) is requested.
 Only scalars, m-vectors and the gradient ever cross back to the host.
 
-Beyond the hot path, posterior means and variances at new inputs are provided (SURVEY.md 8(f) rank 1:
-`Eval.Means`, `Eval.Variances`).  Not provided: sampling, stats, the GSL/SGD/SMD optimisers, FIC covariances.  `FIC` / `Variational_FIC` are provided as aliases because their *evidence* is
-the FITC one (they differ only in predictive covariances, lib/fitc_gp.ml:565-624).
+Beyond the hot path: posterior means and variances at new inputs (`Eval.Mean(s)`,
+`Eval.Variance(s)`), training-set statistics (`Eval.Stats`), posterior covariance matrices
+(`Eval.Covariances`: FITC_covariances in `FITC`/`Variational_FITC`, FIC_covariances in `FIC`/
+`Variational_FIC`, lib/fitc_gp.ml:565-627 -- the only place the two families differ) and the samplers
+(`Eval.Sampler`, `Eval.Cov_sampler`; the standard normal draws come from a numpy Generator instead of
+GSL's ziggurat).  Not provided: `Covariances.calc_model_inputs` (O(n^2) over the training set), the
+GSL/SGD/SMD optimiser drivers (gpr_amd/optim.py is an L-BFGS driver over the same callbacks).
 """
 from __future__ import annotations
 
@@ -66,8 +70,16 @@ class _Model:
             return self._ev[True]
         key = bool(want_grad)
         if key not in self._ev:
-            self._ev[key] = _run(self, None, key)
+            self._ev[key] = _run(self, None, key, self)
         return self._ev[key]
+
+    def ensure_state(self):
+        """Make the device hold this model's chol_km / r_mat: the problem is shared by every model and
+        trained object built on the same inputs, and keeps the state of whichever evaluation ran last."""
+        owner = getattr(self.inputs.problem, "_state_owner", None)
+        if owner is self or (isinstance(owner, _Trained) and owner.model is self):
+            return
+        self._ev[False] = _run(self, None, False, self)
 
 
 class _Trained:
@@ -82,8 +94,13 @@ class _Trained:
 
     def evaluation(self):
         if self._ev is None:
-            self._ev = _run(self.model, self.targets, self.want_grad)
+            self._ev = _run(self.model, self.targets, self.want_grad, self)
         return self._ev
+
+    def ensure_state(self):
+        """Make the device hold this trained model's state (see _Model.ensure_state)."""
+        if self._ev is None or getattr(self.model.inputs.problem, "_state_owner", None) is not self:
+            self._ev = _run(self.model, self.targets, self.want_grad, self)
 
 
 class _HyperT:
@@ -91,7 +108,7 @@ class _HyperT:
         self.evaluation, self.kernel, self.inducing_points, self.spec = evaluation, kernel, inducing_points, spec
 
 
-def _run(model, targets, want_grad):
+def _run(model, targets, want_grad, owner):
     inputs = model.inputs
     prob = inputs.problem
     spec = prob._spec
@@ -106,11 +123,19 @@ def _run(model, targets, want_grad):
                    model_only=targets is None, want_grad=want_grad, jitter=prob._jitter, reuse_v=reuse,
                    **spec.eval_args(kernel))
     prob._last_sig = sig
+    prob._state_owner = owner
     prob._last_refs = (kernel, inputs.inducing.points)  # keep the ids alive
     return ev
 
 
-def _make_variant(spec, variational, functor):
+_default_rng = np.random.default_rng()
+
+
+def _rng(rng):
+    return _default_rng if rng is None else rng
+
+
+def _make_variant(spec, variational, functor, cov_kind="FITC"):
     def inducing_calc(kernel, points):
         return _Inducing(kernel, points)
 
@@ -174,7 +199,7 @@ def _make_variant(spec, variational, functor):
         if inputs.inducing.points is not _model_of(owner).inputs.inducing.points:
             # phys_equal check of the reference, lib/fitc_gp.ml:419-424, :499-506
             raise ValueError("Means.calc: trained and inputs disagree about inducing points")
-        owner.evaluation() if isinstance(owner, _Trained) else owner.evaluation(False)
+        owner.ensure_state()
         return _model_of(owner).inputs.problem.predict(inputs.points, predictive=predictive,
                                                        want_variances=want_variances)
 
@@ -198,6 +223,121 @@ def _make_variant(spec, variational, functor):
     Eval.Variances = SimpleNamespace(
         calc=variances_calc,                                                                   # :498-518
         get=lambda v, predictive=True: v.variances + v.sigma2 if predictive else v.variances)  # :520-529
+
+    # ---- single-point prediction (Input / Mean / Variance, lib/fitc_gp.ml:88-101, :402-414, :447-482)
+    class _Input:
+        def __init__(self, inducing, point):
+            self.inducing = inducing
+            self.point = np.ascontiguousarray(point, dtype=np.float64)
+            self.points = np.asfortranarray(self.point.reshape(-1, 1))
+
+    class _Mean:
+        def __init__(self, point, value):
+            self.point, self.value = point, value
+
+    class _Variance:
+        def __init__(self, point, variance, sigma2):
+            self.point, self.variance, self.sigma2 = point, variance, sigma2
+
+    Eval.Input = SimpleNamespace(calc=lambda inducing, point: _Input(inducing, point))
+    Eval.Mean = SimpleNamespace(
+        calc=lambda mean_predictor, inp: _Mean(inp.point, float(_predict(mean_predictor, inp, False, False)[0][0])),
+        get=lambda mean: mean.value)
+    Eval.Variance = SimpleNamespace(
+        calc=lambda cvp, sigma2, inp: _Variance(inp.point, float(_predict(cvp, inp, False, True)[1][0]), sigma2),
+        get=lambda v, predictive=True: v.variance + v.sigma2 if predictive else v.variance)
+
+    # ---- Stats (lib/fitc_gp.ml:304-374): residual sums on the device, the derived figures here
+    def stats_calc(trained):
+        trained.ensure_state()
+        ev = trained.evaluation()
+        sums, _ = trained.model.inputs.problem.train_stats()
+        n = trained.targets.shape[0]
+        sse, sad, maxad, sy2 = (float(x) for x in sums)
+        target_variance = sy2 / n                                 # :318
+        mse = sse / n
+        prior_l = -0.5 * np.log(2.0 * np.pi * target_variance) - 0.5   # :329-330
+        return SimpleNamespace(n_samples=n, target_variance=target_variance, sse=sse, mse=mse,
+                               rmse=float(np.sqrt(mse)), smse=mse / target_variance,
+                               msll=float(prior_l - ev.l / n), mad=sad / n, maxad=maxad)
+
+    Eval.Stats = SimpleNamespace(
+        calc=stats_calc,
+        calc_n_samples=lambda trained: trained.targets.shape[0],
+        calc_target_variance=lambda trained: float(trained.targets @ trained.targets) / trained.targets.shape[0],
+        calc_sse=lambda trained: stats_calc(trained).sse, calc_mse=lambda trained: stats_calc(trained).mse,
+        calc_rmse=lambda trained: stats_calc(trained).rmse, calc_smse=lambda trained: stats_calc(trained).smse,
+        calc_msll=lambda trained: stats_calc(trained).msll, calc_mad=lambda trained: stats_calc(trained).mad,
+        calc_maxad=lambda trained: stats_calc(trained).maxad)
+    Eval.Trained.calc_means = lambda trained: (trained.ensure_state(),
+                                               trained.model.inputs.problem.train_stats(True)[1])[1]  # :296-297
+
+    # ---- Covariances (FITC_covariances / FIC_covariances, lib/fitc_gp.ml:565-627) and samplers (:629-697)
+    class _Covariances:
+        def __init__(self, points, covariances, sigma2, problem):
+            self.points, self.covariances, self.sigma2, self._problem = points, covariances, sigma2, problem
+
+    def covariances_calc(cvp, sigma2, inputs):
+        owner = cvp
+        if inputs.inducing.points is not _model_of(owner).inputs.inducing.points:
+            raise ValueError("%s_covariances.calc: co-variance predictor and inputs disagree about "
+                             "inducing points" % cov_kind)                      # :537-546
+        owner.ensure_state()
+        prob = _model_of(owner).inputs.problem
+        return _Covariances(inputs.points, prob.covariances(inputs.points, kind=cov_kind), sigma2, prob)
+
+    def covariances_get(c, predictive=True):
+        if not predictive:
+            return c.covariances
+        res = c.covariances.copy()
+        res[np.diag_indices(res.shape[0])] += c.sigma2                          # :549-559
+        return res
+
+    def covariances_calc_model_inputs(_model):
+        raise NotImplementedError("Covariances.calc_model_inputs (O(n^2) over the training set) is not provided")
+
+    Eval.Covariances = SimpleNamespace(
+        calc=covariances_calc, get=covariances_get, calc_model_inputs=covariances_calc_model_inputs,
+        get_variances=lambda c: _Variances(np.diag(c.covariances).copy(), c.sigma2))   # :564-565
+
+    class _Sampler:
+        def __init__(self, mean, stddev):
+            self.mean, self.stddev = mean, stddev
+
+    def sampler_calc(mean, variance, predictive=True):
+        if mean.point is not variance.point:                                    # :633-635
+            raise ValueError("%s.Sampler: mean and variance disagree about input point" % cov_kind)
+        used = variance.variance + variance.sigma2 if predictive else variance.variance
+        return _Sampler(mean.value, float(np.sqrt(used)))
+
+    Eval.Sampler = SimpleNamespace(
+        calc=sampler_calc,
+        sample=lambda sampler, rng=None: sampler.mean + sampler.stddev * _rng(rng).standard_normal(),
+        samples=lambda sampler, n, rng=None: sampler.mean + sampler.stddev * _rng(rng).standard_normal(n))
+
+    class _CovSampler:
+        def __init__(self, means, covariances, add_diag):
+            self.means, self.covariances, self.add_diag = means, covariances, add_diag
+
+        def draw(self, z):
+            return self.covariances._problem.cov_samples(self.covariances.covariances, self.means, z,
+                                                         add_diag=self.add_diag, jitter=functor.jitter)
+
+    def cov_sampler_calc(means, covariances, predictive=True, points=None):
+        """Common_cov_sampler.calc (:659-675).  `means` is the vector Means.get returns; pass `points` (the
+        matrix the means were computed at) to have the reference's phys_equal check applied."""
+        if points is not None and points is not covariances.points:
+            raise ValueError("%s.Cov_sampler: means and covariances disagree about input points" % cov_kind)
+        smp = _CovSampler(np.asarray(means, dtype=np.float64), covariances,
+                          covariances.sigma2 if predictive else 0.0)
+        smp.draw(np.zeros((smp.means.shape[0], 1)))   # factor now: potrf failures surface in calc, as in :673
+        return smp
+
+    Eval.Cov_sampler = SimpleNamespace(
+        calc=cov_sampler_calc,
+        sample=lambda smp, rng=None: smp.draw(_rng(rng).standard_normal((smp.means.shape[0], 1)))[:, 0],
+        samples=lambda smp, n, rng=None: smp.draw(_rng(rng).standard_normal((smp.means.shape[0], n))),
+        samples_from=lambda smp, z: smp.draw(z))
 
     def prepare_hyper_model(model):
         return _HyperT(model.evaluation(True), model.inputs.inducing.kernel, model.inputs.inducing.points, spec)
@@ -274,8 +414,8 @@ class Make_deriv:
         self._problems = {}
         self.FITC = _make_variant(spec, False, self)
         self.Variational_FITC = _make_variant(spec, True, self)
-        self.FIC = self.FITC
-        self.Variational_FIC = self.Variational_FITC
+        self.FIC = _make_variant(spec, False, self, "FIC")
+        self.Variational_FIC = _make_variant(spec, True, self, "FIC")
 
     def close(self):
         for p in self._problems.values():

@@ -142,6 +142,45 @@ class Problem:
                                             _f64_ptr(var) if want_variances else None))
         return means, var
 
+    def train_stats(self, want_means=False):
+        """Residual sums of the training set under the last evaluation's mean coefficients
+        (Trained.calc_means + the loops of Stats.calc, lib/fitc_gp.ml:296-297, :353-373).
+        Returns (sums = [sse, sum|y-mean|, max|y-mean|, sum y^2], means or None)."""
+        sums = np.empty(4, dtype=np.float64)
+        means = np.empty(self.n, dtype=np.float64) if want_means else None
+        _lib.check(self._lib.gprhip_train_stats(self._h, _f64_ptr(means) if want_means else None,
+                                                _f64_ptr(sums)))
+        return sums, means
+
+    def covariances(self, test_inputs, kind="FITC", predictive=False):
+        """FITC_covariances.calc / FIC_covariances.calc (lib/fitc_gp.ml:585-599, :617-627): nt x nt posterior
+        covariance between the test points (full symmetric matrix)."""
+        xt = np.asfortranarray(test_inputs, dtype=np.float64)
+        if xt.ndim != 2 or xt.shape[0] != self.D:
+            raise ValueError("covariances: expected test inputs of shape (%d, nt)" % self.D)
+        nt = xt.shape[1]
+        cov = np.empty((nt, nt), dtype=np.float64, order="F")
+        _lib.check(self._lib.gprhip_covariances(self._h, _f64_ptr(xt), self.D, nt, {"FITC": 0, "FIC": 1}[kind],
+                                                int(predictive), _f64_ptr(cov)))
+        return cov
+
+    def cov_samples(self, covariances, means, z, add_diag=0.0, jitter=CHOLESKY_JITTER):
+        """Common_cov_sampler.calc + samples (lib/fitc_gp.ml:656-697): means + chol(cov + (add_diag+jitter) I)^T z
+        for every column of z (nt x ns standard normal draws)."""
+        cov = np.asfortranarray(covariances, dtype=np.float64)
+        nt = cov.shape[0]
+        means = np.ascontiguousarray(means, dtype=np.float64)
+        z = np.asfortranarray(z, dtype=np.float64)
+        if z.ndim == 1:
+            z = np.asfortranarray(z.reshape(nt, 1))
+        if cov.shape != (nt, nt) or means.shape != (nt,) or z.shape[0] != nt:
+            raise ValueError("cov_samples: shapes of covariances/means/z disagree")
+        ns = z.shape[1]
+        out = np.empty((nt, ns), dtype=np.float64, order="F")
+        _lib.check(self._lib.gprhip_cov_samples(self._h, _f64_ptr(cov), nt, nt, float(add_diag), float(jitter),
+                                                _f64_ptr(means), _f64_ptr(z), ns, _f64_ptr(out)))
+        return out
+
     # ---- staged evaluation (row-sharded across devices; see gpr_amd/dist.py)
     def ar1_len(self):
         return int(self._lib.gprhip_ar1_len(self._h))

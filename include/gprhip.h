@@ -156,6 +156,31 @@ void* gprhip_stream(gprhip_problem* p);
 int gprhip_predict(gprhip_problem* p, const double* test_inputs, int64_t ld, int64_t nt, int predictive,
                    double* means, double* variances);
 
+/* Training-set residual statistics with the model state left by the last evaluation (which must have had
+ * targets): means[i] = K_nm[i,:] . coeffs over the resident training inputs (Trained.calc_means,
+ * lib/fitc_gp.ml:296-297; host, n doubles, may be NULL) and
+ *   sums[0] = sum (y-mean)^2   sums[1] = sum |y-mean|   sums[2] = max |y-mean|   sums[3] = sum y^2
+ * from which Stats.calc (lib/fitc_gp.ml:353-373) derives sse/mse/rmse/smse/msll/mad/maxad.  For a row shard
+ * the sums are this shard's; combine with sum/sum/max/sum. */
+int gprhip_train_stats(gprhip_problem* p, double* means, double* sums);
+
+/* Posterior covariance matrix between nt test points (fp64 in both precision modes):
+ *   kind 0: FITC_covariances.calc  K_tt - V_t V_t^T + Q_t Q_t^T                    lib/fitc_gp.ml:585-599
+ *   kind 1: FIC_covariances.calc   Q_t Q_t^T + diag(k_tt - rowsum(K_tm .^ 2))      lib/fitc_gp.ml:617-627
+ * with V_t = K_tm U^-1, Q_t = K_tm R^-1.  predictive != 0 adds sigma2 to the diagonal (Common_covariances.get,
+ * :549-559).  test_inputs: Fortran D x nt (ld >= D), host.  cov: nt x nt, ld = nt, host; the full symmetric
+ * matrix is written (the reference defines the upper triangle only). */
+int gprhip_covariances(gprhip_problem* p, const double* test_inputs, int64_t ld, int64_t nt, int kind,
+                       int predictive, double* cov);
+
+/* Common_cov_sampler.calc + samples (lib/fitc_gp.ml:656-697): factor chol(cov + (add_diag + jitter) I) (upper
+ * triangle of the Fortran nt x nt `cov`, ld >= nt, is read) and return samples[:, j] = means + chol^T z[:, j]
+ * for the ns columns of z (Fortran nt x ns standard normal draws supplied by the caller; samples likewise).
+ * add_diag = sigma2 for ?predictive = true, else 0; jitter = Utils.cholesky_jitter.  Uses only the device
+ * and stream of `p`.  GPRHIP_ENOTPOSDEF if the factorisation fails. */
+int gprhip_cov_samples(gprhip_problem* p, const double* cov, int64_t ld, int64_t nt, double add_diag,
+                       double jitter, const double* means, const double* z, int64_t ns, double* samples);
+
 /* Intermediates of the last evaluation, for parity tests (copied to host; sizes in doubles):
  *   "r" n, "is" n, "v" n, "w" n, "t" m.  Returns GPRHIP_EBADARG for an unknown name. */
 int gprhip_debug_fetch(gprhip_problem* p, const char* name, double* out, int64_t len);

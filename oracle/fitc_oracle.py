@@ -651,6 +651,88 @@ def predict_variances(k, inducing_points, model, test_inputs, predictive=True):
     return var + model["sigma2"] if predictive else var
 
 
+def spec_inputs_calc_upper(k, inputs):
+    """Spec.Eval.Inputs.calc_upper: lib/cov_se_iso.ml:124 (= Inducing.calc_upper on the inputs) and
+    lib/cov_se_fat.ml:221 (calc_upper_vanilla of the projected inputs: no multiscales, no hetero term).
+    Strict lower triangle NaN, as the reference leaves it undefined."""
+    inputs = _F(inputs)
+    if isinstance(k, SeIsoKernel):
+        return se_iso_calc_upper_with_sqr_diff(k, se_iso_calc_sqr_diff_upper(inputs))
+    return se_fat_calc_upper_vanilla(k, se_fat_project(k, inputs))
+
+
+def _syrk_upper(alpha, a, beta, c):
+    """dsyrk `U ~trans:`N: the upper triangle of alpha*a*a^T + beta*c; lower triangle of c kept."""
+    return _F(blas.dsyrk(alpha, a, beta=beta, c=c, lower=0, trans=0, overwrite_c=0))
+
+
+def fitc_covariances(k, inducing_points, model, test_inputs):
+    """FITC_covariances.calc lib/fitc_gp.ml:585-599: calc_upper - syrk(K_tm chol_km^-1) + syrk(K_tm r_mat^-1).
+    Upper triangle defined."""
+    ktm, _ = spec_calc_shared_cross(k, test_inputs, inducing_points)
+    cov = spec_inputs_calc_upper(k, test_inputs)
+    cov = np.triu(np.nan_to_num(cov, nan=0.0))  # dsyrk never reads the lower triangle; keep it finite
+    tmp = _F(blas.dtrsm(1.0, model["inducing"]["chol_km"], ktm, side=1, lower=0, trans_a=0))
+    cov = _syrk_upper(-1.0, tmp, 1.0, _F(cov))
+    tmp = _F(blas.dtrsm(1.0, model["r_mat"], ktm, side=1, lower=0, trans_a=0))
+    cov = _syrk_upper(1.0, tmp, 1.0, cov)
+    return np.triu(cov)
+
+
+def fic_covariances(k, inducing_points, model, test_inputs):
+    """FIC_covariances.calc lib/fitc_gp.ml:617-627 -> calc_common :603-609.  Note :620: the diagonal
+    correction is Mat.syrk_diag ~alpha:-1 ktm -- computed from K_tm itself."""
+    ktm, _ = spec_calc_shared_cross(k, test_inputs, inducing_points)
+    kt_diag = spec_calc_diag(k, ktm.shape[0])
+    r_vec = kt_diag - np.einsum("ij,ij->i", ktm, ktm)
+    q_mat = _F(blas.dtrsm(1.0, model["r_mat"], ktm, side=1, lower=0, trans_a=0))
+    nt = ktm.shape[0]
+    cov = _syrk_upper(1.0, q_mat, 0.0, np.zeros((nt, nt), order="F"))
+    cov[np.diag_indices(nt)] += r_vec
+    return np.triu(cov)
+
+
+def covariances_get(cov, sigma2, predictive=True):
+    """Common_covariances.get_common lib/fitc_gp.ml:549-559."""
+    if not predictive:
+        return cov
+    res = cov.copy()
+    res[np.diag_indices(res.shape[0])] += sigma2
+    return res
+
+
+def cov_sampler_calc(means, cov, sigma2, predictive=True, jitter=CHOLESKY_JITTER):
+    """Common_cov_sampler.calc lib/fitc_gp.ml:659-675: potrf of cov (+sigma2) + jitter."""
+    a = np.triu(cov).copy()
+    n = a.shape[0]
+    if predictive:
+        a[np.diag_indices(n)] += sigma2
+    a[np.diag_indices(n)] += jitter
+    return dict(means=np.asarray(means, dtype=np.float64), cov_chol=potrf_upper(_F(a)))
+
+
+def cov_sampler_samples(sampler, z):
+    """Common_cov_sampler.samples lib/fitc_gp.ml:685-697 with the standard normal draws `z` (n_means x n)
+    given instead of drawn from GSL: trmm ~transa:`T cov_chol z, then + means per column."""
+    z = _F(z)
+    res = _F(blas.dtrmm(1.0, sampler["cov_chol"], z, side=0, lower=0, trans_a=1, diag=0))
+    return res + sampler["means"][:, None]
+
+
+def stats_calc(y, means, l):
+    """Stats.calc lib/fitc_gp.ml:353-373 given the training means (Trained.calc_means :296-297)."""
+    y = np.asarray(y, dtype=np.float64)
+    n = y.shape[0]
+    target_variance = float(y @ y) / n                      # :318 (Vec.sqr_nrm2 y / n -- no centring)
+    sse = float(np.sum((y - means) ** 2))
+    mse = sse / n
+    prior_l = -0.5 * math.log(2.0 * math.pi * target_variance) - 0.5   # :329-330
+    ad = np.abs(y - means)
+    return dict(n_samples=n, target_variance=target_variance, sse=sse, mse=mse, rmse=math.sqrt(mse),
+                smse=mse / target_variance, msll=prior_l - l / n, mad=float(np.sum(ad)) / n,
+                maxad=float(np.max(ad)))
+
+
 # ---------------------------------------------------------------------------
 # One full evaluation, the reference way (multim_dcommon lib/fitc_gp.ml:1612-1636)
 # ---------------------------------------------------------------------------

@@ -48,6 +48,29 @@ def save(name, k, X, y, Z, sigma2, variational, extra):
     print(name, "l=%.12g" % out["l"], "n_hypers=%d" % len(out["grad"]))
 
 
+def save_posterior(name, k, X, y, Z, sigma2, Xt, z, extra):
+    """Posterior quantities either side of the evidence path: Means/Variances,
+    FITC_/FIC_covariances, Cov_sampler with the given draws z, Stats."""
+    out = O.evaluate(k, Z, X, y, sigma2, want_grad=False, keep=True)
+    knm, _ = O.spec_calc_shared_cross(k, X, Z)
+    train_means = knm @ out["coeffs"]
+    st = O.stats_calc(y, train_means, out["l"])
+    means = O.predict_means(k, Z, out["coeffs"], Xt)
+    fitc = O.fitc_covariances(k, Z, out["model"], Xt)
+    fic = O.fic_covariances(k, Z, out["model"], Xt)
+    smp = O.cov_sampler_calc(means, fitc, sigma2, predictive=True)
+    np.savez_compressed(
+        os.path.join(HERE, name + ".npz"), X=X, y=y, Z=Z, sigma2=sigma2, Xt=Xt, z=z, l=out["l"],
+        coeffs=out["coeffs"], train_means=train_means, means=means,
+        variances=O.predict_variances(k, Z, out["model"], Xt, predictive=False),
+        fitc_cov=fitc, fic_cov=fic, samples=O.cov_sampler_samples(smp, z),
+        stats=np.array([st[key] for key in STAT_KEYS], dtype=np.float64), **extra)
+    print(name, "l=%.12g" % out["l"], "rmse=%.6g" % st["rmse"])
+
+
+STAT_KEYS = ("n_samples", "target_variance", "sse", "mse", "rmse", "smse", "msll", "mad", "maxad")
+
+
 def main():
     # C1 shape of BASELINE.json (n=2000 m=50 d=3), seed 1, standard + variational
     X, y, Z = synth(1, 2000, 50, 3)
@@ -100,6 +123,16 @@ def main():
     kn = O.SeFatKernel(4, -0.1, None)
     save("fat_noproj", kn, Xa, ya, np.asfortranarray(Xa[:, :16] + 0.01), 0.2, False,
          dict(kind="fat", d=4, log_sf2=-0.1))
+    # posterior fixtures: iso at a ragged size, and Cov_se_fat with projection + hetero + multiscales
+    # (K_tt of the covariances is the plain kernel of the projected test points, lib/cov_se_fat.ml:221)
+    prng = np.random.default_rng(99)
+    X, y, Z = synth(41, 500, 20, 2)
+    save_posterior("posterior_iso", O.SeIsoKernel(0.2, 0.1), X, y, Z, 0.15,
+                   np.asfortranarray(prng.normal(size=(2, 37))), np.asfortranarray(prng.normal(size=(37, 4))),
+                   dict(kind="iso", log_ell=0.2, log_sf2=0.1))
+    save_posterior("posterior_fat_all", kall, Xb, yb, Zf, 0.1,
+                   np.asfortranarray(prng.normal(size=(5, 29))), np.asfortranarray(prng.normal(size=(29, 3))),
+                   dict(kind="fat", d=3, log_sf2=0.2, tproj=P, log_hetero=lh, log_multiscales=lms))
 
 
 if __name__ == "__main__":

@@ -12,7 +12,8 @@ import pytest
 import gpr_amd
 from gpr_amd import cov_se_fat, cov_se_iso, fitc_gp
 from oracle import fitc_oracle as O
-from tests.util import golden_names, load_golden, oracle_kernel, relinf, synth
+from tests.util import (STAT_KEYS, golden_names, load_golden, oracle_kernel, posterior_golden_names, relinf,
+                        synth)
 
 pytestmark = pytest.mark.gpu
 
@@ -37,7 +38,7 @@ def _problem_for(g, chunk_rows=0):
 
 def _eval_golden(p, g, **kw):
     args = dict(log_sf2=float(g["log_sf2"]), sigma2=float(g["sigma2"]), inducing=g["Z"],
-                variational=bool(g["variational"]))
+                variational=bool(g.get("variational", False)))
     if g["kind"] == "iso":
         args["log_ell"] = float(g["log_ell"])
     else:
@@ -491,3 +492,123 @@ def test_bench_two_ranks_on_one_device_match_single_rank():
     for k in ("l", "dl_dsigma2", "grad_norm"):
         a, b = one["last_eval"][k], two["last_eval"][k]
         assert abs(a - b) <= TOL_SHARD * max(1.0, abs(a)), (k, a, b)
+
+
+def test_stats_covariances_and_samplers():
+    """Stats (lib/fitc_gp.ml:304-374), FITC_/FIC_covariances (:565-627), Cov_sampler and Sampler
+    (:629-697) on the device against the oracle -- directly on the C ABI and through the mirrored modules.
+    nt is not a multiple of the tile and the training set spans several chunks."""
+    n, m, d, nt = 3000, 130, 3, 301
+    X, y, Z = synth(33, n, m, d)
+    rng = np.random.default_rng(8)
+    Xt = np.asfortranarray(rng.normal(size=(d, nt)))
+    k = O.SeIsoKernel(0.35, 0.15)
+    s2 = 0.2
+    ref = O.evaluate(k, Z, X, y, s2, want_grad=False, keep=True)
+    knm, _ = O.spec_calc_shared_cross(k, X, Z)
+    tm_ref = knm @ ref["coeffs"]
+    st_ref = O.stats_calc(y, tm_ref, ref["l"])
+    fitc_ref = O.fitc_covariances(k, Z, ref["model"], Xt)
+    fic_ref = O.fic_covariances(k, Z, ref["model"], Xt)
+    mean_ref = O.predict_means(k, Z, ref["coeffs"], Xt)
+
+    p = gpr_amd.Problem(gpr_amd.COV_SE_ISO, n, d, d, m, chunk_rows=1024)
+    p.set_inputs(X)
+    p.set_targets(y)
+    p.eval(log_ell=0.35, log_sf2=0.15, sigma2=s2, inducing=Z, want_grad=False)
+    sums, tm = p.train_stats(want_means=True)
+    assert relinf(tm, tm_ref) <= 1e-8
+    assert abs(sums[0] - st_ref["sse"]) <= 1e-8 * st_ref["sse"]
+    assert abs(sums[1] / n - st_ref["mad"]) <= 1e-8 * st_ref["mad"]
+    assert abs(sums[2] - st_ref["maxad"]) <= 1e-8 * st_ref["maxad"]
+    assert abs(sums[3] / n - st_ref["target_variance"]) <= 1e-12 * st_ref["target_variance"]
+    scale = np.max(np.abs(np.diag(fitc_ref)))
+    for kind, cref in (("FITC", fitc_ref), ("FIC", fic_ref)):
+        cov = p.covariances(Xt, kind=kind)
+        assert np.array_equal(cov, cov.T)
+        assert np.max(np.abs(np.triu(cov) - cref)) <= 1e-8 * max(scale, np.max(np.abs(cref)))
+        covp = p.covariances(Xt, kind=kind, predictive=True)
+        assert np.allclose(np.diag(covp), np.diag(cov) + s2, rtol=0, atol=1e-12)
+    cov = p.covariances(Xt, kind="FITC")
+    _, var = p.predict(Xt, predictive=False)
+    assert np.max(np.abs(np.diag(cov) - var)) <= 1e-9 * scale
+    # sampler: same z through the oracle's potrf/trmm
+    z = rng.normal(size=(nt, 5))
+    smp_ref = O.cov_sampler_calc(mean_ref, fitc_ref, s2, predictive=True)
+    S_ref = O.cov_sampler_samples(smp_ref, z)
+    S = p.cov_samples(cov, mean_ref, z, add_diag=s2)
+    assert S.shape == (nt, 5) and np.max(np.abs(S - S_ref)) <= 1e-9 * np.max(np.abs(S_ref))
+    # z = I returns means + chol^T column by column: chol^T chol must rebuild the matrix
+    L = p.cov_samples(cov, np.zeros(nt), np.eye(nt), add_diag=s2)          # = chol^T
+    assert np.max(np.abs(np.triu(L, 1))) == 0.0
+    full = cov + (s2 + 1e-6) * np.eye(nt)
+    assert np.max(np.abs(L @ L.T - full)) <= 1e-12 * np.max(np.abs(full))
+    with pytest.raises(gpr_amd.NotPositiveDefinite):
+        p.cov_samples(-np.eye(nt), np.zeros(nt), z)
+    p.close()
+
+    GP = fitc_gp.Make_deriv(cov_se_iso)
+    kernel = cov_se_iso.Kernel.create(cov_se_iso.Params(0.35, 0.15))
+    for F, cref in ((GP.FITC, fitc_ref), (GP.FIC, fic_ref)):
+        E = F.Eval
+        inducing = E.Inducing.calc(kernel, Z)
+        model = E.Model.calc(E.Inputs.calc(X, inducing), sigma2=s2)
+        trained = E.Trained.calc(model, targets=y)
+        st = E.Stats.calc(trained)
+        for key in ("target_variance", "sse", "mse", "rmse", "smse", "msll", "mad", "maxad"):
+            assert abs(getattr(st, key) - st_ref[key]) <= 1e-8 * abs(st_ref[key]), key
+        assert st.n_samples == n and abs(E.Stats.calc_rmse(trained) - st_ref["rmse"]) <= 1e-8
+        assert relinf(E.Trained.calc_means(trained), tm_ref) <= 1e-8
+        tin = E.Inputs.calc(Xt, inducing)
+        covs = E.Covariances.calc(E.Co_variance_predictor.calc_model(model), s2, tin)
+        assert np.max(np.abs(np.triu(E.Covariances.get(covs, predictive=False)) - cref)) <= 1e-8 * scale
+        assert np.allclose(np.diag(E.Covariances.get(covs)), np.diag(cref) + s2, rtol=0, atol=1e-8)
+        v = E.Covariances.get_variances(covs)
+        assert np.allclose(E.Variances.get(v, predictive=False), np.diag(cref), rtol=0, atol=1e-8)
+    E = GP.FITC.Eval
+    means = E.Means.get(E.Means.calc(E.Mean_predictor.calc_trained(trained), tin))
+    smp = E.Cov_sampler.calc(means, E.Covariances.calc(model, s2, tin), predictive=True, points=tin.points)
+    S2 = E.Cov_sampler.samples_from(smp, z)
+    assert np.max(np.abs(S2 - S_ref)) <= 1e-8 * np.max(np.abs(S_ref))
+    draws = E.Cov_sampler.samples(smp, 64, rng=np.random.default_rng(0))
+    assert draws.shape == (nt, 64) and np.all(np.isfinite(draws))
+    assert E.Cov_sampler.sample(smp, rng=np.random.default_rng(1)).shape == (nt,)
+    # single-point modules
+    inp = E.Input.calc(inducing, Xt[:, 7])
+    mean1 = E.Mean.calc(trained, inp)
+    var1 = E.Variance.calc(model, s2, inp)
+    assert abs(E.Mean.get(mean1) - mean_ref[7]) <= 1e-8 * np.max(np.abs(mean_ref))
+    assert abs(E.Variance.get(var1, predictive=False) - fitc_ref[7, 7]) <= 1e-8 * scale
+    one = E.Sampler.calc(mean1, var1)
+    assert abs(one.stddev - np.sqrt(fitc_ref[7, 7] + s2)) <= 1e-8
+    assert E.Sampler.samples(one, 10, rng=np.random.default_rng(2)).shape == (10,)
+    GP.close()
+
+
+@pytest.mark.parametrize("name", posterior_golden_names())
+def test_golden_posterior(name):
+    """Committed posterior fixtures (tests/golden/make_golden.py save_posterior): prediction, both covariance
+    families, the covariance sampler with fixed draws, training-set statistics; iso and Cov_se_fat with
+    projection + heteroskedastic + multiscale terms."""
+    g = load_golden(name)
+    p = _problem_for(g, chunk_rows=256)
+    ev = _eval_golden(p, g, want_grad=False)
+    assert abs(ev.l - g["l"]) <= TOL_L * abs(g["l"])
+    s2 = float(g["sigma2"])
+    means, var = p.predict(g["Xt"], predictive=False)
+    assert relinf(means, g["means"]) <= 1e-8
+    assert relinf(var, g["variances"]) <= 1e-8
+    scale = max(np.max(np.abs(g["fitc_cov"])), np.max(np.abs(g["fic_cov"])))
+    cov = p.covariances(g["Xt"], kind="FITC")
+    assert np.max(np.abs(np.triu(cov) - g["fitc_cov"])) <= 1e-8 * scale
+    assert np.max(np.abs(np.triu(p.covariances(g["Xt"], kind="FIC")) - g["fic_cov"])) <= 1e-8 * scale
+    S = p.cov_samples(cov, means, g["z"], add_diag=s2)
+    assert np.max(np.abs(S - g["samples"])) <= 1e-8 * np.max(np.abs(g["samples"]))
+    sums, tm = p.train_stats(want_means=True)
+    assert relinf(tm, g["train_means"]) <= 1e-8
+    st = dict(zip(STAT_KEYS, g["stats"]))
+    n = int(st["n_samples"])
+    assert abs(sums[0] - st["sse"]) <= 1e-8 * st["sse"] and abs(sums[1] / n - st["mad"]) <= 1e-8 * st["mad"]
+    assert abs(sums[2] - st["maxad"]) <= 1e-8 * st["maxad"]
+    assert abs(sums[3] / n - st["target_variance"]) <= 1e-12 * st["target_variance"]
+    p.close()

@@ -6,7 +6,8 @@ import numpy as np
 import pytest
 
 from oracle import fitc_oracle as O
-from tests.util import golden_names, load_golden, oracle_kernel, relinf, synth
+from tests.util import (STAT_KEYS, golden_names, load_golden, oracle_kernel, posterior_golden_names, relinf,
+                        synth)
 
 
 @pytest.mark.parametrize("variational", [False, True])
@@ -218,3 +219,65 @@ def test_error_behaviour():
     Zdup = np.asfortranarray(np.repeat(Z[:, :1], 3, axis=1))
     # duplicate inducing points are only saved by the jitter (lib/utils.ml:35): still factorises
     O.evaluate(k, Zdup, X, y, 0.1, want_grad=False)
+
+
+def test_covariances_sampler_and_stats_against_dense_posterior():
+    """FITC_/FIC_covariances, Cov_sampler and Stats (lib/fitc_gp.ml:304-374, :533-697) against the textbook
+    FITC posterior  cov = K** - K*m (K_m^-1 - B^-1) Km*  and direct definitions."""
+    X, y, Z = synth(17, 160, 8, 2)
+    k = O.SeIsoKernel(0.2, -0.1)
+    out = O.evaluate(k, Z, X, y, 0.3, want_grad=False, keep=True)
+    rng = np.random.default_rng(3)
+    Xt = np.asfortranarray(rng.normal(size=(2, 11)))
+    km, _ = O.spec_calc_shared_upper(k, Z)
+    km = np.triu(km) + np.triu(km, 1).T + O.CHOLESKY_JITTER * np.eye(8)
+    knm, _ = O.spec_calc_shared_cross(k, X, Z)
+    ktm, _ = O.spec_calc_shared_cross(k, Xt, Z)
+    s = k.sf2 - np.einsum("ij,ji->i", knm, np.linalg.solve(km, knm.T)) + 0.3
+    B = km + (knm / s[:, None]).T @ knm
+    ktt = O.spec_inputs_calc_upper(k, Xt)
+    ktt = np.triu(ktt) + np.triu(ktt, 1).T
+    ref = ktt - ktm @ (np.linalg.inv(km) - np.linalg.inv(B)) @ ktm.T
+    cov = O.fitc_covariances(k, Z, out["model"], Xt)
+    assert np.max(np.abs(cov - np.triu(ref))) < 1e-7
+    # its diagonal is Variances.calc (Common_covariances.get_variances, lib/fitc_gp.ml:564-565)
+    assert np.allclose(np.diag(cov), O.predict_variances(k, Z, out["model"], Xt, predictive=False), atol=1e-10)
+    # FIC: Q_t Q_t^T + diag(k** - rowsum(K_tm^2)) exactly as lib/fitc_gp.ml:603-627 writes it
+    fic = O.fic_covariances(k, Z, out["model"], Xt)
+    fic_ref = ktm @ np.linalg.inv(B) @ ktm.T + np.diag(k.sf2 - np.sum(ktm * ktm, axis=1))
+    assert np.max(np.abs(fic - np.triu(fic_ref))) < 1e-7
+    assert np.allclose(np.diag(O.covariances_get(cov, 0.3)), np.diag(cov) + 0.3)
+    # sampler: chol^T chol == cov + sigma2 + jitter; with z = I the samples are means + rows of chol
+    means = O.predict_means(k, Z, out["coeffs"], Xt)
+    smp = O.cov_sampler_calc(means, cov, 0.3, predictive=True)
+    u = np.triu(smp["cov_chol"])
+    full = np.triu(cov) + np.triu(cov, 1).T + (0.3 + O.CHOLESKY_JITTER) * np.eye(11)
+    assert np.max(np.abs(u.T @ u - full)) < 1e-12
+    S = O.cov_sampler_samples(smp, np.eye(11))
+    assert np.max(np.abs(S - (u.T + means[:, None]))) < 1e-14
+    # stats
+    tm = knm @ out["coeffs"]
+    st = O.stats_calc(y, tm, out["l"])
+    assert st["n_samples"] == 160 and abs(st["mse"] - np.mean((y - tm) ** 2)) < 1e-14
+    assert abs(st["smse"] - st["mse"] / np.mean(y * y)) < 1e-14
+    assert abs(st["msll"] - (-0.5 * np.log(2 * np.pi * np.mean(y * y)) - 0.5 - out["l"] / 160)) < 1e-14
+    assert abs(st["mad"] - np.mean(np.abs(y - tm))) < 1e-14 and st["maxad"] == np.max(np.abs(y - tm))
+
+
+@pytest.mark.parametrize("name", posterior_golden_names())
+def test_posterior_golden_fixtures_reproduce(name):
+    g = load_golden(name)
+    k = oracle_kernel(g)
+    s2 = float(g["sigma2"])
+    out = O.evaluate(k, g["Z"], g["X"], g["y"], s2, want_grad=False, keep=True)
+    assert abs(out["l"] - g["l"]) < 1e-12 * abs(g["l"])
+    means = O.predict_means(k, g["Z"], out["coeffs"], g["Xt"])
+    assert relinf(means, g["means"]) < 1e-12
+    fitc = O.fitc_covariances(k, g["Z"], out["model"], g["Xt"])
+    assert relinf(fitc, g["fitc_cov"]) < 1e-12
+    assert relinf(O.fic_covariances(k, g["Z"], out["model"], g["Xt"]), g["fic_cov"]) < 1e-12
+    smp = O.cov_sampler_calc(means, fitc, s2, predictive=True)
+    assert relinf(O.cov_sampler_samples(smp, g["z"]), g["samples"]) < 1e-11
+    knm, _ = O.spec_calc_shared_cross(k, g["X"], g["Z"])
+    st = O.stats_calc(g["y"], knm @ out["coeffs"], out["l"])
+    assert relinf([st[key] for key in STAT_KEYS], g["stats"]) < 1e-12

@@ -8,8 +8,21 @@ from oracle import fitc_oracle as O
 GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
-def golden_names():
+def _names():
     return sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
+
+
+def golden_names():
+    """Evidence + gradient fixtures."""
+    return [n for n in _names() if not n.startswith("posterior_")]
+
+
+def posterior_golden_names():
+    """Prediction / covariance / sampler / stats fixtures (make_golden.save_posterior)."""
+    return [n for n in _names() if n.startswith("posterior_")]
+
+
+STAT_KEYS = ("n_samples", "target_variance", "sse", "mse", "rmse", "smse", "msll", "mad", "maxad")
 
 
 def load_golden(name):
