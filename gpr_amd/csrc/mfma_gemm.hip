@@ -312,31 +312,49 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgsT<T> g) {
     T cv[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) cv[j] = (T)g.epi_col[col0 + j * 32];
+    // per 16-row group: issue every load of the group (4 rows x (4 M values + 3 row scalars)) before the first
+    // use, so a block pays 4 memory round trips here instead of one per row
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 4; ++i) {
+      T mv[4][4], ra[4], rb[4], rc[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int row = rowb + i * 16 + G::crow(lq, r);
-        const T ra = (T)g.epi_rows_a[row], rb = (T)g.epi_rows_b[row], rc = (T)g.epi_rows_c[row];
+        ra[r] = (T)g.epi_rows_a[row];
+        rb[r] = (T)g.epi_rows_b[row];
+        rc[r] = (T)g.epi_rows_c[row];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) mv[r][j] = Mp[(int64_t)row * g.epi_ldm + j * 32];
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = rowb + i * 16 + G::crow(lq, r);
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-          Cp[(int64_t)row * g.ldc + j * 32] =
-              ra * acc[i][j][r] - rb * Mp[(int64_t)row * g.epi_ldm + j * 32] - rc * cv[j];
+          Cp[(int64_t)row * g.ldc + j * 32] = ra[r] * acc[i][j][r] - rb[r] * mv[r][j] - rc[r] * cv[j];
       }
+    }
     return;
   }
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < 4; ++i) {
+    T old[4][4];
+    if (beta != (T)0) {  // all 16 loads of the row group in flight before the first use
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) old[j][r] = Cp[(int64_t)(rowb + i * 16 + G::crow(lq, r)) * g.ldc + j * 32];
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        T* p = Cp + (int64_t)(rowb + i * 16 + G::crow(lq, r)) * g.ldc + j * 32;
         T v = alpha * acc[i][j][r];
-        if (beta != (T)0) v += beta * (*p);
-        *p = v;
+        if (beta != (T)0) v += beta * old[j][r];
+        Cp[(int64_t)(rowb + i * 16 + G::crow(lq, r)) * g.ldc + j * 32] = v;
         acc[i][j][r] = v;  // the stored value, for the row reductions below
       }
+  }
   if (g.rp_sumsq) {
     // wavefront row reductions over this wave's 64 columns: 4 values in-thread, then the 16 lanes of a
     // row group by xor-shuffles; lane l15 == 0 writes one partial per (row, tile, wave column)
