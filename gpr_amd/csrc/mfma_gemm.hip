@@ -13,6 +13,7 @@
 //       disjoint bank ranges.
 // Fragment maps (cdna_hip_programming.md section 3): A lane l holds A[i=l&15][k=l>>4], B lane l holds
 // B[k=l>>4][j=l&15]; C/D lane l reg r holds C[(l>>4)+4r][l&15] for f64 and C[4(l>>4)+r][l&15] for f32.
+#include <type_traits>
 #include "mfma_gemm.h"
 
 namespace gprhip {
@@ -100,6 +101,22 @@ __device__ __forceinline__ void tile_of_block(const GemmArgsT<T>& g, int b, int 
     bm = b % nbm;
   }
   bn = (g.tri == TRI_KHI_BN) ? (nbn - 1 - bi) : bi;
+}
+
+// Value of lane (l ^ O) within each row of 16 lanes, O in {1, 2, 4, 8}, through DPP register moves (no LDS
+// crossbar): quad_perm for 1 and 2, row_half_mirror + quad_perm[3,2,1,0] for 4 (l^7^3), row_ror:8 for 8.
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+template <int O>
+__device__ __forceinline__ double xor16(double v) {
+  if constexpr (O == 1) return dpp_mov<0xB1>(v);
+  else if constexpr (O == 2) return dpp_mov<0x4E>(v);
+  else if constexpr (O == 4) return dpp_mov<0x1B>(dpp_mov<0x141>(v));
+  else return dpp_mov<0x128>(v);
 }
 
 template <typename T, int OP>
@@ -381,21 +398,25 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgsT<T> g) {
       }
     // transposing butterfly over the 16 lanes of a row group: 8+4+2+1 exchanges leave lane l15 with the
     // total of value k = l15 (i = l15 >> 2, r = l15 & 3)
-#pragma unroll
-    for (int o = 8; o > 0; o >>= 1) {
+    auto fold = [&](auto oc) {
+      constexpr int o = decltype(oc)::value;
       const bool hi = (l15 & o) != 0;
 #pragma unroll
       for (int k = 0; k < o; ++k) {
         const double keep = hi ? s2[k + o] : s2[k];
         const double send = hi ? s2[k] : s2[k + o];
-        s2[k] = keep + __shfl_xor(send, o);
+        s2[k] = keep + xor16<o>(send);
         if (g.rp_dot) {
           const double keepd = hi ? sd[k + o] : sd[k];
           const double sendd = hi ? sd[k] : sd[k + o];
-          sd[k] = keepd + __shfl_xor(sendd, o);
+          sd[k] = keepd + xor16<o>(sendd);
         }
       }
-    }
+    };
+    fold(std::integral_constant<int, 8>{});
+    fold(std::integral_constant<int, 4>{});
+    fold(std::integral_constant<int, 2>{});
+    fold(std::integral_constant<int, 1>{});
     const int64_t idx = (int64_t)(rowb + (l15 >> 2) * 16 + G::crow(lq, l15 & 3)) * npart + 2 * bn + wc;
     g.rp_sumsq[idx] = s2[0];
     if (g.rp_dot) g.rp_dot[idx] = sd[0];
