@@ -29,6 +29,13 @@ __device__ __forceinline__ double bcast_lane(double v, int l) {
   return __hiloint2double(hi, lo);
 }
 
+typedef double pd4 __attribute__((ext_vector_type(4)));
+// v_mfma_f64_16x16x4_f64: lane supplies A[lane&15][lane>>4] and B[lane>>4][lane&15]; accumulator element r is
+// D[(lane>>4) + 4r][lane&15]
+__device__ __forceinline__ pd4 mfma_f64(double a, double b, pd4 c) {
+  return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+}
+
 __device__ __forceinline__ double* dblk(double* T, int b) {
   // home of the inverse of diagonal micro-block b: the free block just below the diagonal (b<7: (b+1,b); 7: (7,0))
   return (b < 7) ? T + ((b + 1) * MB) * LDT + b * MB : T + (7 * MB) * LDT;
@@ -60,29 +67,38 @@ __global__ __launch_bounds__(PT) void potrf_diag_kernel(double* __restrict__ A, 
   const int rh = tid >> 7;        // row phase 0..3
   constexpr int RS = PT / NB;     // row stride
   for (int k0 = 0; k0 < ((flags & 1) ? 0 : NB); k0 += MB) {
-    if (wid == 0) {
+    if (wid == 0 && !(flags & 4)) {
       const int cc = lane & 15;   // lanes 16..63 mirror lanes 0..15
       double a[MB];
 #pragma unroll
       for (int r = 0; r < MB; ++r) a[r] = T[(k0 + r) * LDT + k0 + cc];
+      // Per step the dependent chain is: pivot broadcast -> 1/sqrt (v_rsq_f64 + one third-order correction, no
+      // separate sqrt and divide) -> scale the row -> update the next pivot's entry.  Pivots are O(jitter)..O(m)
+      // here, so no denormal pre-scaling; a non-positive (or NaN) pivot is recorded and replaced by 1.
+      int badq = 0;
+      double myrp = 0.0;
 #pragma unroll
       for (int q = 0; q < MB; ++q) {
         double dq = bcast_lane(a[q], q);
-        if (!(dq > 0.0)) {
-          if (lane == 0 && bad == 0) bad = k0 + q + 1;
-          dq = 1.0;  // keep going with finite numbers; the caller reads `info`
-        }
-        const double piv = sqrt(dq);
-        const double rp = 1.0 / piv;
-        double uqc = (cc == q) ? piv : a[q] * rp;
+        const bool ok = dq > 0.0;
+        badq = (!ok && badq == 0) ? k0 + q + 1 : badq;
+        dq = ok ? dq : 1.0;  // keep going with finite numbers; the caller reads `info`
+        double y = __builtin_amdgcn_rsq(dq);
+        const double e = fma(-dq * y, y, 1.0);
+        y = fma(y * e, fma(0.375, e, 0.5), y);        // rsqrt to ~1 ulp
+        double piv = dq * y;
+        piv = fma(fma(-piv, piv, dq), 0.5 * y, piv);  // sqrt(dq), one Heron correction
+        const double uqc = (cc == q) ? piv : a[q] * y;
         a[q] = uqc;
-        if (lane == q) rdiag[k0 + q] = rp;
+        myrp = (cc == q) ? y : myrp;
 #pragma unroll
         for (int r = q + 1; r < MB; ++r) {
           const double uqr = bcast_lane(uqc, r);
           a[r] -= uqr * uqc;
         }
       }
+      if (lane < MB) rdiag[k0 + cc] = myrp;
+      if (lane == 0 && badq != 0 && bad == 0) bad = badq;
       if (lane < MB) {
 #pragma unroll
         for (int r = 0; r < MB; ++r)
@@ -91,7 +107,7 @@ __global__ __launch_bounds__(PT) void potrf_diag_kernel(double* __restrict__ A, 
     }
     __syncthreads();
     // panel: U12 = U11^-T A12, one thread per column (forward substitution in registers)
-    if (tid < NB && tid >= k0 + MB) {
+    if (tid < NB && tid >= k0 + MB && !(flags & 8)) {
       double x[MB];
 #pragma unroll
       for (int q = 0; q < MB; ++q) {
@@ -104,17 +120,29 @@ __global__ __launch_bounds__(PT) void potrf_diag_kernel(double* __restrict__ A, 
       for (int q = 0; q < MB; ++q) T[(k0 + q) * LDT + tid] = x[q];
     }
     __syncthreads();
-    // trailing: A22 -= U12^T U12 on the upper triangle
-    if (c >= k0 + MB) {
-      double uc[MB];
+    // trailing: A22 -= U12^T U12, one 16x16 tile (ti <= tj) per wavefront at a time, 4 MFMAs per tile
+    if (!(flags & 16)) {
+      const int b1 = k0 / MB + 1, nt = NB / MB - b1;
+      const int ntile = nt * (nt + 1) / 2;
+      const int l15 = lane & 15, lq = lane >> 4;
+      for (int t = wid; t < ntile; t += PT / 64) {
+        int ti = 0, rem = t;
+        while (rem >= nt - ti) {
+          rem -= nt - ti;
+          ++ti;
+        }
+        const int ci = (b1 + ti) * MB, cj = (b1 + ti + rem) * MB;
+        double* Ct = T + (ci + lq) * LDT + cj + l15;
+        pd4 acc;
 #pragma unroll
-      for (int q = 0; q < MB; ++q) uc[q] = T[(k0 + q) * LDT + c];
-#pragma unroll 2
-      for (int r = k0 + MB + rh; r <= c; r += RS) {
-        double s = T[r * LDT + c];
+        for (int r = 0; r < 4; ++r) acc[r] = Ct[4 * r * LDT];
 #pragma unroll
-        for (int q = 0; q < MB; ++q) s -= T[(k0 + q) * LDT + r] * uc[q];
-        T[r * LDT + c] = s;
+        for (int kk = 0; kk < 4; ++kk) {
+          const double* urow = T + (k0 + 4 * kk + lq) * LDT;
+          acc = mfma_f64(-urow[ci + l15], urow[cj + l15], acc);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Ct[4 * r * LDT] = acc[r];
       }
     }
     __syncthreads();
@@ -154,38 +182,43 @@ __global__ __launch_bounds__(PT) void potrf_diag_kernel(double* __restrict__ A, 
       }
     }
     __syncthreads();
-    for (int j0 = 0; j0 < NB; j0 += MB) {
-      const double* D = dblk(T, j0 / MB);
-      // T1[r][q..q+3] = sum_{k=r..j0-1} X[r][k] U[k][j0+q..]   (X = already inverted leading block, in place)
-      for (int idx = tid; idx < j0 * (MB / 4); idx += PT) {
-        const int r = idx / (MB / 4), q = (idx % (MB / 4)) * 4;
-        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-        for (int k = r; k < j0; ++k) {
-          const double xv = T[r * LDT + k];
-          const double* u = T + k * LDT + j0 + q;
-          s0 += xv * u[0];
-          s1 += xv * u[1];
-          s2 += xv * u[2];
-          s3 += xv * u[3];
+    // block column b of the inverse, in place (LAPACK dtrtri order): wavefront ri < b owns the 16x16 tile (ri, b):
+    //   T1 = sum_{kt=ri}^{b-1} X(ri,kt) U(kt,b)   (X = the already inverted leading block; 4 MFMAs per kt)
+    //   X(ri,b) = -T1 D_b                           (T1 re-laid out as an A operand through the wave's LDS scratch)
+    // wavefront b copies D_b onto the diagonal tile.  All reads of U(.,b) finish before the first write.
+    const int l15 = lane & 15, lq = lane >> 4;
+    for (int b = 0; b < NB / MB; ++b) {
+      const double* D = dblk(T, b);
+      const int cb = b * MB;
+      pd4 t1 = {0.0, 0.0, 0.0, 0.0};
+      if (wid < b) {
+        const int rb = wid * MB;
+        for (int kt = wid; kt < b; ++kt) {
+#pragma unroll
+          for (int kk = 0; kk < 4; ++kk) {
+            const int k = kt * MB + 4 * kk + lq;
+            t1 = mfma_f64(T[(rb + l15) * LDT + k], T[k * LDT + cb + l15], t1);
+          }
         }
-        double* o = T1 + r * MB + q;
-        o[0] = s0; o[1] = s1; o[2] = s2; o[3] = s3;
+        double* scr = T1 + wid * (MB * MB);   // [16][16] per wavefront
+#pragma unroll
+        for (int r = 0; r < 4; ++r) scr[(lq + 4 * r) * MB + l15] = t1[r];
       }
       __syncthreads();
-      // X[0:j0, j0+q] = -sum_{i<=q} T1[r][i] D[i][q];  X[jj] = D
-      for (int idx = tid; idx < (j0 + MB) * MB; idx += PT) {
-        const int r = idx / MB, q = idx % MB;
-        double v;
-        if (r < j0) {
-          double s = 0.0;
+      if (wid < b) {
+        const int rb = wid * MB;
+        const double* scr = T1 + wid * (MB * MB);
+        pd4 x = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-          for (int i = 0; i < MB; ++i)
-            if (i <= q) s += T1[r * MB + i] * D[i * LDT + q];
-          v = -s;
-        } else {
-          v = D[(r - j0) * LDT + q];
+        for (int kk = 0; kk < 4; ++kk) {
+          const int k = 4 * kk + lq;
+          x = mfma_f64(-scr[l15 * MB + k], D[k * LDT + l15], x);
         }
-        T[r * LDT + j0 + q] = v;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) T[(rb + lq + 4 * r) * LDT + cb + l15] = x[r];
+      } else if (wid == b) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) T[(cb + lq + 4 * r) * LDT + cb + l15] = D[(lq + 4 * r) * LDT + l15];
       }
       __syncthreads();
     }

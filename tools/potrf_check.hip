@@ -13,7 +13,7 @@ int main() {
   double *dA, *dD; int* dI;
   hipMalloc(&dA, n*n*8); hipMalloc(&dD, n*n*8); hipMalloc(&dI, 8); hipMemset(dI, 0, 8);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-  for (int flags = 0; flags < 4; ++flags) {
+  for (int flags : {0, 1, 2, 3, 2 + 4, 2 + 8, 2 + 16, 2 + 4 + 8 + 16}) {
     float best = 1e9;
     for (int rep = 0; rep < 5; ++rep) {
       hipMemcpy(dA, A.data(), n*n*8, hipMemcpyHostToDevice);
@@ -22,7 +22,7 @@ int main() {
       hipEventRecord(e1, 0); hipEventSynchronize(e1);
       float ms; hipEventElapsedTime(&ms, e0, e1); best = std::min(best, ms);
     }
-    printf("flags=%d (bit0 skip factor, bit1 skip invert): %.1f us\n", flags, best * 1e3);
+    printf("flags=%d (1 skip factor, 2 skip invert, 4 skip diag16, 8 skip panel solve, 16 skip trailing): %.1f us\n", flags, best * 1e3);
   }
   // correctness of the full kernel
   hipMemcpy(dA, A.data(), n*n*8, hipMemcpyHostToDevice);
