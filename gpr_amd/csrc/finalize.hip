@@ -31,6 +31,27 @@ void launch_sum_slices(const double* base, const TS* slices, int nslices, int64_
 template void launch_sum_slices<double>(const double*, const double*, int, int64_t, int, double*, hipStream_t);
 template void launch_sum_slices<float>(const double*, const float*, int, int64_t, int, double*, hipStream_t);
 
+// dst[b][r][c] = sum_z slices[z][b][r][c] over a rows x cols rectangle (leading dimension ld, batch stride bs;
+// slices and dst share offsets): combines the split-K partial products of small GEMM launches in a fixed order.
+__global__ __launch_bounds__(256) void sum_slices_rect_kernel(const double* __restrict__ slices, int nslices,
+                                                              int64_t stride, int rows, int cols, int64_t ld,
+                                                              int64_t bs, double* __restrict__ dst) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  const int r = blockIdx.y;
+  if (c >= cols) return;
+  const int64_t off = (int64_t)blockIdx.z * bs + (int64_t)r * ld + c;
+  double acc = 0.0;
+  for (int z = 0; z < nslices; ++z) acc += slices[(int64_t)z * stride + off];
+  dst[off] = acc;
+}
+
+void launch_sum_slices_rect(const double* slices, int nslices, int64_t stride, int rows, int cols, int64_t ld,
+                            int nbatch, int64_t bs, double* dst, hipStream_t s) {
+  hipLaunchKernelGGL(sum_slices_rect_kernel, dim3((cols + 255) / 256, rows, nbatch), dim3(256), 0, s, slices,
+                     nslices, stride, rows, cols, ld, bs, dst);
+  GPR_HIP(hipGetLastError());
+}
+
 __global__ void to_float_kernel(const double* __restrict__ src, float* __restrict__ dst, int64_t n) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i < n) dst[i] = (float)src[i];

@@ -103,6 +103,7 @@ struct gprhip_problem {
   int f32 = 0;
   size_t esz = 8;
   void* slices = nullptr;
+  int64_t slices_bytes = 0;
   double *rowpart = nullptr, *gemvpart = nullptr, *colpart = nullptr, *scalpart = nullptr,
          *kmpart = nullptr, *kmred = nullptr;
   double *ar1 = nullptr, *ar2 = nullptr;  // internal exchange buffers for single-device eval
@@ -229,20 +230,45 @@ void trtri_upper(gprhip_problem* p, const double* U, double* X, double* tmp) {
     const int nfull = (int)(mp / pair);                 // pairs with two full halves
     const int64_t rem = mp - (int64_t)nfull * pair;     // a trailing pair with a short second half?
     auto join = [&](int64_t off, int64_t s2, int nb) {
+      // The late levels have few output tiles and long k-ranges: split k over up to 8 slices so the launch fills
+      // the chip (partial products go to the split-K scratch at the destination's offsets, then a fixed-order sum)
+      const int64_t blocks = (int64_t)nb * (sz / TILE) * (s2 / TILE);
+      auto slices_for = [&](int64_t kdim) {
+        int ks = 1;
+        while (ks < 8 && blocks * ks * 2 <= 256 && kdim / (ks * 2) >= 256) ks *= 2;
+        return (double*)p->slices && (int64_t)ks * mp * mp * 8 <= p->slices_bytes ? ks : 1;
+      };
+      double* const sl = static_cast<double*>(p->slices);
       // T = U12 * X22   (X22 upper triangular)
       GemmArgs a;
       a.A = U + off * mp + off + sz; a.lda = mp; a.B = X + (off + sz) * (mp + 1); a.ldb = mp;
       a.C = tmp + off * mp + off + sz; a.ldc = mp;
       a.M = (int)sz; a.N = (int)s2; a.K = (int)s2; a.tri = TRI_KHI_BN;
       a.nbatch = nb; a.batch_a = a.batch_b = a.batch_c = pair * (mp + 1);
-      launch_gemm(OP_NN, a, s);
+      const int ksa = slices_for(s2);
+      if (ksa > 1) {
+        a.C = sl + off * mp + off + sz; a.kslices = ksa; a.slice_stride = (int64_t)mp * mp;
+        launch_gemm(OP_NN, a, s);
+        launch_sum_slices_rect(sl + off * mp + off + sz, ksa, (int64_t)mp * mp, (int)sz, (int)s2, mp, nb,
+                               pair * (mp + 1), tmp + off * mp + off + sz, s);
+      } else {
+        launch_gemm(OP_NN, a, s);
+      }
       // X12 = -X11 * T  (X11 upper triangular)
       GemmArgs b;
       b.A = X + off * (mp + 1); b.lda = mp; b.B = tmp + off * mp + off + sz; b.ldb = mp;
       b.C = X + off * mp + off + sz; b.ldc = mp;
       b.M = (int)sz; b.N = (int)s2; b.K = (int)sz; b.tri = TRI_KLO_BM; b.alpha = -1.0;
       b.nbatch = nb; b.batch_a = b.batch_b = b.batch_c = pair * (mp + 1);
-      launch_gemm(OP_NN, b, s);
+      const int ksb = slices_for(sz);
+      if (ksb > 1) {
+        b.C = sl + off * mp + off + sz; b.kslices = ksb; b.slice_stride = (int64_t)mp * mp;
+        launch_gemm(OP_NN, b, s);
+        launch_sum_slices_rect(sl + off * mp + off + sz, ksb, (int64_t)mp * mp, (int)sz, (int)s2, mp, nb,
+                               pair * (mp + 1), X + off * mp + off + sz, s);
+      } else {
+        launch_gemm(OP_NN, b, s);
+      }
     };
     if (nfull > 0) join(0, sz, nfull);
     if (rem > sz) join((int64_t)nfull * pair, rem - sz, 1);
@@ -1068,7 +1094,8 @@ int gprhip_problem_create_ex(int device, int cov_kind, int precision, int64_t n,
       p->uinv_f = p->alloc<float>(mm);
       p->rinv_f = p->alloc<float>(mm);
     }
-    p->slices = p->alloc<char>((int64_t)p->kslices * mm * p->esz);
+    p->slices_bytes = (int64_t)p->kslices * mm * p->esz;
+    p->slices = p->alloc<char>(p->slices_bytes);
     p->rowpart = p->alloc<double>((int64_t)pass1_row_blocks((int)chunk) * 4);
     p->gemvpart = p->alloc<double>(((npad + 255) / 256) * mp);
     const int64_t nslab = (chunk + grad_slab_rows() - 1) / grad_slab_rows();

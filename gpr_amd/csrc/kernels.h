@@ -103,6 +103,10 @@ void launch_row_sumsq_dot(const TS* M, const double* b, int rows, int mp, double
 void launch_variance_combine(const double* k, const double* b, int rows, double sf2, double add,
                              double* var, hipStream_t s);
 
+// dst = sum over split-K slices on a batched rows x cols rectangle (slices and dst share offsets)
+void launch_sum_slices_rect(const double* slices, int nslices, int64_t stride, int rows, int cols, int64_t ld,
+                            int nbatch, int64_t bs, double* dst, hipStream_t s);
+
 // ---- posterior paths (posterior.hip)
 // partial[block][4] = { sum (y-mean)^2, sum |y-mean|, max |y-mean|, sum y^2 } per 256 rows  (Stats, lib/fitc_gp.ml:304-374)
 int residual_stat_blocks(int rows);

@@ -86,6 +86,10 @@ __device__ __forceinline__ void tile_of_block(const GemmArgsT<T>& g, int b, int 
     bm = t;
     return;
   }
+  if (g.kslices > 1) {  // full grid with split-K: the slices of one output tile set run back to back
+    slice = b / (nbm * nbn);
+    b %= nbm * nbn;
+  }
   if (g.tri == TRI_KLO_BM) {
     bm = b / nbn;
     bn = b % nbn;
@@ -446,8 +450,8 @@ static void launch_gemm_t(GemmOp op, const GemmArgsT<T>& g, hipStream_t stream) 
   }
   const int nbm = g.M / TILE, nbn = g.N / TILE;
   int tiles = g.upper_only ? nbn * (nbn + 1) / 2 : nbm * nbn;
-  if (g.kslices > 1 && !g.upper_only) {
-    set_error("gprhip: launch_gemm: split-K is implemented for upper_only (SYRK-shaped) launches");
+  if (g.kslices > 1 && (g.beta != 0.0 || g.epi_rows_a || g.rp_sumsq)) {
+    set_error("gprhip: launch_gemm: split-K launches write plain partial products (no beta / fused epilogue)");
     throw HipFail{ST_BAD_ARG};
   }
   dim3 grid(tiles * (g.kslices > 1 ? g.kslices : 1), g.nbatch > 1 ? g.nbatch : 1);

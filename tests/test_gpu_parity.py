@@ -146,10 +146,10 @@ def test_mid_size_against_oracle():
     p.close()
 
 
-@pytest.mark.parametrize("m", [640, 800])
+@pytest.mark.parametrize("m", [640, 800, 1100, 2048])
 def test_odd_block_counts_of_the_triangular_inverse(m):
-    """m/128 = 5 and 7: exercises the ragged joins of the recursive triangular inverse and the
-    split-K / tile enumeration away from powers of two."""
+    """m/128 = 5, 7, 9 (padded), 16: exercises the ragged joins of the recursive triangular inverse, its
+    split-K late levels (m >= 1024) and the tile enumeration away from powers of two."""
     n, d = 3000, 4
     X, y, Z = synth(17, n, m, d)
     ref = O.evaluate_fast(O.SeIsoKernel(0.7, 0.0), Z, X, y, 0.1)
