@@ -216,6 +216,22 @@ void potrf_upper_n(hipStream_t s, double* A, int mp, double* dinv, int* info) {
 }
 void potrf_upper(gprhip_problem* p, double* A, int* info) { potrf_upper_n(p->stream, A, p->mp, p->dinv, info); }
 
+// A non-batched m x m product with few output tiles and a long k-range, split over `ks` k-slices so that the
+// launch fills the chip; partial products go to the split-K scratch and are summed in a fixed order.
+void gemm_splitk(gprhip_problem* p, GemmOp op, GemmArgs g, int ks) {
+  const int64_t mm = (int64_t)p->mp * p->mp;
+  if (ks < 2 || (int64_t)ks * mm * 8 > p->slices_bytes || g.ldc != p->mp) {
+    launch_gemm(op, g, p->stream);
+    return;
+  }
+  double* const dst = g.C;
+  g.C = static_cast<double*>(p->slices);
+  g.kslices = ks;
+  g.slice_stride = mm;
+  launch_gemm(op, g, p->stream);
+  launch_sum_slices_rect(static_cast<double*>(p->slices), ks, mm, g.M, g.N, p->mp, 1, 0, dst, p->stream);
+}
+
 // inv(U) for the upper-triangular factor by recursive doubling over the 128-blocks:
 //   inv([U11 U12; 0 U22]) = [X11, -X11 U12 X22; 0, X22]
 // Level s joins neighbouring inverted diagonal blocks of s rows; all joins of a level are independent
@@ -618,11 +634,13 @@ void do_finish(gprhip_problem* p, const double* ar2, gprhip_result* res, double*
     GemmArgs y;  // Y = W~ U^-T
     y.A = p->wtil; y.lda = mp; y.B = p->uinv; y.ldb = mp; y.C = p->bmat; y.ldc = mp;
     y.M = mp; y.N = mp; y.K = mp; y.tri = TRI_KLO_BN;
-    launch_gemm(OP_NT, y, s);
+    int wks = ((int64_t)(mp / TILE) * (mp / TILE) <= 256 && mp >= 1024) ? 4 : 1;
+    if (const char* e = getenv("GPRHIP_WKS")) wks = atoi(e);
+    gemm_splitk(p, OP_NT, y, wks);
     GemmArgs w;  // W = U^-1 Y   (lib/fitc_gp.ml:1196-1203)
     w.A = p->uinv; w.lda = mp; w.B = p->bmat; w.ldb = mp; w.C = p->wmat; w.ldc = mp;
     w.M = mp; w.N = mp; w.K = mp; w.tri = TRI_KLO_BM;
-    launch_gemm(OP_NN, w, s);
+    gemm_splitk(p, OP_NN, w, wks);
     if (p->has_ms()) {
       launch_km_traces_ms(p->wmat, p->km, p->Z, p->ms, m, mp, d, p->kmpart, s);
       launch_reduce_rows(p->kmpart, nkslab, (2 * d + 2) * mp, p->kmred, 0, s);

@@ -155,7 +155,9 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgsT<T> g) {
   // k-range of this block, in elements
   int k_lo = 0, k_hi = g.K;
   if (g.kslices > 1) {
-    int per = ((g.K / BK + g.kslices - 1) / g.kslices) * BK;
+    // triangular operands: slices end on 128-block boundaries, so a diagonal block never straddles two slices
+    const int gran = (g.tri != TRI_NONE) ? TILE : BK;
+    int per = ((g.K / gran + g.kslices - 1) / g.kslices) * gran;
     k_lo = slice * per;
     k_hi = min(g.K, k_lo + per);
   }

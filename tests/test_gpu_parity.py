@@ -146,11 +146,11 @@ def test_mid_size_against_oracle():
     p.close()
 
 
-@pytest.mark.parametrize("m", [640, 800, 1100, 2048])
+@pytest.mark.parametrize("m", [640, 800, 1100, 2048, 3100])
 def test_odd_block_counts_of_the_triangular_inverse(m):
-    """m/128 = 5, 7, 9 (padded), 16: exercises the ragged joins of the recursive triangular inverse, its
+    """m/128 = 5, 7, 9 (padded), 16, 25 (an odd k-range under split-K): exercises the ragged joins of the recursive triangular inverse, its
     split-K late levels (m >= 1024) and the tile enumeration away from powers of two."""
-    n, d = 3000, 4
+    n, d = max(3000, m + 500), 4
     X, y, Z = synth(17, n, m, d)
     ref = O.evaluate_fast(O.SeIsoKernel(0.7, 0.0), Z, X, y, 0.1)
     p = gpr_amd.Problem(gpr_amd.COV_SE_ISO, n, d, d, m)
