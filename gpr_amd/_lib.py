@@ -81,6 +81,8 @@ SIGNATURES = {
     "gprhip_covariances": (C.c_int, [_vp, _dp, C.c_int64, C.c_int64, C.c_int, C.c_int, _dp]),
     "gprhip_cov_samples": (C.c_int, [_vp, _dp, C.c_int64, C.c_int64, C.c_double, C.c_double, _dp, _dp,
                                      C.c_int64, _dp]),
+    "gprhip_co_variance_coeffs": (C.c_int, [_vp, _dp, _dp]),
+    "gprhip_load_predictor": (C.c_int, [_vp, C.POINTER(Hypers), _dp, _dp, _dp]),
     "gprhip_debug_fetch": (C.c_int, [_vp, C.c_char_p, _dp, C.c_int64]),
     "gprhip_last_timings": (C.c_int, [_vp, C.POINTER(C.c_char_p), C.POINTER(C.c_float), C.c_int]),
     "gprhip_last_error": (C.c_char_p, []),

@@ -61,6 +61,10 @@ __global__ __launch_bounds__(PT) void potrf_diag_kernel(double* __restrict__ A, 
   }
   if (tid == 0) bad = 0;
   __syncthreads();
+  if (flags & 1) {  // block already holds a factor (model import): only its inverse is wanted
+    if (tid < NB) rdiag[tid] = 1.0 / T[tid * LDT + tid];
+    __syncthreads();
+  }
 
   // ---------------- factor
   const int c = tid & (NB - 1);   // column owned in the panel / trailing phases

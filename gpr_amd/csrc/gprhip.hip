@@ -97,6 +97,7 @@ struct gprhip_problem {
   double *rp1 = nullptr, *rp2 = nullptr;  // per-row partial sums from the GEMM epilogues [chunk][2*mp/128]
   double *xt = nullptr, *pt = nullptr, *prow = nullptr;  // prediction: test-point chunk, its projection, 3 row vectors
   bool have_model = false;
+  bool have_factors = false;  // U^-1 / R~^-1 valid (false after a means-only gprhip_load_predictor)
   // n x m storage: double, or float in the fp32-bulk mode (element size `esz`)
   void *bufA = nullptr, *bufB = nullptr, *Vstore = nullptr;
   float *uinv_f = nullptr, *rinv_f = nullptr;  // fp32 copies of U^-1 / R~^-1 (fp32-bulk mode)
@@ -632,13 +633,13 @@ void do_finish(gprhip_problem* p, const double* ar2, gprhip_result* res, double*
     tstart(p, "finish");
     launch_build_w(p->binv, p->ttil, ar2, mp, p->wtil, s);
     GemmArgs y;  // Y = W~ U^-T
-    y.A = p->wtil; y.lda = mp; y.B = p->uinv; y.ldb = mp; y.C = p->bmat; y.ldc = mp;
+    y.A = p->wtil; y.lda = mp; y.B = p->uinv; y.ldb = mp; y.C = p->kj; y.ldc = mp;  // kj is free after potrf; R~ stays in bmat
     y.M = mp; y.N = mp; y.K = mp; y.tri = TRI_KLO_BN;
     int wks = ((int64_t)(mp / TILE) * (mp / TILE) <= 256 && mp >= 1024) ? 4 : 1;
     if (const char* e = getenv("GPRHIP_WKS")) wks = atoi(e);
     gemm_splitk(p, OP_NT, y, wks);
     GemmArgs w;  // W = U^-1 Y   (lib/fitc_gp.ml:1196-1203)
-    w.A = p->uinv; w.lda = mp; w.B = p->bmat; w.ldb = mp; w.C = p->wmat; w.ldc = mp;
+    w.A = p->uinv; w.lda = mp; w.B = p->kj; w.ldb = mp; w.C = p->wmat; w.ldc = mp;
     w.M = mp; w.N = mp; w.K = mp; w.tri = TRI_KLO_BM;
     gemm_splitk(p, OP_NN, w, wks);
     if (p->has_ms()) {
@@ -675,6 +676,7 @@ void do_finish(gprhip_problem* p, const double* ar2, gprhip_result* res, double*
   GPR_HIP(hipStreamSynchronize(s));
   p->stage = 0;
   p->have_model = true;
+  p->have_factors = true;
   if (p->timer.on) tcollect(p);
   if (hinfo[0] != 0 || hinfo[1] != 0) {
     char buf[160];
@@ -788,6 +790,10 @@ void do_predict(gprhip_problem* p, const double* test_inputs, int64_t ld, int64_
     set_error("gprhip_predict: no completed evaluation to predict from");
     throw HipFail{ST_STATE};
   }
+  if (variances && !p->have_factors) {
+    set_error("gprhip_predict: the loaded predictor has no co-variance coefficients (chol_km, r_mat)");
+    throw HipFail{ST_STATE};
+  }
   GPR_HIP(hipSetDevice(p->device));
   hipStream_t s = p->stream;
   const int mp = p->mp;
@@ -857,6 +863,13 @@ struct DevBuf {
   }
 };
 
+void need_factors(gprhip_problem* p, const char* who) {
+  if (!p->have_factors) {
+    set_error(std::string(who) + ": the loaded predictor has no co-variance coefficients (chol_km, r_mat)");
+    throw HipFail{ST_STATE};
+  }
+}
+
 void need_model(gprhip_problem* p, const char* who) {
   if (!p->have_model || p->stage != 0) {
     set_error(std::string(who) + ": no completed evaluation to work from");
@@ -912,6 +925,7 @@ void do_train_stats(gprhip_problem* p, double* means, double* sums) {
 void do_covariances(gprhip_problem* p, const double* test_inputs, int64_t ld, int64_t nt, int kind,
                     int predictive, double* cov) {
   need_model(p, "gprhip_covariances");
+  need_factors(p, "gprhip_covariances");
   GPR_HIP(hipSetDevice(p->device));
   hipStream_t s = p->stream;
   const int mp = p->mp;
@@ -1007,6 +1021,90 @@ void do_cov_samples(gprhip_problem* p, const double* cov, int64_t ld, int64_t nt
               " is not positive definite");
     throw HipFail{ST_NOT_POSDEF};
   }
+}
+
+// Row-major padded upper factor -> Fortran m x m (upper triangle, zeros below) on the host.
+void fetch_upper_fortran(gprhip_problem* p, const double* dev, double* out) {
+  const int mp = p->mp, m = p->m;
+  std::vector<double> h((size_t)mp * mp);
+  GPR_HIP(hipMemcpyAsync(h.data(), dev, h.size() * sizeof(double), hipMemcpyDeviceToHost, p->stream));
+  GPR_HIP(hipStreamSynchronize(p->stream));
+  for (int c = 0; c < m; ++c)
+    for (int r = 0; r < m; ++r) out[(size_t)c * m + r] = (r <= c) ? h[(size_t)r * mp + c] : 0.0;
+}
+
+// Fortran m x m upper factor on the host -> row-major padded mp x mp on the device (zeros below, identity padding).
+void upload_upper_fortran(gprhip_problem* p, const double* in, double* dev) {
+  const int mp = p->mp, m = p->m;
+  std::vector<double> h((size_t)mp * mp, 0.0);
+  for (int r = 0; r < mp; ++r)
+    for (int c = r; c < mp; ++c)
+      h[(size_t)r * mp + c] = (c < m) ? in[(size_t)c * m + r] : (r == c ? 1.0 : 0.0);
+  GPR_HIP(hipMemcpyAsync(dev, h.data(), h.size() * sizeof(double), hipMemcpyHostToDevice, p->stream));
+  GPR_HIP(hipStreamSynchronize(p->stream));  // h goes out of scope
+}
+
+// Model.calc_co_variance_coeffs (lib/fitc_gp.ml:240): (chol_km, r_mat) = (U, R~ U) of the last evaluation.
+void do_co_variance_coeffs(gprhip_problem* p, double* chol_km, double* r_mat) {
+  need_model(p, "gprhip_co_variance_coeffs");
+  need_factors(p, "gprhip_co_variance_coeffs");
+  GPR_HIP(hipSetDevice(p->device));
+  const int mp = p->mp;
+  if (chol_km) fetch_upper_fortran(p, p->umat, chol_km);
+  if (r_mat) {
+    GemmArgs g;  // R = R~ U, both upper triangular
+    g.A = p->bmat; g.lda = mp; g.B = p->umat; g.ldb = mp; g.C = p->wmat; g.ldc = mp;
+    g.M = mp; g.N = mp; g.K = mp; g.tri = TRI_BAND; g.upper_only = 1;
+    launch_gemm(OP_NN, g, p->stream);
+    fetch_upper_fortran(p, p->wmat, r_mat);
+  }
+}
+
+// inv of an upper factor that is already on the device: per-block inverses, then the recursive-doubling joins
+void trtri_of_factor(gprhip_problem* p, double* U, double* X) {
+  for (int j = 0; j < p->mp / TILE; ++j)
+    launch_potrf_diag_flags(U, p->mp, j, p->dinv + (int64_t)j * TILE * TILE, p->info, 1, p->stream);
+  trtri_upper(p, U, X, p->wmat);
+}
+
+// Mean_predictor.calc + Co_variance_predictor.calc (lib/fitc_gp.ml:386-391, :446-447): install the predictor
+// state of a saved model -- kernel, inducing points, mean coefficients, (chol_km, r_mat) -- without an evaluation.
+void do_load_predictor(gprhip_problem* p, const gprhip_hypers* h, const double* coeffs, const double* chol_km,
+                       const double* r_mat) {
+  GPR_HIP(hipSetDevice(p->device));
+  hipStream_t s = p->stream;
+  const int mp = p->mp, m = p->m;
+  const int64_t mm = (int64_t)mp * mp;
+  upload_hypers(p, h);
+  std::vector<double> t(mp, 0.0);
+  if (coeffs) std::memcpy(t.data(), coeffs, (size_t)m * sizeof(double));
+  GPR_HIP(hipMemcpyAsync(p->tvec, t.data(), (size_t)mp * sizeof(double), hipMemcpyHostToDevice, s));
+  GPR_HIP(hipMemsetAsync(p->info, 0, 2 * sizeof(int), s));
+  p->have_factors = chol_km != nullptr;
+  if (chol_km) {
+    upload_upper_fortran(p, chol_km, p->umat);
+    trtri_of_factor(p, p->umat, p->uinv);
+    upload_upper_fortran(p, r_mat, p->binv);       // R, scratch
+    trtri_of_factor(p, p->binv, p->wtil);          // R^-1
+    GemmArgs g;  // R~^-1 = U R^-1  (R = R~ U)
+    g.A = p->umat; g.lda = mp; g.B = p->wtil; g.ldb = mp; g.C = p->rinv; g.ldc = mp;
+    g.M = mp; g.N = mp; g.K = mp; g.tri = TRI_BAND; g.upper_only = 1;
+    GPR_HIP(hipMemsetAsync(p->rinv, 0, (size_t)mm * sizeof(double), s));
+    launch_gemm(OP_NN, g, s);
+    GemmArgs b;  // R~ = R U^-1, kept for a later export
+    b.A = p->binv; b.lda = mp; b.B = p->uinv; b.ldb = mp; b.C = p->bmat; b.ldc = mp;
+    b.M = mp; b.N = mp; b.K = mp; b.tri = TRI_BAND; b.upper_only = 1;
+    GPR_HIP(hipMemsetAsync(p->bmat, 0, (size_t)mm * sizeof(double), s));
+    launch_gemm(OP_NN, b, s);
+    if (p->f32) {
+      launch_to_float(p->uinv, p->uinv_f, mm, s);
+      launch_to_float(p->rinv, p->rinv_f, mm, s);
+    }
+  }
+  GPR_HIP(hipStreamSynchronize(s));
+  p->stage = 0;
+  p->have_model = true;
+  p->h.model_only = coeffs ? 0 : 1;
 }
 
 template <typename F>
@@ -1305,6 +1403,27 @@ int gprhip_cov_samples(gprhip_problem* p, const double* cov, int64_t ld, int64_t
       throw HipFail{ST_BAD_ARG};
     }
     do_cov_samples(p, cov, ld, nt, add_diag, jitter, means, z, ns, samples);
+  });
+}
+
+int gprhip_co_variance_coeffs(gprhip_problem* p, double* chol_km, double* r_mat) {
+  return guarded([&] {
+    if (!p) {
+      set_error("gprhip_co_variance_coeffs: invalid arguments");
+      throw HipFail{ST_BAD_ARG};
+    }
+    do_co_variance_coeffs(p, chol_km, r_mat);
+  });
+}
+
+int gprhip_load_predictor(gprhip_problem* p, const gprhip_hypers* h, const double* coeffs, const double* chol_km,
+                          const double* r_mat) {
+  return guarded([&] {
+    if (!p || !h || (chol_km == nullptr) != (r_mat == nullptr) || (!coeffs && !chol_km)) {
+      set_error("gprhip_load_predictor: invalid arguments");
+      throw HipFail{ST_BAD_ARG};
+    }
+    do_load_predictor(p, h, coeffs, chol_km, r_mat);
   });
 }
 

@@ -43,6 +43,8 @@ void launch_project(const double* X, int64_t n, int D, int d, const double* tpro
 // zero its strict lower part, and write inv(U_jj) (upper, lower zero) to dinv (128x128 row-major).
 // On a non-positive pivot, *info (if still 0) is set to the 1-based global index.
 void launch_potrf_diag(double* A, int mp, int j, double* dinv, int* info, hipStream_t s);
+// flags bit0: the block already holds an upper factor -- skip the factorisation, only write inv(U_jj) to dinv
+void launch_potrf_diag_flags(double* A, int mp, int j, double* dinv, int* info, int flags, hipStream_t s);
 void launch_zero_strict_lower(double* A, int mp, hipStream_t s);
 void launch_copy_block(const double* src, int64_t lds, double* dst, int64_t ldd, int rows, int cols,
                        hipStream_t s);

@@ -25,6 +25,7 @@ enum GemmTri : int {
   TRI_KLO_BN = 2,   // k >= start of the block's column tile (NT, B upper triangular)
   TRI_KLO_BM = 3,   // k >= start of the block's row tile    (NN, A upper triangular)
   TRI_KLO_MAX = 4,  // k >= max(row tile, column tile) start (NT, A and B upper triangular)
+  TRI_BAND = 6,     // row tile start <= k < column tile end      (NN, A and B upper triangular)
   TRI_KHI_MIN = 5,  // k <  min(row tile, column tile) end   (TN, A and B upper triangular)
 };
 

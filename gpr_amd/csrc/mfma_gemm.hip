@@ -167,6 +167,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgsT<T> g) {
     case TRI_KLO_BM: k_lo = max(k_lo, bm * TILE); break;
     case TRI_KLO_MAX: k_lo = max(k_lo, max(bm, bn) * TILE); break;
     case TRI_KHI_MIN: k_hi = min(k_hi, (min(bm, bn) + 1) * TILE); break;
+    case TRI_BAND: k_lo = max(k_lo, bm * TILE); k_hi = min(k_hi, (bn + 1) * TILE); break;
     default: break;
   }
   const int nk = (k_hi - k_lo) / BK;

@@ -128,6 +128,37 @@ def _run(model, targets, want_grad, owner):
     return ev
 
 
+class _Standalone:
+    """Mean_predictor.t / Co_variance_predictor.t built from stored numbers (lib/fitc_gp.ml:377-391, :429-447)
+    rather than from a model on the device: the `test` flow of bin/ocaml_gpr.ml:373-413.  The device problem that
+    serves it is created on first use, sized for the batch of points it is asked about."""
+
+    def __init__(self, spec, functor, inducing_points, coeffs=None, kernel=None, cov_coeffs=None):
+        self.spec, self.functor = spec, functor
+        self.inducing_points = inducing_points
+        self.coeffs, self.kernel, self.cov_coeffs = coeffs, kernel, cov_coeffs
+        self._prob = None
+        self._loaded_for = None
+
+    def problem_for(self, kernel, points, sigma2):
+        D, nt = points.shape
+        d, m = self.inducing_points.shape
+        if self._prob is None or self._prob.D != D or self._prob.n < nt:
+            if self._prob is not None:
+                self._prob.close()
+            self._prob = Problem(self.spec.COV_KIND, max(nt, 1024), D, d, m, precision=self.functor.precision)
+            self.functor._standalone.append(self._prob)
+            self._loaded_for = None
+        key = (id(kernel), float(sigma2))
+        if self._loaded_for != key:
+            self._prob.load_predictor(sigma2=sigma2, inducing=self.inducing_points, coeffs=self.coeffs,
+                                      co_variance_coeffs=self.cov_coeffs, jitter=self.functor.jitter,
+                                      **self.spec.eval_args(kernel))
+            self._loaded_for = key
+            self._kernel_ref = kernel
+        return self._prob
+
+
 _default_rng = np.random.default_rng()
 
 
@@ -194,23 +225,51 @@ def _make_variant(spec, variational, functor, cov_kind="FITC"):
 
     # ---- prediction (lib/fitc_gp.ml:377-531): means and variances at new inputs, on the device that
     # holds the trained model's state
-    def _predict(model_or_trained, inputs, predictive, want_variances):
-        owner = model_or_trained
+    def _problem_of(owner, inputs, sigma2=0.0):
+        """The device problem holding `owner`'s state, after the reference's phys_equal check on inducing points
+        (lib/fitc_gp.ml:419-424, :499-506, :537-546)."""
+        if isinstance(owner, _Standalone):
+            if inputs.inducing.points is not owner.inducing_points:
+                raise ValueError("Means.calc: trained and inputs disagree about inducing points")
+            kernel = owner.kernel if owner.kernel is not None else inputs.inducing.kernel
+            return owner.problem_for(kernel, np.asarray(inputs.points), sigma2)
         if inputs.inducing.points is not _model_of(owner).inputs.inducing.points:
-            # phys_equal check of the reference, lib/fitc_gp.ml:419-424, :499-506
             raise ValueError("Means.calc: trained and inputs disagree about inducing points")
         owner.ensure_state()
-        return _model_of(owner).inputs.problem.predict(inputs.points, predictive=predictive,
-                                                       want_variances=want_variances)
+        return _model_of(owner).inputs.problem
+
+    def _predict(model_or_trained, inputs, predictive, want_variances, sigma2=0.0):
+        return _problem_of(model_or_trained, inputs, sigma2).predict(inputs.points, predictive=predictive,
+                                                                     want_variances=want_variances)
 
     def _model_of(obj):
         return obj.model if isinstance(obj, _Trained) else obj
 
-    Eval.Mean_predictor = SimpleNamespace(calc_trained=lambda trained: trained)            # :380-384
+    def mean_predictor_calc(inducing_points, coeffs):
+        if inducing_points.shape[1] != np.asarray(coeffs).shape[0]:                        # :387-390
+            raise ValueError("Mean_predictor.calc: number of inducing points disagrees with dimension of "
+                             "coefficients")
+        return _Standalone(spec, functor, inducing_points, coeffs=np.asarray(coeffs, dtype=np.float64))
+
+    Eval.Mean_predictor = SimpleNamespace(
+        calc_trained=lambda trained: trained,                                              # :380-384
+        calc=mean_predictor_calc,                                                          # :386-391
+        get_inducing=lambda mp: mp.inducing_points if isinstance(mp, _Standalone)
+        else mp.model.inputs.inducing.points,
+        get_coeffs=lambda mp: mp.coeffs if isinstance(mp, _Standalone) else mp.evaluation().coeffs)
     Eval.Means = SimpleNamespace(
         calc=lambda mean_predictor, inputs: _predict(mean_predictor, inputs, False, False)[0],  # :418-425
         get=lambda means: means)
-    Eval.Co_variance_predictor = SimpleNamespace(calc_model=lambda model: model)             # :438-444
+    Eval.Co_variance_predictor = SimpleNamespace(
+        calc_model=lambda model: model,                                                    # :438-444
+        calc=lambda kernel, inducing_points, co_variance_coeffs:                           # :446-447
+        _Standalone(spec, functor, inducing_points, kernel=kernel, cov_coeffs=co_variance_coeffs))
+
+    def calc_co_variance_coeffs(model):                                                    # :240
+        model.ensure_state()
+        return model.inputs.problem.co_variance_coeffs()
+
+    Eval.Model.calc_co_variance_coeffs = calc_co_variance_coeffs
 
     class _Variances:
         def __init__(self, variances, sigma2):
@@ -218,7 +277,7 @@ def _make_variant(spec, variational, functor, cov_kind="FITC"):
 
     def variances_calc(cvp, sigma2, inputs):
         # the state (chol_km, r_mat) comes from an evaluation of `cvp` (a model or a trained model)
-        return _Variances(_predict(cvp, inputs, False, True)[1], sigma2)
+        return _Variances(_predict(cvp, inputs, False, True, sigma2)[1], sigma2)
 
     Eval.Variances = SimpleNamespace(
         calc=variances_calc,                                                                   # :498-518
@@ -244,7 +303,8 @@ def _make_variant(spec, variational, functor, cov_kind="FITC"):
         calc=lambda mean_predictor, inp: _Mean(inp.point, float(_predict(mean_predictor, inp, False, False)[0][0])),
         get=lambda mean: mean.value)
     Eval.Variance = SimpleNamespace(
-        calc=lambda cvp, sigma2, inp: _Variance(inp.point, float(_predict(cvp, inp, False, True)[1][0]), sigma2),
+        calc=lambda cvp, sigma2, inp: _Variance(inp.point, float(_predict(cvp, inp, False, True, sigma2)[1][0]),
+                                                sigma2),
         get=lambda v, predictive=True: v.variance + v.sigma2 if predictive else v.variance)
 
     # ---- Stats (lib/fitc_gp.ml:304-374): residual sums on the device, the derived figures here
@@ -278,12 +338,11 @@ def _make_variant(spec, variational, functor, cov_kind="FITC"):
             self.points, self.covariances, self.sigma2, self._problem = points, covariances, sigma2, problem
 
     def covariances_calc(cvp, sigma2, inputs):
-        owner = cvp
-        if inputs.inducing.points is not _model_of(owner).inputs.inducing.points:
+        try:
+            prob = _problem_of(cvp, inputs, sigma2)
+        except ValueError:
             raise ValueError("%s_covariances.calc: co-variance predictor and inputs disagree about "
-                             "inducing points" % cov_kind)                      # :537-546
-        owner.ensure_state()
-        prob = _model_of(owner).inputs.problem
+                             "inducing points" % cov_kind) from None                # :537-546
         return _Covariances(inputs.points, prob.covariances(inputs.points, kind=cov_kind), sigma2, prob)
 
     def covariances_get(c, predictive=True):
@@ -412,12 +471,14 @@ class Make_deriv:
         self.jitter = jitter  # read once at functor application, like lib/fitc_gp.ml:33
         self.precision = precision  # gpr_amd.F64 (reference parity) or gpr_amd.F32_BULK
         self._problems = {}
+        self._standalone = []
         self.FITC = _make_variant(spec, False, self)
         self.Variational_FITC = _make_variant(spec, True, self)
         self.FIC = _make_variant(spec, False, self, "FIC")
         self.Variational_FIC = _make_variant(spec, True, self, "FIC")
 
     def close(self):
-        for p in self._problems.values():
+        for p in list(self._problems.values()) + self._standalone:
             p.close()
         self._problems.clear()
+        self._standalone.clear()

@@ -10,6 +10,8 @@ from __future__ import annotations
 
 import numpy as np
 
+from ._lib import NotPositiveDefinite
+
 
 def train(functor_variant, spec, kernel, inducing, inputs, targets, sigma2=None, learn_sigma2=True,
           hypers=None, max_iter=100, tol=1e-6, report=None):
@@ -37,15 +39,27 @@ def train(functor_variant, spec, kernel, inducing, inputs, targets, sigma2=None,
         return k, z, s2
 
     def fdf(x):  # multim_fdf, lib/fitc_gp.ml:1641-1647
-        k, z, s2 = unpack(x)
-        ind = F.Deriv.Inducing.calc(k, z)
-        model = F.Deriv.Model.calc(F.Deriv.Inputs.calc(ind, inputs), sigma2=s2)
-        trained = F.Deriv.Trained.calc(model, targets=targets)
-        le = F.Eval.Trained.calc_log_evidence(trained)
-        g = F.Deriv.Optim.calc_gradient(learn_sigma2, s2, hypers, trained)
         state["n"] += 1
-        if not np.isfinite(le):  # lib/fitc_gp.ml:1523-1528
-            raise FloatingPointError("Optim: log evidence is not finite")
+        try:
+            k, z, s2 = unpack(x)
+            ind = F.Deriv.Inducing.calc(k, z)
+            model = F.Deriv.Model.calc(F.Deriv.Inputs.calc(ind, inputs), sigma2=s2)
+            trained = F.Deriv.Trained.calc(model, targets=targets)
+            le = F.Eval.Trained.calc_log_evidence(trained)
+            g = F.Deriv.Optim.calc_gradient(learn_sigma2, s2, hypers, trained)
+            ok = np.isfinite(le) and np.all(np.isfinite(g))
+        except (NotPositiveDefinite, OverflowError):
+            ok = False
+        if not ok:
+            # The reference aborts the whole optimisation here (check_exception, lib/fitc_gp.ml:1523-1528: NaN
+            # evidence raises Optim_exception).  A line search that overshoots into a region where K_m or B is
+            # numerically singular is routine, so this driver rejects the trial point instead: an objective worse
+            # than anything seen, with a zero gradient, makes the line search back off.
+            if state["best"] is None:
+                raise FloatingPointError("Optim: log evidence is not finite at the starting point")
+            state["rejected"] = state.get("rejected", 0) + 1
+            return state["worst"] + 1e3 * (1.0 + abs(state["worst"])), np.zeros_like(x)
+        state["worst"] = max(state.get("worst", -le), -le)
         if state["best"] is None or le > state["best"][0]:
             state["best"] = (le, k, z, s2)
             if report is not None:

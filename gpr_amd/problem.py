@@ -181,6 +181,38 @@ class Problem:
                                                 _f64_ptr(means), _f64_ptr(z), ns, _f64_ptr(out)))
         return out
 
+    # ---- model export / import (bin/ocaml_gpr.ml:207-232, :373-413)
+    def co_variance_coeffs(self):
+        """Model.calc_co_variance_coeffs (lib/fitc_gp.ml:240): (chol_km, r_mat) of the last evaluation, each an
+        m x m upper-triangular Fortran matrix."""
+        u = np.empty((self.m, self.m), dtype=np.float64, order="F")
+        r = np.empty((self.m, self.m), dtype=np.float64, order="F")
+        _lib.check(self._lib.gprhip_co_variance_coeffs(self._h, _f64_ptr(u), _f64_ptr(r)))
+        return u, r
+
+    def load_predictor(self, *, log_sf2, sigma2, inducing, coeffs=None, co_variance_coeffs=None, log_ell=0.0,
+                       tproj=None, jitter=CHOLESKY_JITTER, log_hetero_skedasticity=None,
+                       log_multiscales_m05=None):
+        """Mean_predictor.calc / Co_variance_predictor.calc (lib/fitc_gp.ml:386-391, :446-447): install a saved
+        model's predictor state; `predict` / `covariances` then work without any evaluation."""
+        h, keep = self._hypers(log_ell, log_sf2, sigma2, inducing, tproj, False, False, jitter,
+                               log_hetero_skedasticity, log_multiscales_m05)
+        c = u = r = None
+        if coeffs is not None:
+            c = np.ascontiguousarray(coeffs, dtype=np.float64)
+            if c.shape != (self.m,):  # lib/fitc_gp.ml:387-390
+                raise ValueError("Mean_predictor.calc: number of inducing points disagrees with dimension of "
+                                 "coefficients")
+        if co_variance_coeffs is not None:
+            u = np.asfortranarray(co_variance_coeffs[0], dtype=np.float64)
+            r = np.asfortranarray(co_variance_coeffs[1], dtype=np.float64)
+            if u.shape != (self.m, self.m) or r.shape != (self.m, self.m):
+                raise ValueError("Co_variance_predictor.calc: expected two %d x %d factors" % (self.m, self.m))
+        _lib.check(self._lib.gprhip_load_predictor(self._h, C.byref(h), _f64_ptr(c) if c is not None else None,
+                                                   _f64_ptr(u) if u is not None else None,
+                                                   _f64_ptr(r) if r is not None else None))
+        del keep
+
     # ---- staged evaluation (row-sharded across devices; see gpr_amd/dist.py)
     def ar1_len(self):
         return int(self._lib.gprhip_ar1_len(self._h))

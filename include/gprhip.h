@@ -181,6 +181,22 @@ int gprhip_covariances(gprhip_problem* p, const double* test_inputs, int64_t ld,
 int gprhip_cov_samples(gprhip_problem* p, const double* cov, int64_t ld, int64_t nt, double add_diag,
                        double jitter, const double* means, const double* z, int64_t ns, double* samples);
 
+/* Model.calc_co_variance_coeffs (lib/fitc_gp.ml:240): the pair (chol_km, r_mat) of the last evaluation, each a
+ * Fortran m x m upper-triangular factor (zeros below the diagonal), host; either may be NULL.  Together with the
+ * kernel parameters, the inducing points and the mean coefficients this is what bin/ocaml_gpr.ml:207-232 stores
+ * in its model file. */
+int gprhip_co_variance_coeffs(gprhip_problem* p, double* chol_km, double* r_mat);
+
+/* Install the predictor state of a saved model without evaluating anything -- Mean_predictor.calc
+ * (lib/fitc_gp.ml:386-391) + Inducing.calc + Co_variance_predictor.calc (:446-447), the `test` flow of
+ * bin/ocaml_gpr.ml:373-413.  h: kernel parameters, inducing points, sigma2 (as for gprhip_eval); coeffs: m mean
+ * coefficients (NULL: variances/covariances only); chol_km, r_mat: as returned by gprhip_co_variance_coeffs
+ * (both NULL: means only -- variance/covariance calls then return GPRHIP_ESTATE).
+ * Afterwards gprhip_predict / gprhip_covariances work on `p`; training inputs need not have been set
+ * (create the problem with n = the largest test batch you intend to pass). */
+int gprhip_load_predictor(gprhip_problem* p, const gprhip_hypers* h, const double* coeffs, const double* chol_km,
+                          const double* r_mat);
+
 /* Intermediates of the last evaluation, for parity tests (copied to host; sizes in doubles):
  *   "r" n, "is" n, "v" n, "w" n, "t" m.  Returns GPRHIP_EBADARG for an unknown name. */
 int gprhip_debug_fetch(gprhip_problem* p, const char* name, double* out, int64_t len);

@@ -612,3 +612,96 @@ def test_golden_posterior(name):
     assert abs(sums[2] - st["maxad"]) <= 1e-8 * st["maxad"]
     assert abs(sums[3] / n - st["target_variance"]) <= 1e-12 * st["target_variance"]
     p.close()
+
+
+def test_device_resident_inputs_equal_host_inputs():
+    """gprhip_set_inputs_device / gprhip_set_targets_device (inputs already in HBM, point-major [n][D]) give
+    bitwise the same evaluation as the host-pointer entry points (Fortran D x n)."""
+    import torch
+    n, m, d = 5000, 96, 5
+    X, y, Z = synth(3, n, m, d)
+    hyp = dict(log_ell=0.3, log_sf2=-0.1, sigma2=0.3, inducing=Z)
+    a = gpr_amd.Problem(gpr_amd.COV_SE_ISO, n, d, d, m, chunk_rows=2048)
+    a.set_inputs(X)
+    a.set_targets(y)
+    ea = a.eval(**hyp)
+    xd = torch.from_numpy(np.ascontiguousarray(X.T)).to("cuda:0")   # [n][D]
+    yd = torch.from_numpy(y).to("cuda:0")
+    torch.cuda.synchronize()
+    b = gpr_amd.Problem(gpr_amd.COV_SE_ISO, n, d, d, m, chunk_rows=2048)
+    b.set_inputs_device(xd.data_ptr())
+    b.set_targets_device(yd.data_ptr())
+    eb = b.eval(**hyp)
+    assert ea.l == eb.l and ea.dl_dsigma2 == eb.dl_dsigma2
+    assert np.array_equal(ea.grad, eb.grad) and np.array_equal(ea.coeffs, eb.coeffs)
+    a.close()
+    b.close()
+
+
+def test_model_export_import_and_file_flow(tmp_path):
+    """Model.calc_co_variance_coeffs (lib/fitc_gp.ml:240) against the oracle's QR factors, a
+    predictor rebuilt from stored numbers alone (Mean_predictor.calc / Co_variance_predictor.calc, the `test`
+    flow of bin/ocaml_gpr.ml:373-413) against the live model, and the train -> save -> load -> predict flow."""
+    from gpr_amd import model_file
+    g = load_golden("posterior_fat_all")
+    k = oracle_kernel(g)
+    s2 = float(g["sigma2"])
+    ref = O.evaluate(k, g["Z"], g["X"], g["y"], s2, want_grad=False, keep=True)
+    p = _problem_for(g)
+    _eval_golden(p, g, want_grad=True)        # a gradient evaluation must leave R~ intact as well
+    chol_km, r_mat = p.co_variance_coeffs()
+    assert relinf(np.triu(chol_km), np.triu(ref["model"]["inducing"]["chol_km"])) <= 1e-9
+    assert relinf(np.triu(r_mat), np.triu(ref["model"]["r_mat"])) <= 1e-9
+    assert np.all(np.tril(chol_km, -1) == 0.0) and np.all(np.tril(r_mat, -1) == 0.0)
+    means, var = p.predict(g["Xt"], predictive=False)
+    cov = p.covariances(g["Xt"], kind="FIC")
+    coeffs = ref["coeffs"]
+    p.close()
+    # a fresh problem that never sees the training data
+    D, nt = g["Xt"].shape
+    d, m = g["Z"].shape
+    q = gpr_amd.Problem(gpr_amd.COV_SE_FAT, nt, D, d, m)
+    args = dict(log_sf2=float(g["log_sf2"]), sigma2=s2, inducing=g["Z"], tproj=g["tproj"],
+                log_hetero_skedasticity=g["log_hetero"], log_multiscales_m05=g["log_multiscales"])
+    q.load_predictor(coeffs=coeffs, co_variance_coeffs=(chol_km, r_mat), **args)
+    means2, var2 = q.predict(g["Xt"], predictive=False)
+    assert relinf(means2, g["means"]) <= 1e-8 and relinf(means2, means) <= 1e-10
+    assert relinf(var2, g["variances"]) <= 1e-8 and relinf(var2, var) <= 1e-9
+    assert relinf(q.covariances(g["Xt"], kind="FIC"), cov) <= 1e-9
+    u2, r2 = q.co_variance_coeffs()            # what was loaded comes back out
+    assert relinf(u2, chol_km) <= 1e-12 and relinf(r2, r_mat) <= 1e-10
+    q.load_predictor(coeffs=coeffs, **args)    # means only
+    assert relinf(q.predict(g["Xt"], want_variances=False)[0], means) <= 1e-10
+    with pytest.raises(gpr_amd.GprHipError):
+        q.predict(g["Xt"])
+    q.close()
+
+    # file flow on the 1-D recipe of test/gen_data.ml: samples as text, train, save, load, predict
+    gd = load_golden("iso_gen_data")
+    text = "".join("%.17g,%.17g\n" % (x, t) for x, t in zip(gd["X"][0], gd["y"]))
+    inputs, targets = model_file.read_training_samples(text)
+    assert np.array_equal(inputs, gd["X"]) and np.array_equal(targets, gd["y"])
+    # the tool standardises every input dimension to unit *norm* (bin/ocaml_gpr.ml:254-265), so the unit-length
+    # Cov_se_fat kernel needs its learnt projection (-dim-red) to see any structure
+    model = model_file.train(inputs, targets, n_inducing=10, sigma2=1.0, dim_red=1, max_iter=60,
+                             rng=np.random.default_rng(4))
+    assert model.stats.rmse < 0.8 and 0.3 < model.sigma2 < 0.8     # noise sigma 0.7
+    path = tmp_path / "model.npz"
+    model_file.save_model(path, model)
+    loaded = model_file.load_model(path)
+    xt = np.linspace(-4.5, 4.5, 56)[None, :]     # even count: no sample at x = 0
+    mu, sd = model_file.predict(loaded, xt, with_stddev=True)
+    # the same numbers straight from the oracle with the stored hyper-parameters
+    kp = loaded.kernel.params
+    ok = O.SeFatKernel(kp.d, kp.log_sf2, kp.tproj, kp.log_hetero_skedasticity, kp.log_multiscales_m05)
+    xs = model_file.apply_standardization(inputs, loaded.input_means, loaded.input_stddevs)
+    oref = O.evaluate(ok, loaded.inducing_points, xs, targets - loaded.target_mean, loaded.sigma2,
+                      variational=True, want_grad=False, keep=True)
+    xts = model_file.apply_standardization(xt, loaded.input_means, loaded.input_stddevs)
+    mu_ref = O.predict_means(ok, loaded.inducing_points, oref["coeffs"], xts) + loaded.target_mean
+    var_ref = O.predict_variances(ok, loaded.inducing_points, oref["model"], xts, predictive=True)
+    assert relinf(mu, mu_ref) <= 1e-7 and relinf(sd, np.sqrt(var_ref)) <= 1e-7
+    lines = model_file.format_predictions(mu, sd).splitlines()
+    assert len(lines) == 56 and all(len(ln.split(",")) == 2 for ln in lines)
+    truth = np.sin(3 * xt[0]) / xt[0] + np.abs(xt[0] - 3) / (xt[0] ** 2 + 1)
+    assert np.sqrt(np.mean((mu - truth) ** 2)) < 0.35

@@ -144,3 +144,43 @@ def test_world_size_2_sharded_eval_over_gloo():
     # every rank returns the same numbers (replicated m x m work on identical reduced buffers)
     assert results[0][1] == results[1][1]
     assert np.array_equal(results[0][3], results[1][3])
+
+
+def test_model_file_text_standardisation_and_roundtrip(tmp_path):
+    """Host-side data formats of the reference's tool (bin/ocaml_gpr.ml:148-201, :254-265, :203-232): sample
+    text, the standardisation statistics exactly as the reference computes them, the model archive."""
+    from types import SimpleNamespace
+
+    from gpr_amd import cov_se_fat, model_file
+    s = model_file.read_samples("1,2,3\n4,5,6\n\n7,8,10\n")
+    assert s.shape == (3, 3)
+    with pytest.raises(ValueError, match="incompatible dimension"):
+        model_file.read_samples("1,2\n3\n")
+    with pytest.raises(ValueError, match="converting sample"):
+        model_file.read_samples("1,x\n")
+    with pytest.raises(ValueError, match="no data"):
+        model_file.read_samples("\n\n")
+    x, y = model_file.read_training_samples("1,2,3\n4,5,6\n7,8,10\n")
+    assert x.shape == (2, 3) and np.array_equal(y, [3.0, 6.0, 10.0])
+    xs, mean, sd = model_file.standardize_inputs(x)
+    assert np.allclose(mean, [4.0, 5.0]) and np.allclose(sd, np.sqrt(18.0))     # sqrt of the SUM of squares
+    assert np.allclose(model_file.apply_standardization(x, mean, sd), xs)
+    rng = np.random.default_rng(0)
+    params = model_file.default_params(5, 7, amplitude=2.0, dim_red=3, log_het_sked=-5.0, multiscale=True, rng=rng)
+    assert params.d == 3 and params.tproj.shape == (5, 3) and np.max(np.abs(params.tproj)) <= 0.2
+    assert abs(params.log_sf2 - 2 * np.log(2.0)) < 1e-15 and np.all(params.log_hetero_skedasticity == -5.0)
+    assert params.log_multiscales_m05.shape == (3, 7) and not params.log_multiscales_m05.any()
+    u = np.triu(rng.normal(size=(7, 7)))
+    model = SimpleNamespace(sigma2=0.3, target_mean=1.5, input_means=mean, input_stddevs=sd,
+                            kernel=cov_se_fat.Kernel.create(params),
+                            inducing_points=np.asfortranarray(rng.normal(size=(3, 7))),
+                            coeffs=rng.normal(size=7), co_variance_coeffs=(u, 2 * u))
+    path = tmp_path / "m.npz"
+    model_file.save_model(path, model)
+    back = model_file.load_model(path)
+    assert back.sigma2 == 0.3 and back.target_mean == 1.5
+    assert np.array_equal(back.inducing_points, model.inducing_points) and np.array_equal(back.coeffs, model.coeffs)
+    assert np.array_equal(back.kernel.params.tproj, params.tproj)
+    assert np.array_equal(back.co_variance_coeffs[1], 2 * u)
+    assert model_file.format_predictions([1.0, 2.5]) == "1.000000\n2.500000\n"
+    assert model_file.format_predictions([1.0], [0.25]) == "1.000000,0.250000\n"
