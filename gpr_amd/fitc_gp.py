@@ -23,8 +23,9 @@ Beyond the hot path: posterior means and variances at new input
 (`Eval.Covariances`: FITC_covariances in `FITC`/`Variational_FITC`, FIC_covariances in `FIC`/
 `Variational_FIC`, lib/fitc_gp.ml:565-627 -- the only place the two families differ) and the samplers
 (`Eval.Sampler`, `Eval.Cov_sampler`; the standard normal draws come from a numpy Generator instead of
-GSL's ziggurat).  Not provided: `Covariances.calc_model_inputs` (O(n^2) over the training set), the
-GSL/SGD/SMD optimiser drivers (gpr_amd/optim.py is an L-BFGS driver over the same callbacks).
+GSL's ziggurat).  Not provided: `Covariances.calc_model_inputs` (O(n^2) over the training set).  The
+optimiser drivers live in gpr_amd/optim.py: an L-BFGS driver over the reference's multim_f/multim_dcommon callbacks
+(GSL itself is not available) and step-for-step mirrors of Optim.SGD / Optim.SMD.
 """
 from __future__ import annotations
 

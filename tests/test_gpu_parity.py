@@ -705,3 +705,71 @@ def test_model_export_import_and_file_flow(tmp_path):
     assert len(lines) == 56 and all(len(ln.split(",")) == 2 for ln in lines)
     truth = np.sin(3 * xt[0]) / xt[0] + np.abs(xt[0] - 3) / (xt[0] ** 2 + 1)
     assert np.sqrt(np.mean((mu - truth) ** 2)) < 0.35
+
+
+def _oracle_gradient(k, Z, X, y, s2):
+    out = O.evaluate_fast(k, Z, X, y, s2)
+    return out["l"], np.concatenate([[out["dl_dsigma2"] * s2], out["grad"]])
+
+
+def test_sgd_and_smd_drivers_follow_the_oracle_trajectory():
+    """Optim.SGD / Optim.SMD (lib/fitc_gp.ml:1724-2017) mirrored over the device gradient, against the same update
+    rules driven by the oracle's gradient: three SGD steps, two SMD steps (central-difference Hessian-vector
+    product), plus make_test's best-state bookkeeping."""
+    from gpr_amd import optim
+    n, m, d = 600, 12, 2
+    X, y, Z = synth(29, n, m, d)
+    GP = fitc_gp.Make_deriv(cov_se_iso)
+    F = GP.FITC
+    kernel = cov_se_iso.Kernel.create(cov_se_iso.Params(0.2, 0.1))
+
+    def unpack(vals):
+        return O.SeIsoKernel(vals[0], vals[1]), np.asfortranarray(vals[2:].reshape(m, d).T)
+
+    # ---- SGD
+    t = optim.SGD.create(F, cov_se_iso, kernel, Z, X, y, tau=10.0, eta0=1e-4, sigma2=0.3)
+    vals = np.concatenate([[0.2, 0.1], Z.T.ravel()])
+    s2, eta = 0.3, 1e-4
+    _, g = _oracle_gradient(*unpack(vals), X, y, s2)
+    assert relinf(t.gradient, g) <= 1e-7 and abs(t.gradient_norm - np.linalg.norm(g)) <= 1e-7 * np.linalg.norm(g)
+    for step in range(3):
+        t = optim.SGD.step(t)
+        s2 = float(np.exp(np.log(s2) + eta * g[0]))
+        vals = vals + eta * g[1:]
+        eta = 10.0 / (10.0 + step) * eta
+        le, g = _oracle_gradient(*unpack(vals), X, y, s2)
+        assert abs(t.sigma2 - s2) <= 1e-9 * s2 and relinf(t.hyper_vals, vals) <= 1e-9
+        assert abs(t.eta - eta) <= 1e-15 and t.step_no == step + 1
+        assert abs(t.log_evidence() - le) <= 1e-8 * abs(le) and relinf(t.gradient, g) <= 1e-6
+    best = optim.SGD.test(optim.SGD.create(F, cov_se_iso, kernel, Z, X, y, tau=10.0, eta0=1e-4, sigma2=0.3),
+                          epsabs=1e-3, max_iter=3)
+    assert best.log_evidence() >= t.log_evidence() - 1e-9 * abs(t.log_evidence())   # ascent: later is better
+    with pytest.raises(ValueError, match="tau"):
+        optim.SGD.create(F, cov_se_iso, kernel, Z, X, y, tau=0.0)
+
+    # ---- SMD
+    eps, lam, mu = 1e-4, 0.1, 1e-3
+    t = optim.SMD.create(F, cov_se_iso, kernel, Z, X, y, eps=eps, sigma2=0.3, eta0=np.full(3 + m * d, 2e-4))
+    vals = np.concatenate([[0.2, 0.1], Z.T.ravel()])
+    s2 = 0.3
+    eta = np.full(3 + m * d, 2e-4)
+    nu = np.full(3 + m * d, 1e-3)
+    nh = 2 + m * d
+    _, g = _oracle_gradient(*unpack(vals), X, y, s2)
+    for _ in range(2):
+        t = optim.SMD.step(t)
+        gp = _oracle_gradient(*unpack(vals + eps * nu[1:]), X, y, float(np.exp(np.log(s2) + eps * nu[0])))[1]
+        gm = _oracle_gradient(*unpack(vals - eps * nu[1:]), X, y, float(np.exp(np.log(s2) - eps * nu[0])))[1]
+        lhn = lam / (2 * eps) * (gp - gm)
+        new_eta = eta * np.maximum(0.5, 1.0 + mu * g * nu)
+        new_s2 = float(np.exp(np.log(s2) + new_eta[0] * g[0]))
+        new_vals = vals + new_eta[:nh] * g[1:1 + nh]
+        nu = eta * (g + lhn) + lam * nu
+        eta, s2, vals = new_eta, new_s2, new_vals
+        _, g = _oracle_gradient(*unpack(vals), X, y, s2)
+        assert relinf(t.eta, eta) <= 1e-9 and abs(t.sigma2 - s2) <= 1e-9 * s2
+        assert relinf(t.hyper_vals, vals) <= 1e-9 and relinf(t.gradient, g) <= 1e-6
+        assert relinf(t.nu, nu) <= 1e-3      # carries the finite-difference noise of both sides
+    with pytest.raises(ValueError, match="lambda"):
+        optim.SMD.create(F, cov_se_iso, kernel, Z, X, y, lam=1.5)
+    GP.close()
