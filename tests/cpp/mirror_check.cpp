@@ -1,0 +1,166 @@
+// Exercises include/gprhip.hpp (the C++ mirror of Fitc_gp.Make_deriv) on a problem dumped by the Python test:
+//   mirror_check <in.bin>  ->  "key v1 v2 ..." lines on stdout (17 significant digits)
+// Input: 10 int64 [kind n D d m nt has_tproj has_het has_ms variational], then doubles
+//   log_ell log_sf2 sigma2 | X (D*n) | y (n) | Z (d*m) | [tproj D*d] | [het m] | [ms d*m] | Xt (D*nt)
+// all matrices column-major.  The test compares every line with the oracle / golden fixtures.
+#include <cstdio>
+#include <cstdlib>
+#include <fstream>
+#include <iostream>
+
+#include "gprhip.hpp"
+
+using gpr::Hyper;
+using gpr::Mat;
+using gpr::MatP;
+using gpr::Vec;
+
+static void put(const char* key, const Vec& v) {
+  std::printf("%s", key);
+  for (double x : v) std::printf(" %.17g", x);
+  std::printf("\n");
+}
+static void put(const char* key, double x) { put(key, Vec{x}); }
+
+struct Dump {
+  int64_t kind, n, D, d, m, nt, has_tproj, has_het, has_ms, variational;
+  double log_ell, log_sf2, sigma2;
+  std::shared_ptr<Mat> X, Z, Xt;
+  Vec y;
+  std::optional<Mat> tproj, ms;
+  std::optional<Vec> het;
+};
+
+static Mat read_mat(std::ifstream& f, int r, int c) {
+  Mat m(r, c);
+  f.read(reinterpret_cast<char*>(m.data()), sizeof(double) * (size_t)r * c);
+  return m;
+}
+
+template <class Spec, class V>
+static void exercise(const Dump& dm, const typename Spec::Kernel& kernel) {
+  using GP = gpr::Make_deriv<Spec>;
+  MatP Z = dm.Z, X = dm.X, Xt = dm.Xt;
+  auto inducing = V::Inducing::calc(kernel, Z);
+  auto inputs = V::Inputs::calc(inducing, X);
+  auto model = V::Model::calc(inputs, dm.sigma2);
+  auto trained = V::Trained::calc(model, dm.y);
+  put("l1", V::Model::calc_log_evidence(model));
+  put("l", V::Trained::calc_log_evidence(trained));
+  put("dl_dsigma2", V::Trained::calc_log_evidence_sigma2(trained));
+  put("model_dl_dsigma2", V::Model::calc_log_evidence_sigma2(model));
+  const auto hypers = Spec::get_all(kernel, *Z);
+  const auto ht = V::Trained::prepare_hyper(trained);
+  const auto hm = V::Model::prepare_hyper(model);
+  Vec grad, mgrad;
+  for (const Hyper& h : hypers) {
+    grad.push_back(V::Trained::calc_log_evidence(ht, h));
+    mgrad.push_back(V::Model::calc_log_evidence(hm, h));
+  }
+  put("grad", grad);
+  put("model_grad", mgrad);
+  put("coeffs", V::Trained::calc_mean_coeffs(trained));
+  put("optim_gradient", V::Optim::calc_gradient(true, dm.sigma2, hypers, trained));
+  // the model evaluation above replaced the trained state on the device: these must re-establish it
+  const auto st = V::Stats::calc(trained);
+  put("stats", Vec{(double)st.n_samples, st.target_variance, st.sse, st.mse, st.rmse, st.smse, st.msll, st.mad,
+                   st.maxad});
+  put("train_means", V::Trained::calc_means(trained));
+  if (dm.nt > 0) {
+    auto tin = V::Inputs::calc(inducing, Xt, /*train=*/false);
+    put("means", V::Means::calc(trained, tin));
+    auto var = V::Variances::calc(model, dm.sigma2, tin);
+    put("variances", V::Variances::get(var, false));
+    put("variances_predictive", V::Variances::get(var));
+    auto cov = V::Covariances::calc(model, dm.sigma2, tin);
+    put("cov", V::Covariances::get(cov, false).a);
+    // phys_equal check of the reference: inputs bound to a different inducing matrix object are refused
+    auto other = V::Inputs::calc(V::Inducing::calc(kernel, std::make_shared<Mat>(*Z)), Xt, false);
+    try {
+      V::Means::calc(trained, other);
+      put("phys_equal_check", 0.0);
+    } catch (const gpr::Failure&) {
+      put("phys_equal_check", 1.0);
+    }
+  }
+  auto cc = V::Model::calc_co_variance_coeffs(model);
+  put("chol_km", cc.first.a);
+  put("r_mat", cc.second.a);
+  // update_sigma2 keeps K_nm, V, r on the device
+  auto model2 = V::Model::update_sigma2(model, 2.0 * dm.sigma2);
+  put("l_sigma2x2", V::Trained::calc_log_evidence(V::Trained::calc(model2, dm.y)));
+  // self test on sigma2 and the first / last hyper (eps 1e-8, tol 1e-2 as in test/test_derivatives.ml)
+  double ok = 1.0;
+  try {
+    V::Test::self_test(kernel, Z, X, dm.sigma2, dm.y, nullptr);
+    V::Test::self_test(kernel, Z, X, dm.sigma2, dm.y, &hypers.front());
+    V::Test::self_test(kernel, Z, X, dm.sigma2, dm.y, &hypers.back());
+  } catch (const gpr::Failure& e) {
+    std::fprintf(stderr, "self_test: %s\n", e.what());
+    ok = 0.0;
+  }
+  put("self_test", ok);
+  // argument checks keep the reference's messages
+  double neg = 0.0, dim = 0.0;
+  try {
+    V::Model::calc(inputs, -1.0);
+  } catch (const gpr::Failure& e) {
+    neg = std::string(e.what()).find("sigma2 < 0") != std::string::npos;
+  }
+  try {
+    V::Trained::calc(model, Vec(dm.y.begin(), dm.y.end() - 1));
+  } catch (const gpr::Failure& e) {
+    dim = std::string(e.what()).find("Vec.dim targets") != std::string::npos;
+  }
+  put("error_checks", Vec{neg, dim});
+  (void)sizeof(GP);
+}
+
+int main(int argc, char** argv) {
+  if (argc < 2) {
+    std::fprintf(stderr, "usage: mirror_check <dump.bin>\n");
+    return 2;
+  }
+  std::ifstream f(argv[1], std::ios::binary);
+  Dump dm;
+  f.read(reinterpret_cast<char*>(&dm.kind), 10 * sizeof(int64_t));
+  f.read(reinterpret_cast<char*>(&dm.log_ell), 3 * sizeof(double));
+  dm.X = std::make_shared<Mat>(read_mat(f, (int)dm.D, (int)dm.n));
+  dm.y.resize((size_t)dm.n);
+  f.read(reinterpret_cast<char*>(dm.y.data()), sizeof(double) * (size_t)dm.n);
+  dm.Z = std::make_shared<Mat>(read_mat(f, (int)dm.d, (int)dm.m));
+  if (dm.has_tproj) dm.tproj = read_mat(f, (int)dm.D, (int)dm.d);
+  if (dm.has_het) {
+    dm.het = Vec((size_t)dm.m);
+    f.read(reinterpret_cast<char*>(dm.het->data()), sizeof(double) * (size_t)dm.m);
+  }
+  if (dm.has_ms) dm.ms = read_mat(f, (int)dm.d, (int)dm.m);
+  dm.Xt = std::make_shared<Mat>(read_mat(f, (int)dm.D, (int)dm.nt));
+  if (!f) {
+    std::fprintf(stderr, "mirror_check: short input file\n");
+    return 2;
+  }
+  try {
+    if (dm.kind == GPRHIP_COV_SE_ISO) {
+      using S = gpr::Cov_se_iso;
+      auto k = S::Kernel::create({dm.log_ell, dm.log_sf2});
+      if (dm.variational) exercise<S, gpr::Make_deriv<S>::Variational_FITC>(dm, k);
+      else exercise<S, gpr::Make_deriv<S>::FITC>(dm, k);
+    } else {
+      using S = gpr::Cov_se_fat;
+      S::Params p;
+      p.d = (int)dm.d;
+      p.log_sf2 = dm.log_sf2;
+      p.tproj = dm.tproj;
+      p.log_hetero_skedasticity = dm.het;
+      p.log_multiscales_m05 = dm.ms;
+      auto k = S::Kernel::create(S::Params::create(p));
+      if (dm.variational) exercise<S, gpr::Make_deriv<S>::Variational_FIC>(dm, k);
+      else exercise<S, gpr::Make_deriv<S>::FIC>(dm, k);
+    }
+  } catch (const gpr::Failure& e) {
+    std::fprintf(stderr, "mirror_check: %s (status %d)\n", e.what(), e.status);
+    return 1;
+  }
+  return 0;
+}

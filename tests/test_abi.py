@@ -51,3 +51,14 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".hip", ".cpp", ".h")):
                 src = open(os.path.join(dirpath, f)).read()
                 assert not pat.search(src), "%s references the oracle" % os.path.join(dirpath, f)
+
+
+def test_cpp_mirror_program_is_built_and_links():
+    """include/gprhip.hpp (C++ mirror of Fitc_gp.Make_deriv) compiles against the C ABI: the Makefile builds
+    tests/cpp/mirror_check.cpp with g++; without arguments it only prints its usage (no device call)."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "gpr_amd", "_build", "mirror_check")
+    assert os.path.exists(exe), "run `make -C gpr_amd/csrc` (or __graft_entry__.build())"
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=60)
+    assert out.returncode == 2 and "usage" in out.stderr

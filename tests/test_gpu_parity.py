@@ -773,3 +773,75 @@ def test_sgd_and_smd_drivers_follow_the_oracle_trajectory():
     with pytest.raises(ValueError, match="lambda"):
         optim.SMD.create(F, cov_se_iso, kernel, Z, X, y, lam=1.5)
     GP.close()
+
+
+def _run_mirror_check(tmp_path, g, Xt, variational):
+    """Dump a fixture for tests/cpp/mirror_check.cpp (built by gpr_amd/csrc/Makefile), run it, parse its lines."""
+    import struct
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "gpr_amd", "_build", "mirror_check")
+    assert os.path.exists(exe), "mirror_check not built (make -C gpr_amd/csrc)"
+    X, Z = np.asfortranarray(g["X"]), np.asfortranarray(g["Z"])
+    D, n = X.shape
+    d, m = Z.shape
+    iso = g["kind"] == "iso"
+    path = tmp_path / "dump.bin"
+    with open(path, "wb") as f:
+        f.write(struct.pack("<10q", 0 if iso else 1, n, D, d, m, Xt.shape[1], int("tproj" in g), int("log_hetero" in g),
+                            int("log_multiscales" in g), int(variational)))
+        f.write(struct.pack("<3d", float(g["log_ell"]) if iso else 0.0, float(g["log_sf2"]), float(g["sigma2"])))
+        arrays = [X, g["y"], Z]
+        arrays += [g[key] for key in ("tproj", "log_hetero", "log_multiscales") if key in g]
+        arrays.append(Xt)
+        for a in arrays:
+            f.write(np.asfortranarray(a, dtype=np.float64).tobytes(order="F"))
+    out = subprocess.run([exe, str(path)], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    res = {}
+    for line in out.stdout.splitlines():
+        key, *vals = line.split()
+        res[key] = np.array([float(v) for v in vals])
+    return res
+
+
+@pytest.mark.parametrize("name", ["iso_c1_var", "posterior_fat_all"])
+def test_cpp_host_mirror(tmp_path, name):
+    """include/gprhip.hpp -- the C++ mirror of Fitc_gp.Make_deriv(Spec).{FITC, Variational_FITC, FIC,
+    Variational_FIC} over the C ABI -- driven by a compiled program and compared with the oracle: evidence,
+    per-hyper derivative lookups in Hyper.get_all order, model-only derivatives, Optim.calc_gradient, Stats,
+    prediction, covariances, co-variance coefficients, update_sigma2, the self-test recipe and error messages."""
+    g = load_golden(name)
+    variational = bool(g.get("variational", False))
+    k = oracle_kernel(g)
+    s2 = float(g["sigma2"])
+    Xt = g["Xt"] if "Xt" in g else np.asfortranarray(np.random.default_rng(1).normal(size=(g["X"].shape[0], 40)))
+    res = _run_mirror_check(tmp_path, g, Xt, variational)
+    ref = O.evaluate(k, g["Z"], g["X"], g["y"], s2, variational=variational, keep=True)
+    assert abs(res["l1"][0] - ref["l1"]) <= TOL_L * abs(ref["l1"])
+    assert abs(res["l"][0] - ref["l"]) <= TOL_L * abs(ref["l"])
+    assert abs(res["dl_dsigma2"][0] - ref["dl_dsigma2"]) <= TOL_DS2 * abs(ref["dl_dsigma2"])
+    assert abs(res["model_dl_dsigma2"][0] - ref["model_dl_dsigma2"]) <= TOL_DS2 * abs(ref["model_dl_dsigma2"])
+    assert res["grad"].shape == ref["grad"].shape and relinf(res["grad"], ref["grad"]) <= TOL_GRAD
+    assert relinf(res["model_grad"], ref["model_grad"]) <= TOL_GRAD
+    assert relinf(res["coeffs"], ref["coeffs"]) <= TOL_COEFF
+    assert relinf(res["optim_gradient"], np.concatenate([[ref["dl_dsigma2"] * s2], ref["grad"]])) <= TOL_GRAD
+    knm, _ = O.spec_calc_shared_cross(k, g["X"], g["Z"])
+    tm = knm @ ref["coeffs"]
+    st = O.stats_calc(g["y"], tm, ref["l"])
+    assert relinf(res["train_means"], tm) <= 1e-8
+    assert relinf(res["stats"], [st[key] for key in STAT_KEYS]) <= 1e-8
+    assert relinf(res["means"], O.predict_means(k, g["Z"], ref["coeffs"], Xt)) <= 1e-8
+    var = O.predict_variances(k, g["Z"], ref["model"], Xt, predictive=False)
+    assert relinf(res["variances"], var) <= 1e-8 and relinf(res["variances_predictive"], var + s2) <= 1e-8
+    nt = Xt.shape[1]
+    cref = (O.fitc_covariances if g["kind"] == "iso" else O.fic_covariances)(k, g["Z"], ref["model"], Xt)
+    cov = res["cov"].reshape(nt, nt)
+    assert np.max(np.abs(np.triu(cov) - cref)) <= 1e-8 * np.max(np.abs(cref))
+    m = g["Z"].shape[1]
+    assert relinf(np.triu(res["chol_km"].reshape(m, m).T), np.triu(ref["model"]["inducing"]["chol_km"])) <= 1e-9
+    assert relinf(np.triu(res["r_mat"].reshape(m, m).T), np.triu(ref["model"]["r_mat"])) <= 1e-9
+    ref2 = O.evaluate(k, g["Z"], g["X"], g["y"], 2 * s2, variational=variational, want_grad=False)
+    assert abs(res["l_sigma2x2"][0] - ref2["l"]) <= TOL_L * abs(ref2["l"])
+    assert res["phys_equal_check"][0] == 1.0 and res["self_test"][0] == 1.0
+    assert np.array_equal(res["error_checks"], [1.0, 1.0])
