@@ -18,10 +18,10 @@ constexpr int POTRF_LDS = (NB * LDT + NB * MB + NB) * 8 + 16;
 // Both phases advance by 16-column micro-panels so that the sequential part runs inside one
 // wavefront on registers (cross-lane broadcasts, no workgroup barrier):
 //   factor : 16x16 diagonal block (wave 0, registers) -> 16 x rest panel solve (thread per column,
-//            reciprocal pivots) -> rank-16 update of the trailing block (all threads)
+//            reciprocal pivots) -> rank-16 update of the trailing block as 16x16 MFMA tiles (all wavefronts)
 //   invert : the eight 16x16 diagonal inverses first, all at once (kept in the unused strictly-lower
 //            blocks of T); then per block column  T1 = X[0:j0,0:j0] U[0:j0,j],  X[0:j0,j] = -T1 inv(U_jj)
-//            in place (LAPACK dtrtri order), four outputs per thread.
+//            in place (LAPACK dtrtri order), one 16x16 MFMA tile per wavefront.
 // broadcast lane `l` (compile-time constant after unrolling) through v_readlane, not the LDS crossbar
 __device__ __forceinline__ double bcast_lane(double v, int l) {
   const int lo = __builtin_amdgcn_readlane(__double2loint(v), l);
@@ -67,9 +67,6 @@ __global__ __launch_bounds__(PT) void potrf_diag_kernel(double* __restrict__ A, 
   }
 
   // ---------------- factor
-  const int c = tid & (NB - 1);   // column owned in the panel / trailing phases
-  const int rh = tid >> 7;        // row phase 0..3
-  constexpr int RS = PT / NB;     // row stride
   for (int k0 = 0; k0 < ((flags & 1) ? 0 : NB); k0 += MB) {
     if (wid == 0 && !(flags & 4)) {
       const int cc = lane & 15;   // lanes 16..63 mirror lanes 0..15
