@@ -480,11 +480,10 @@ void do_pass1(gprhip_problem* p, const gprhip_hypers* h, int want_grad, int64_t 
   b.A = Vstore; b.lda = mp; b.B = Vstore; b.ldb = mp; b.C = slices; b.ldc = mp;
   b.M = mp; b.N = mp; b.K = (int)ktot; b.beta = 0.0; b.scale_k = p->is; b.upper_only = 1;
   b.kslices = ks; b.slice_stride = mm;
+  // c~ rides along: the diagonal-tile blocks of every k-slice also sum V[k][c] * (is*y)[k] over their rows
+  b.cs_w = p->yis; b.cs_out = p->gemvpart;
   launch_gemm(OP_TN, b, s);
-  tstop(p);
-  tstart(p, "p1_gemv_c");
-  launch_gemv_t_partial<TS>(Vstore, (int)ktot, mp, p->yis, p->gemvpart, s);
-  launch_reduce_rows(p->gemvpart, (int)((ktot + 255) / 256), mp, ar1_c, 1, s);
+  launch_reduce_rows(p->gemvpart, ks, mp, ar1_c, 1, s);
   tstop(p);
   p->ks_used = ks;
   launch_sum_slices<TS>(nullptr, slices, ks, mm, mp, ar1, s);
@@ -1213,7 +1212,7 @@ int gprhip_problem_create_ex(int device, int cov_kind, int precision, int64_t n,
     p->slices_bytes = (int64_t)p->kslices * mm * p->esz;
     p->slices = p->alloc<char>(p->slices_bytes);
     p->rowpart = p->alloc<double>((int64_t)pass1_row_blocks((int)chunk) * 4);
-    p->gemvpart = p->alloc<double>(((npad + 255) / 256) * mp);
+    p->gemvpart = p->alloc<double>((int64_t)p->kslices * mp);  // c~ partials, one row per k-slice
     const int64_t nslab = (chunk + grad_slab_rows() - 1) / grad_slab_rows();
     p->colpart = p->alloc<double>(nslab * p->col_rows() * mp);
     p->scalpart = p->alloc<double>(nslab * ((mp + 255) / 256) * 2);

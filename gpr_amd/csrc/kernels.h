@@ -122,10 +122,6 @@ void launch_add_row_vector(double* S, int64_t ld, int ns, int n, const double* v
 // out[i] = a - x[i]
 void launch_const_minus(const double* x, int n, double a, double* out, hipStream_t s);
 
-// partial[slab][col] = sum_{rows of slab} K[row][col] * x[row]; slab = 256 rows
-template <typename TS>
-void launch_gemv_t_partial(const TS* K, int rows_p, int mp, const double* x, double* partial,
-                           hipStream_t s);
 // out[col] (+)= sum_slab partial[slab][col]
 void launch_reduce_rows(const double* partial, int nslabs, int width, double* out, int accumulate,
                         hipStream_t s);

@@ -59,6 +59,11 @@ struct GemmArgsT {
   //   rp_sumsq[row*(2*N/128) + 2*bn + wc] = sum of C[row][c]^2 over the 64 columns wave column wc owns in tile bn
   //   rp_dot  [same index]               = sum of C[row][c] * rp_vec[c] over the same columns
   // (diag(Q_nn)-type row quantities without re-reading the n x m result: lib/fitc_gp.ml:222-223, :1048, :1164)
+  // optional weighted column sums of the raw A operand, computed by the diagonal-tile blocks of an upper_only TN
+  // launch while they stream A anyway:  cs_out[slice * N + c] = sum_{k in slice} A[k][c] * cs_w[k]
+  // (c~ = V^T (y ./ s) without a separate pass over V; lib/fitc_gp.ml:285: gemv ~trans:`T q_mat y~)
+  const double* cs_w = nullptr;
+  double* cs_out = nullptr;
   double* rp_sumsq = nullptr;
   double* rp_dot = nullptr;
   const double* rp_vec = nullptr;

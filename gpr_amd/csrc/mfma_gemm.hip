@@ -123,7 +123,9 @@ __device__ __forceinline__ double xor16(double v) {
   else return dpp_mov<0x128>(v);
 }
 
-template <typename T, int OP>
+// CS: the launch carries weighted column sums of the raw A operand (GemmArgsT::cs_w) -- a separate
+// instantiation, so that launches without them keep their inner loop unchanged
+template <typename T, int OP, bool CS = false>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgsT<T> g) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   T* smem = reinterpret_cast<T*>(smem_raw);
@@ -209,6 +211,13 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgsT<T> g) {
   // the per-k weights of the A operand are fetched with the tile and applied when the tile is
   // written to LDS, so the multiply never waits on a load that was just issued
   T rs[4] = {1, 1, 1, 1};
+  // weighted column sums of raw A (cs_*): only the diagonal tile of each k-slice carries them
+  const bool do_cs = CS && A_KMAJ && bm == bn;
+  const double* cw = do_cs ? g.cs_w + k_lo + km_ku : nullptr;
+  double cwv[4] = {0.0, 0.0, 0.0, 0.0};
+  double csum[EPV];
+#pragma unroll
+  for (int e = 0; e < EPV; ++e) csum[e] = 0.0;
   auto load_global = [&](int t, vec (&ra)[4], vec (&rb)[4]) {
     const T* ap = Ag + (int64_t)t * a_step;
     const T* bp = Bg + (int64_t)t * b_step;
@@ -217,6 +226,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgsT<T> g) {
       if (A_KMAJ) {
         ra[p] = *reinterpret_cast<const vec*>(ap + (int64_t)(KPP * p) * g.lda);
         if (sk) rs[p] = (T)sk[t * BK + KPP * p];
+        if (do_cs) cwv[p] = cw[t * BK + KPP * p];
       } else {
         ra[p] = *reinterpret_cast<const vec*>(ap + (int64_t)(32 * p) * g.lda);
       }
@@ -234,6 +244,10 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgsT<T> g) {
     for (int p = 0; p < 4; ++p) {
       if (A_KMAJ) {
         vec v = ra[p];
+        if (do_cs) {
+#pragma unroll
+          for (int e = 0; e < EPV; ++e) csum[e] += (double)v[e] * cwv[p];
+        }
         if (sk) v *= rs[p];
         *reinterpret_cast<vec*>(As + (km_k + KPP * p) * KS + EPV * km_v) = v;
       } else
@@ -322,6 +336,21 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgsT<T> g) {
         if (more) store_lds((t + 1) & 1, ra, rb);
         __syncthreads();
       }
+    }
+  }
+
+  if (do_cs) {
+    // threads with the same km_v hold partial sums of the same EPV columns for different k-rows: combine the
+    // 256 / VPR groups through LDS (free after the main loop's final barrier)
+    double* red = reinterpret_cast<double*>(smem_raw);
+#pragma unroll
+    for (int e = 0; e < EPV; ++e) red[km_k * TILE + EPV * km_v + e] = csum[e];
+    __syncthreads();
+    if (tid < TILE) {
+      double s = 0.0;
+#pragma unroll
+      for (int q = 0; q < 256 / VPR; ++q) s += red[q * TILE + tid];
+      g.cs_out[(int64_t)slice * g.N + bm * TILE + tid] = s;
     }
   }
 
@@ -438,7 +467,9 @@ void gemm_init() {
                       reinterpret_cast<const void*>(&gemm_kernel<double, OP_TN>),
                       reinterpret_cast<const void*>(&gemm_kernel<float, OP_NN>),
                       reinterpret_cast<const void*>(&gemm_kernel<float, OP_NT>),
-                      reinterpret_cast<const void*>(&gemm_kernel<float, OP_TN>)};
+                      reinterpret_cast<const void*>(&gemm_kernel<float, OP_TN>),
+                      reinterpret_cast<const void*>(&gemm_kernel<double, OP_TN, true>),
+                      reinterpret_cast<const void*>(&gemm_kernel<float, OP_TN, true>)};
   for (const void* k : ks)
     GPR_HIP(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
   done = true;
@@ -453,6 +484,10 @@ static void launch_gemm_t(GemmOp op, const GemmArgsT<T>& g, hipStream_t stream) 
   }
   const int nbm = g.M / TILE, nbn = g.N / TILE;
   int tiles = g.upper_only ? nbn * (nbn + 1) / 2 : nbm * nbn;
+  if (g.cs_w && (op != OP_TN || !g.upper_only || !g.cs_out)) {
+    set_error("gprhip: launch_gemm: column sums ride on upper_only TN launches");
+    throw HipFail{ST_BAD_ARG};
+  }
   if (g.kslices > 1 && (g.beta != 0.0 || g.epi_rows_a || g.rp_sumsq)) {
     set_error("gprhip: launch_gemm: split-K launches write plain partial products (no beta / fused epilogue)");
     throw HipFail{ST_BAD_ARG};
@@ -462,7 +497,10 @@ static void launch_gemm_t(GemmOp op, const GemmArgsT<T>& g, hipStream_t stream) 
   switch (op) {
     case OP_NN: hipLaunchKernelGGL((gemm_kernel<T, OP_NN>), grid, block, LDS_BYTES, stream, g); break;
     case OP_NT: hipLaunchKernelGGL((gemm_kernel<T, OP_NT>), grid, block, LDS_BYTES, stream, g); break;
-    case OP_TN: hipLaunchKernelGGL((gemm_kernel<T, OP_TN>), grid, block, LDS_BYTES, stream, g); break;
+    case OP_TN:
+      if (g.cs_w) hipLaunchKernelGGL((gemm_kernel<T, OP_TN, true>), grid, block, LDS_BYTES, stream, g);
+      else hipLaunchKernelGGL((gemm_kernel<T, OP_TN>), grid, block, LDS_BYTES, stream, g);
+      break;
   }
   GPR_HIP(hipGetLastError());
 }

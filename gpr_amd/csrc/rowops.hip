@@ -235,30 +235,6 @@ void launch_variance_combine(const double* k, const double* b, int rows, double 
   GPR_HIP(hipGetLastError());
 }
 
-// partial[slab][col] = sum_{r in slab} K[r][col] * x[r]
-template <typename TS>
-__global__ __launch_bounds__(256) void gemv_t_partial_kernel(const TS* __restrict__ K, int rows_p,
-                                                             int mp, const double* __restrict__ x,
-                                                             double* __restrict__ partial) {
-  const int col = blockIdx.x * 256 + threadIdx.x;
-  if (col >= mp) return;
-  const int r0 = blockIdx.y * 256;
-  const int r1 = min(rows_p, r0 + 256);
-  double acc = 0.0;
-  for (int r = r0; r < r1; ++r) acc += (double)K[(int64_t)r * mp + col] * x[r];
-  partial[(int64_t)blockIdx.y * mp + col] = acc;
-}
-
-template <typename TS>
-void launch_gemv_t_partial(const TS* K, int rows_p, int mp, const double* x, double* partial,
-                           hipStream_t s) {
-  dim3 grid((mp + 255) / 256, (rows_p + 255) / 256);
-  hipLaunchKernelGGL(gemv_t_partial_kernel<TS>, grid, dim3(256), 0, s, K, rows_p, mp, x, partial);
-  GPR_HIP(hipGetLastError());
-}
-template void launch_gemv_t_partial<double>(const double*, int, int, const double*, double*, hipStream_t);
-template void launch_gemv_t_partial<float>(const float*, int, int, const double*, double*, hipStream_t);
-
 // out[col] (+)= sum_slab partial[slab][col].  A block covers COLS columns with 256/COLS slab lanes
 // per column; each lane strides over the slabs, then the lanes are combined in a fixed order.
 template <int COLS>
