@@ -65,7 +65,7 @@ def measured_traffic():
     best = None
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_bench*.json"))):
         for r in json.load(open(path)):
-            if r["kernel"].startswith("gprhip::gemm_kernel<double, 2>") and (best is None or r["avg_ms"] > best["avg_ms"]):
+            if r["kernel"].startswith("gprhip::gemm_kernel<double, 2") and (best is None or r["avg_ms"] > best["avg_ms"]):
                 best = r
     if best is None:
         return None
@@ -163,7 +163,7 @@ def main():
         flops_per_launch = float(n_local) * m * m
         achieved = flops_per_launch / (syrk_ms / launches * 1e-3) * 1e-12 if syrk_ms > 0 else None
         engine_ms = sum(np.mean(tim.get(k_, [0.0])) for k_ in
-                        ("p1_syrk_B", "p2_syrk_W", "p1_trmm_V", "p1_trmm_A1", "p2_trmm_Q", "p2_trmm_S"))
+                        ("p1_syrk_B", "p2_syrk_W", "p1_trmm_V", "p2_trmm_Q", "p2_trmm_S", "p2_trmm_X"))
         line = {
             "metric": "FITC nLML+grad training-points/sec at n=1M m=2048 d=8",
             "value": value, "unit": "training-points/s", "n_gpus": world, "steps": args.steps,
