@@ -14,6 +14,10 @@ PARITY UNPINNED BY REFERENCE FIXTURES: the reference ships no golden vectors
 (its test/ executables print values, `dune runtest` runs nothing) and no OCaml
 toolchain exists in the build image, so the reference itself cannot be run.
 The oracle is pinned instead by (see tests/test_oracle.py):
+  * Edward Snelson's SPGP routine test/spgp_lik.m -- the third-party code the
+    reference keeps in its test directory and cross-checks itself against in
+    test/oct.m:183-191 -- restated in tests/snelson_spgp.py: evidence and the
+    full gradient (length scale, amplitude, noise, every pseudo-input),
   * the algebraic identity  l1+l2 == dense textbook FITC log-likelihood,
   * central finite differences of that dense likelihood for every hyper,
   * an mpmath 50-digit evaluation at tiny n,

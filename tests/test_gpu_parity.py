@@ -845,3 +845,24 @@ def test_cpp_host_mirror(tmp_path, name):
     assert abs(res["l_sigma2x2"][0] - ref2["l"]) <= TOL_L * abs(ref2["l"])
     assert res["phys_equal_check"][0] == 1.0 and res["self_test"][0] == 1.0
     assert np.array_equal(res["error_checks"], [1.0, 1.0])
+
+
+def test_hip_path_against_snelson_spgp_lik():
+    """The HIP path against Edward Snelson's SPGP routine (test/spgp_lik.m, restated in tests/snelson_spgp.py) at the
+    BASELINE C1 shape -- the external cross-check the reference's own test/oct.m:183-191 performs."""
+    from tests.snelson_spgp import spgp_lik
+    g = load_golden("iso_c1")
+    X, y, Z = g["X"], g["y"], g["Z"]
+    d, m = Z.shape
+    log_ell, log_sf2, s2 = float(g["log_ell"]), float(g["log_sf2"]), float(g["sigma2"])
+    p = _problem_for(g)
+    ev = _eval_golden(p, g)
+    p.close()
+    ew = np.concatenate([Z.T.ravel(order="F"), np.full(d, -2.0 * log_ell), [log_sf2, np.log(s2)]])
+    fw, dfw = spgp_lik(ew, y, np.ascontiguousarray(X.T), m)
+    assert abs(ev.l - (-fw)) <= 1e-9 * abs(fw)
+    scale = np.max(np.abs(ev.grad))
+    assert abs(ev.grad[0] - 2.0 * np.sum(dfw[m * d:m * d + d])) <= 1e-7 * scale
+    assert abs(ev.grad[1] + dfw[-2]) <= 1e-7 * scale
+    assert abs(ev.dl_dsigma2 + dfw[-1] / s2) <= 1e-7 * abs(ev.dl_dsigma2)
+    assert np.max(np.abs(ev.grad[2:].reshape(m, d) + dfw[:m * d].reshape(m, d, order="F"))) <= 1e-7 * scale

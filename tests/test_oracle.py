@@ -281,3 +281,27 @@ def test_posterior_golden_fixtures_reproduce(name):
     knm, _ = O.spec_calc_shared_cross(k, g["X"], g["Z"])
     st = O.stats_calc(g["y"], knm @ out["coeffs"], out["l"])
     assert relinf([st[key] for key in STAT_KEYS], g["stats"]) < 1e-12
+
+
+@pytest.mark.parametrize("shape", [(200, 8, 1), (150, 7, 3)])
+def test_against_snelson_spgp_lik(shape):
+    """test/oct.m:183-191 compares the reference with Edward Snelson's SPGP routine (test/spgp_lik.m), which the
+    reference ships in its test directory.  The same comparison here, for the oracle: evidence, d/dlog_ell,
+    d/dlog_sf2, d/dsigma2 (oct.m's eds_* mappings) and, beyond oct.m, every pseudo-input coordinate."""
+    from tests.snelson_spgp import spgp_lik
+    n, m, d = shape
+    X, y, Z = synth(23, n, m, d)
+    log_ell, log_sf2, sigma2 = 0.3, -0.2, 0.4
+    out = O.evaluate(O.SeIsoKernel(log_ell, log_sf2), Z, X, y, sigma2)
+    hyp = np.concatenate([np.full(d, -2.0 * log_ell), [log_sf2, np.log(sigma2)]])     # oct.m:185 (log_inv_ell2)
+    ew = np.concatenate([Z.T.ravel(order="F"), hyp])                                  # oct.m:186
+    fw, dfw = spgp_lik(ew, y, np.ascontiguousarray(X.T), m)
+    assert abs(out["l"] - (-fw)) < 1e-10 * abs(fw)                                    # eds_evidence
+    dfxb = dfw[:m * d].reshape(m, d, order="F")
+    dfb, dfc, dfsig = dfw[m * d:m * d + d], dfw[-2], dfw[-1]
+    g = out["grad"]
+    scale = np.max(np.abs(g))
+    assert abs(g[0] - 2.0 * np.sum(dfb)) < 1e-8 * scale                               # eds_dlog_ell = 2 dfw(end-2)
+    assert abs(g[1] - (-dfc)) < 1e-8 * scale                                          # eds_dlog_sf2
+    assert abs(out["dl_dsigma2"] - (-dfsig / sigma2)) < 1e-8 * abs(out["dl_dsigma2"])  # eds_dsigma2
+    assert np.max(np.abs(g[2:].reshape(m, d) - (-dfxb))) < 1e-8 * scale               # pseudo-inputs
