@@ -866,3 +866,21 @@ def test_hip_path_against_snelson_spgp_lik():
     assert abs(ev.grad[1] + dfw[-2]) <= 1e-7 * scale
     assert abs(ev.dl_dsigma2 + dfw[-1] / s2) <= 1e-7 * abs(ev.dl_dsigma2)
     assert np.max(np.abs(ev.grad[2:].reshape(m, d) + dfw[:m * d].reshape(m, d, order="F"))) <= 1e-7 * scale
+
+
+def test_parity_at_headline_inducing_count():
+    """Oracle parity at the headline m and d (2048, 8) on as many rows as the oracle evaluates in well under a
+    minute on the GPU box's host cores: two row chunks, the split-K factor search, the full 16 387-entry gradient."""
+    n, m, d = 40000, 2048, 8
+    X, y, Z = synth(2, n, m, d)
+    le = 0.5 * np.log(d)
+    ref = O.evaluate_fast(O.SeIsoKernel(le, 0.0), Z, X, y, 0.1)
+    p = gpr_amd.Problem(gpr_amd.COV_SE_ISO, n, d, d, m)
+    p.set_inputs(X)
+    p.set_targets(y)
+    ev = p.eval(log_ell=le, log_sf2=0.0, sigma2=0.1, inducing=Z)
+    p.close()
+    assert abs(ev.l - ref["l"]) <= TOL_L * abs(ref["l"])
+    assert abs(ev.dl_dsigma2 - ref["dl_dsigma2"]) <= TOL_DS2 * abs(ref["dl_dsigma2"])
+    assert ev.grad.shape == (2 + m * d,) and relinf(ev.grad, ref["grad"]) <= TOL_GRAD
+    assert relinf(ev.coeffs, ref["coeffs"]) <= TOL_COEFF
