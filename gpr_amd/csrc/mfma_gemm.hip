@@ -204,9 +204,18 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgsT<T> g) {
     Bg = g.B + (int64_t)(k_lo + km_k) * g.ldb + (int64_t)bn * TILE + EPV * km_v;
     b_step = (int64_t)BK * g.ldb;
   }
-  // fp64: km_k is wavefront-uniform (tid >> 6): say so, and the weights come through the scalar cache
-  const int km_ku = (VPR == 64) ? __builtin_amdgcn_readfirstlane(km_k) : km_k;
+  // The per-k weights come through the scalar cache.  fp64: a wavefront stages one k-row per pass (km_k = tid >> 6
+  // is wavefront-uniform).  fp32: a wavefront stages two adjacent k-rows (km_k = 2 * wave + half); both weights are
+  // fetched with wavefront-uniform addresses and each half-wave selects its own.
+  constexpr int RPW = 64 / VPR;  // k-rows per wavefront and pass: 1 (fp64) or 2 (fp32)
+  const int km_ku = __builtin_amdgcn_readfirstlane(km_k);  // first k-row of this wavefront
+  const bool hi_half = (RPW == 2) && (lane >= 32);
   const double* sk = (A_KMAJ && g.scale_k) ? g.scale_k + k_lo + km_ku : nullptr;
+  auto weight = [&](const double* w, int off) -> double {
+    if (RPW == 1) return w[off];
+    const double w0 = w[off], w1 = w[off + 1];
+    return hi_half ? w1 : w0;
+  };
 
   // the per-k weights of the A operand are fetched with the tile and applied when the tile is
   // written to LDS, so the multiply never waits on a load that was just issued
@@ -225,8 +234,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgsT<T> g) {
     for (int p = 0; p < 4; ++p) {
       if (A_KMAJ) {
         ra[p] = *reinterpret_cast<const vec*>(ap + (int64_t)(KPP * p) * g.lda);
-        if (sk) rs[p] = (T)sk[t * BK + KPP * p];
-        if (do_cs) cwv[p] = cw[t * BK + KPP * p];
+        if (sk) rs[p] = (T)weight(sk, t * BK + KPP * p);
+        if (do_cs) cwv[p] = weight(cw, t * BK + KPP * p);
       } else {
         ra[p] = *reinterpret_cast<const vec*>(ap + (int64_t)(32 * p) * g.lda);
       }
