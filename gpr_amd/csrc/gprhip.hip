@@ -140,6 +140,7 @@ struct gprhip_problem {
   int ks_used = 8;
   int64_t slice_rows = 4096;  // training points per split-K slice of the SYRK launches
   int tile_order = 0;
+  int grad_scalar = 0;  // GPRHIP_GRAD_SCALAR: use the scalar gradient kernel even where the MFMA one applies
   // Cov_se_fat `Proj hypers: rows of the exchange-2 column block beyond d+1, and the D x d second term
   int dbig() const { return kind == GPRHIP_COV_SE_FAT ? D : 0; }
   bool has_proj() const { return kind == GPRHIP_COV_SE_FAT && h.tproj != nullptr; }
@@ -584,7 +585,14 @@ void do_pass2(gprhip_problem* p, const double* ar1, double* ar2) {
         }
         ga.rowes = p->rowes;
       }
-      launch_grad_fused(ga, s);
+      // matrix-core version unless multiscales (or > 64 dimensions) need the scalar kernel; GPRHIP_GRAD_SCALAR=1
+      // forces the scalar one (parity tests run both)
+      int nbx = p->grad_scalar ? 0 : grad_mfma_col_blocks(ga);
+      if (nbx > 0) launch_grad_mfma(ga, s);
+      else {
+        launch_grad_fused(ga, s);
+        nbx = (mp + 255) / 256;
+      }
       const int nslabs = (int)((rows + grad_slab_rows() - 1) / grad_slab_rows());
       launch_reduce_rows(p->colpart, nslabs, ga.col_rows * mp, ar2_col, 1, s);
       if (proj) {
@@ -598,7 +606,7 @@ void do_pass2(gprhip_problem* p, const double* ar1, double* ar2) {
         }
         launch_reduce_rows(p->projpart, (int)((rows + 255) / 256), p->D * p->d, ar2_proj, 1, s);
       }
-      launch_reduce_rows(p->scalpart, nslabs * ((mp + 255) / 256), 2, ar2_tail + A2_SUME, 1, s);
+      launch_reduce_rows(p->scalpart, nslabs * nbx, 2, ar2_tail + A2_SUME, 1, s);
       tstop(p);
     }
     // G~_part = V^T diag(v) V over all rows (the two dsyrk of lib/fitc_gp.ml:1198-1203, whitened, in one)
@@ -1177,6 +1185,7 @@ int gprhip_problem_create_ex(int device, int cov_kind, int precision, int64_t n,
     if (const char* e = getenv("GPRHIP_KSLICES")) p->kslices = std::max(8, atoi(e) / 8 * 8);
     if (const char* e = getenv("GPRHIP_TIMING")) p->timer.on = atoi(e) != 0;
     if (const char* e = getenv("GPRHIP_TILE_ORDER")) p->tile_order = atoi(e);
+    if (const char* e = getenv("GPRHIP_GRAD_SCALAR")) p->grad_scalar = atoi(e);
     GPR_HIP(hipStreamCreate(&p->stream));
     const int mp = p->mp;
     const int64_t mm = (int64_t)mp * mp;
@@ -1215,7 +1224,7 @@ int gprhip_problem_create_ex(int device, int cov_kind, int precision, int64_t n,
     p->gemvpart = p->alloc<double>((int64_t)p->kslices * mp);  // c~ partials, one row per k-slice
     const int64_t nslab = (chunk + grad_slab_rows() - 1) / grad_slab_rows();
     p->colpart = p->alloc<double>(nslab * p->col_rows() * mp);
-    p->scalpart = p->alloc<double>(nslab * ((mp + 255) / 256) * 2);
+    p->scalpart = p->alloc<double>(nslab * (mp / TILE) * 2);
     p->kmpart = p->alloc<double>((int64_t)((m + 255) / 256) * p->km_rows() * mp);
     p->kmred = p->alloc<double>(p->km_rows() * mp);
     p->ar1 = p->alloc<double>(mm + mp + A1_TAIL);

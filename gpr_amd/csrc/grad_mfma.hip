@@ -1,0 +1,217 @@
+// Fused gradient pass on the matrix cores (Cov_se_iso, Cov_se_fat without multiscales).
+//
+// Same outputs as grad_fused_kernel (rowops.hip): with E = X .* K_nm (K_nm recomputed, never stored)
+//   colpart[slab][0][c]       = sum_r E_rc                    `Factor / Log_sf2, lib/fitc_gp.ml:991
+//   colpart[slab][1+k][c]     = sum_r p_kr E_rc               `Sparse_cols inducing derivative, lib/cov_se_iso.ml:301-327
+//   colpart[slab][1+d+k][c]   = sum_r x_big,kr E_rc           `Proj, lib/cov_se_fat.ml:570-596
+//   scalpart[...][0..1]       = sum E, sum E * |p_r - z_c|^2  Log_ell, lib/cov_se_iso.ml:313-318
+// but the three contractions over the point dimension run as v_mfma_f64_16x16x4_f64:
+//   S = P Z^T  (the "distance GEMM" of SURVEY 8(d)):  |p_r - z_c|^2 = |p_r|^2 + |z_c|^2 - 2 S_rc
+//   G += P^T E, Gb += X_big^T E  (the "inducing-gradient GEMM")
+// A 16x16 tile of E comes out of the elementwise step in the accumulator layout (lane holds rows lq + 4r of column
+// l15), which is exactly four B operands (k = lq) of the next MFMAs: E never leaves the registers.
+// Workgroup: 4 wavefronts x 32 columns, one slab of 256 rows, rows staged through LDS 32 at a time.
+#include "kernels.h"
+
+namespace gprhip {
+
+namespace {
+
+typedef double gd4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ gd4 mfma4(double a, double b, gd4 c) {
+  return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ double wsum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+constexpr int G_SLAB = 256;  // must equal grad_slab_rows()
+constexpr int G_RC = 32;     // rows per staged chunk
+
+// KS4 = ceil(d / 4) k-steps of the distance product, DT = ceil(d / 16) tiles of point dimensions,
+// BT = ceil(D / 16) tiles of original input dimensions (0: no projection hypers)
+template <int KS4, int DT, int BT, typename TS>
+__global__ __launch_bounds__(256) void grad_mfma_kernel(GradArgs<TS> a) {
+  constexpr int DP = DT * 16, LDP = DP + 1;
+  constexpr int BP = BT > 0 ? BT * 16 : 1, LDB = BP + 1;
+  __shared__ double ps[G_RC * LDP];
+  __shared__ double bs[BT > 0 ? G_RC * LDB : 1];
+  __shared__ double pn[G_RC];
+  __shared__ double red[4][2];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int l15 = lane & 15, lq = lane >> 4;
+  const int cb = blockIdx.x * 128 + wv * 32;
+
+  double zf[2][KS4], zn[2];
+  bool live_c[2];
+#pragma unroll
+  for (int jt = 0; jt < 2; ++jt) {
+    const int col = cb + jt * 16 + l15;
+    live_c[jt] = col < a.m;
+    double s2 = 0.0;
+#pragma unroll
+    for (int s = 0; s < KS4; ++s) {
+      const int k = 4 * s + lq;
+      const double z = (live_c[jt] && k < a.d) ? a.Z[(int64_t)col * a.d + k] : 0.0;
+      zf[jt][s] = z;
+      s2 += z * z;
+    }
+    s2 += __shfl_xor(s2, 16);
+    s2 += __shfl_xor(s2, 32);
+    zn[jt] = s2;
+  }
+  gd4 g[DT][2], gb[BT > 0 ? BT : 1][2];
+#pragma unroll
+  for (int t = 0; t < DT; ++t)
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt) g[t][jt] = (gd4){0, 0, 0, 0};
+#pragma unroll
+  for (int t = 0; t < (BT > 0 ? BT : 1); ++t)
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt) gb[t][jt] = (gd4){0, 0, 0, 0};
+  double cs[2] = {0.0, 0.0}, sE = 0.0, sED = 0.0;
+
+  const int r0 = blockIdx.y * G_SLAB;
+  const int r1 = min(a.rows, r0 + G_SLAB);
+  for (int rb = r0; rb < r1; rb += G_RC) {
+    __syncthreads();
+    for (int idx = tid; idx < G_RC * DP; idx += 256) {
+      const int r = idx / DP, k = idx % DP;
+      ps[r * LDP + k] = (k < a.d && rb + r < r1) ? a.pts[(int64_t)(rb + r) * a.d + k] : 0.0;
+    }
+    if (BT > 0) {
+      for (int idx = tid; idx < G_RC * BP; idx += 256) {
+        const int r = idx / BP, k = idx % BP;
+        bs[r * LDB + k] = (k < a.D && rb + r < r1) ? a.big[(int64_t)(rb + r) * a.D + k] : 0.0;
+      }
+    }
+    __syncthreads();
+    if (tid < G_RC) {
+      double s2 = 0.0;
+      for (int k = 0; k < DP; ++k) s2 += ps[tid * LDP + k] * ps[tid * LDP + k];
+      pn[tid] = s2;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int rt = 0; rt < G_RC / 16; ++rt) {
+      if (rb + rt * 16 >= r1) break;
+      double xv[2][4];
+#pragma unroll
+      for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = rb + rt * 16 + lq + 4 * r;
+          xv[jt][r] = (row < r1) ? (double)a.X[(int64_t)row * a.mp + cb + jt * 16 + l15] : 0.0;
+        }
+      double ev[2][4];
+#pragma unroll
+      for (int jt = 0; jt < 2; ++jt) {
+        gd4 s4 = (gd4){0, 0, 0, 0};
+#pragma unroll
+        for (int s = 0; s < KS4; ++s) s4 = mfma4(ps[(rt * 16 + l15) * LDP + 4 * s + lq], zf[jt][s], s4);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int lr = rt * 16 + lq + 4 * r;
+          const double dist = fmax(pn[lr] + zn[jt] - 2.0 * s4[r], 0.0);
+          const double e = (live_c[jt] && rb + lr < r1) ? xv[jt][r] * exp(a.log_sf2 + a.inv_ell2_05 * dist) : 0.0;
+          ev[jt][r] = e;
+          cs[jt] += e;
+          sE += e;
+          sED += e * dist;
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int prow = (rt * 16 + 4 * r + lq);
+#pragma unroll
+        for (int t = 0; t < DT; ++t) {
+          const double ap = ps[prow * LDP + t * 16 + l15];
+          g[t][0] = mfma4(ap, ev[0][r], g[t][0]);
+          g[t][1] = mfma4(ap, ev[1][r], g[t][1]);
+        }
+        if (BT > 0) {
+#pragma unroll
+          for (int t = 0; t < (BT > 0 ? BT : 1); ++t) {
+            const double ab = bs[prow * LDB + t * 16 + l15];
+            gb[t][0] = mfma4(ab, ev[0][r], gb[t][0]);
+            gb[t][1] = mfma4(ab, ev[1][r], gb[t][1]);
+          }
+        }
+      }
+    }
+  }
+
+  double* cp = a.colpart + (int64_t)blockIdx.y * a.col_rows * a.mp;
+#pragma unroll
+  for (int jt = 0; jt < 2; ++jt) {
+    const int col = cb + jt * 16 + l15;
+    double c = cs[jt];
+    c += __shfl_xor(c, 16);
+    c += __shfl_xor(c, 32);
+    if (lq == 0) cp[col] = c;
+#pragma unroll
+    for (int t = 0; t < DT; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int dim = t * 16 + lq + 4 * r;
+        if (dim < a.d) cp[(int64_t)(1 + dim) * a.mp + col] = g[t][jt][r];
+      }
+    if (BT > 0) {
+#pragma unroll
+      for (int t = 0; t < (BT > 0 ? BT : 1); ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int dim = t * 16 + lq + 4 * r;
+          if (dim < a.D) cp[(int64_t)(a.d + 1 + dim) * a.mp + col] = gb[t][jt][r];
+        }
+    }
+  }
+  sE = wsum(sE);
+  sED = wsum(sED);
+  if (lane == 0) {
+    red[wv][0] = sE;
+    red[wv][1] = sED;
+  }
+  __syncthreads();
+  if (tid < 2)
+    a.scalpart[((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 2 + tid] =
+        (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+}
+
+template <int KS4, int DT, typename TS>
+void dispatch_big(const GradArgs<TS>& a, dim3 grid, hipStream_t s) {
+  if (!a.big) hipLaunchKernelGGL((grad_mfma_kernel<KS4, DT, 0, TS>), grid, dim3(256), 0, s, a);
+  else if (a.D <= 16) hipLaunchKernelGGL((grad_mfma_kernel<KS4, DT, 1, TS>), grid, dim3(256), 0, s, a);
+  else if (a.D <= 32) hipLaunchKernelGGL((grad_mfma_kernel<KS4, DT, 2, TS>), grid, dim3(256), 0, s, a);
+  else hipLaunchKernelGGL((grad_mfma_kernel<KS4, DT, 4, TS>), grid, dim3(256), 0, s, a);
+}
+
+}  // namespace
+
+// Column blocks (128 columns each) of the MFMA gradient kernel; 0 when the launch is not eligible
+// (multiscales, or more than 64 point / input dimensions) and the scalar kernel has to be used.
+template <typename TS>
+int grad_mfma_col_blocks(const GradArgs<TS>& a) {
+  if (a.ms || a.d > 64 || a.D > 64 || (a.mp % 128) != 0) return 0;
+  return a.mp / 128;
+}
+
+template <typename TS>
+void launch_grad_mfma(const GradArgs<TS>& a, hipStream_t s) {
+  dim3 grid(a.mp / 128, (a.rows + G_SLAB - 1) / G_SLAB);
+  if (a.d <= 4) dispatch_big<1, 1, TS>(a, grid, s);
+  else if (a.d <= 8) dispatch_big<2, 1, TS>(a, grid, s);
+  else if (a.d <= 16) dispatch_big<4, 1, TS>(a, grid, s);
+  else if (a.d <= 32) dispatch_big<8, 2, TS>(a, grid, s);
+  else dispatch_big<16, 4, TS>(a, grid, s);
+  GPR_HIP(hipGetLastError());
+}
+
+template int grad_mfma_col_blocks<double>(const GradArgs<double>&);
+template int grad_mfma_col_blocks<float>(const GradArgs<float>&);
+template void launch_grad_mfma<double>(const GradArgs<double>&, hipStream_t);
+template void launch_grad_mfma<float>(const GradArgs<float>&, hipStream_t);
+
+}  // namespace gprhip

@@ -149,6 +149,11 @@ void launch_proj_term2(const double* X, const double* P, const double* es, int e
 // es[row][k] = sum_slot rowes[row][slot][k]
 void launch_reduce_rowes(const double* rowes, int rows, int nslots, int d, double* es, hipStream_t s);
 int grad_slab_rows();
+// the same pass on the matrix cores (grad_mfma.hip): column blocks of 128, or 0 if the launch is not eligible
+template <typename TS>
+int grad_mfma_col_blocks(const GradArgs<TS>& a);
+template <typename TS>
+void launch_grad_mfma(const GradArgs<TS>& a, hipStream_t s);
 template <typename TS>
 void launch_grad_fused(const GradArgs<TS>& a, hipStream_t s);
 

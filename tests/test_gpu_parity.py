@@ -884,3 +884,21 @@ def test_parity_at_headline_inducing_count():
     assert abs(ev.dl_dsigma2 - ref["dl_dsigma2"]) <= TOL_DS2 * abs(ref["dl_dsigma2"])
     assert ev.grad.shape == (2 + m * d,) and relinf(ev.grad, ref["grad"]) <= TOL_GRAD
     assert relinf(ev.coeffs, ref["coeffs"]) <= TOL_COEFF
+
+
+@pytest.mark.parametrize("name", ["iso_ragged", "fat_proj", "fat_hetero"])
+def test_scalar_and_mfma_gradient_kernels_agree(name, monkeypatch):
+    """The fused gradient pass exists twice: on the matrix cores (grad_mfma.hip: distance and inducing-gradient
+    products as MFMA tiles, |p - z|^2 by expansion) and as the scalar kernel that multiscales still need
+    (rowops.hip, direct differences).  Both must meet the oracle tolerance and agree with each other."""
+    g = load_golden(name)
+    p = _problem_for(g)
+    a = _eval_golden(p, g)
+    p.close()
+    monkeypatch.setenv("GPRHIP_GRAD_SCALAR", "1")
+    q = _problem_for(g)
+    b = _eval_golden(q, g)
+    q.close()
+    assert relinf(a.grad, g["grad"]) <= TOL_GRAD and relinf(b.grad, g["grad"]) <= TOL_GRAD
+    assert relinf(a.grad, b.grad) <= 1e-9
+    assert a.l == b.l
