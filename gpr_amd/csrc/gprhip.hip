@@ -94,6 +94,7 @@ struct gprhip_problem {
   int* info = nullptr;
   double *r = nullptr, *is = nullptr, *yis = nullptr, *w = nullptr, *v = nullptr, *es = nullptr;
   double* projpart = nullptr;
+  double* zshift = nullptr;  // [64] centroid of the inducing points (gradient kernel's expansion offset)
   double *rp1 = nullptr, *rp2 = nullptr;  // per-row partial sums from the GEMM epilogues [chunk][2*mp/128]
   double *xt = nullptr, *pt = nullptr, *prow = nullptr;  // prediction: test-point chunk, its projection, 3 row vectors
   bool have_model = false;
@@ -116,6 +117,7 @@ struct gprhip_problem {
   int64_t n_total = 0;
   int stage = 0;  // 0 idle, 1 pass1 done, 2 pass2 done
   bool have_inputs = false, have_targets = false;
+  std::vector<double> hShift;  // centroid of the inducing points
   std::vector<double> hZ;  // host copy of inducing (padded point-major) for the gradient assembly
   std::vector<double> hTproj, hHet, hMs;  // host copies: projection, exp(log_hetero), multiscales [mp][d]
   double* het = nullptr;                  // device copy of hHet
@@ -366,6 +368,13 @@ void upload_hypers(gprhip_problem* p, const gprhip_hypers* h) {
   std::memcpy(p->hZ.data(), h->inducing, (size_t)p->m * p->d * sizeof(double));
   GPR_HIP(hipMemcpyAsync(p->Z, p->hZ.data(), p->hZ.size() * sizeof(double), hipMemcpyHostToDevice,
                          p->stream));
+  {  // centroid of the inducing points
+    p->hShift.assign(64, 0.0);
+    for (int c = 0; c < p->m; ++c)
+      for (int k = 0; k < p->d && k < 64; ++k) p->hShift[k] += p->hZ[(size_t)c * p->d + k];
+    for (int k = 0; k < 64; ++k) p->hShift[k] /= p->m;
+    GPR_HIP(hipMemcpyAsync(p->zshift, p->hShift.data(), 64 * sizeof(double), hipMemcpyHostToDevice, p->stream));
+  }
   if (h->tproj) {
     p->hTproj.assign(h->tproj, h->tproj + (size_t)p->D * p->d);  // borrowed pointer: copy before returning
     p->h.tproj = p->hTproj.data();
@@ -575,7 +584,7 @@ void do_pass2(gprhip_problem* p, const double* ar1, double* ar2) {
       ga.log_sf2 = p->cp.log_sf2; ga.inv_ell2_05 = p->cp.inv_ell2_05;
       ga.colpart = p->colpart; ga.scalpart = p->scalpart;
       ga.big = proj ? p->X + base * p->D : nullptr; ga.D = proj ? p->D : 0;
-      ga.ms = p->cp.ms; ga.rowes = nullptr;
+      ga.ms = p->cp.ms; ga.rowes = nullptr; ga.shift = p->zshift;
       ga.col_rows = p->d + 1 + ga.D + (ga.ms ? p->d : 0);  // rows this launch produces (tightly packed)
       const int nslots = 4 * ((mp + 255) / 256);
       if (ga.ms && proj) {
@@ -1225,6 +1234,7 @@ int gprhip_problem_create_ex(int device, int cov_kind, int precision, int64_t n,
     const int64_t nslab = (chunk + grad_slab_rows() - 1) / grad_slab_rows();
     p->colpart = p->alloc<double>(nslab * p->col_rows() * mp);
     p->scalpart = p->alloc<double>(nslab * (mp / TILE) * 2);
+    p->zshift = p->alloc<double>(64);
     p->kmpart = p->alloc<double>((int64_t)((m + 255) / 256) * p->km_rows() * mp);
     p->kmred = p->alloc<double>(p->km_rows() * mp);
     p->ar1 = p->alloc<double>(mm + mp + A1_TAIL);

@@ -7,6 +7,8 @@
 //   scalpart[...][0..1]       = sum E, sum E * |p_r - z_c|^2  Log_ell, lib/cov_se_iso.ml:313-318
 // but the three contractions over the point dimension run as v_mfma_f64_16x16x4_f64:
 //   S = P Z^T  (the "distance GEMM" of SURVEY 8(d)):  |p_r - z_c|^2 = |p_r|^2 + |z_c|^2 - 2 S_rc
+//     (both sides are first shifted by the centroid of the inducing points, so the expansion loses digits only
+//      relative to the spread of the data, not to a common offset; sum_r p_kr E_rc is corrected by shift_k * sum_r E_rc)
 //   G += P^T E, Gb += X_big^T E  (the "inducing-gradient GEMM")
 // A 16x16 tile of E comes out of the elementwise step in the accumulator layout (lane holds rows lq + 4r of column
 // l15), which is exactly four B operands (k = lq) of the next MFMAs: E never leaves the registers.
@@ -54,7 +56,7 @@ __global__ __launch_bounds__(256) void grad_mfma_kernel(GradArgs<TS> a) {
 #pragma unroll
     for (int s = 0; s < KS4; ++s) {
       const int k = 4 * s + lq;
-      const double z = (live_c[jt] && k < a.d) ? a.Z[(int64_t)col * a.d + k] : 0.0;
+      const double z = (live_c[jt] && k < a.d) ? a.Z[(int64_t)col * a.d + k] - (a.shift ? a.shift[k] : 0.0) : 0.0;
       zf[jt][s] = z;
       s2 += z * z;
     }
@@ -79,7 +81,8 @@ __global__ __launch_bounds__(256) void grad_mfma_kernel(GradArgs<TS> a) {
     __syncthreads();
     for (int idx = tid; idx < G_RC * DP; idx += 256) {
       const int r = idx / DP, k = idx % DP;
-      ps[r * LDP + k] = (k < a.d && rb + r < r1) ? a.pts[(int64_t)(rb + r) * a.d + k] : 0.0;
+      ps[r * LDP + k] =
+          (k < a.d && rb + r < r1) ? a.pts[(int64_t)(rb + r) * a.d + k] - (a.shift ? a.shift[k] : 0.0) : 0.0;
     }
     if (BT > 0) {
       for (int idx = tid; idx < G_RC * BP; idx += 256) {
@@ -156,7 +159,7 @@ __global__ __launch_bounds__(256) void grad_mfma_kernel(GradArgs<TS> a) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int dim = t * 16 + lq + 4 * r;
-        if (dim < a.d) cp[(int64_t)(1 + dim) * a.mp + col] = g[t][jt][r];
+        if (dim < a.d) cp[(int64_t)(1 + dim) * a.mp + col] = g[t][jt][r] + (a.shift ? a.shift[dim] * c : 0.0);
       }
     if (BT > 0) {
 #pragma unroll

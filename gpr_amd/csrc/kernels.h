@@ -139,6 +139,8 @@ struct GradArgs {
                          //     rows d+1..d+D = sum_r x_big,r E_rc, then (multiscales) d rows sum_r p_kr^2 E_rc
   int col_rows;          // rows of one slab of colpart
   double* scalpart;      // out [nslabs][nbx][2]: sum E, sum E*sqr_diff
+  const double* shift;   // [d] common offset (centroid of the inducing points) the MFMA kernel subtracts from points
+                         //     and inducing points before it expands |p - z|^2, or null
   const double* ms;      // multiscales [mp][d] or null (Cov_se_fat)
   double* rowes;         // multiscales + tproj: out [rows][nslots][d] partial sum_c E_rc / ms_kc, nslots = 4*gridDim.x
 };

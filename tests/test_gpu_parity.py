@@ -902,3 +902,20 @@ def test_scalar_and_mfma_gradient_kernels_agree(name, monkeypatch):
     assert relinf(a.grad, g["grad"]) <= TOL_GRAD and relinf(b.grad, g["grad"]) <= TOL_GRAD
     assert relinf(a.grad, b.grad) <= 1e-9
     assert a.l == b.l
+
+
+def test_inputs_with_a_large_common_offset():
+    """The matrix-core gradient kernel expands |p - z|^2 around the centroid of the inducing points: data far from
+    the origin (offset 1e4 at unit spread) must not cost digits against the oracle's direct differences."""
+    n, m, d = 3000, 100, 3
+    X, y, Z = synth(31, n, m, d)
+    X = np.asfortranarray(X + 1.0e4)
+    Z = np.asfortranarray(Z + 1.0e4)
+    ref = O.evaluate_fast(O.SeIsoKernel(0.3, 0.0), Z, X, y, 0.1)
+    p = gpr_amd.Problem(gpr_amd.COV_SE_ISO, n, d, d, m)
+    p.set_inputs(X)
+    p.set_targets(y)
+    ev = p.eval(log_ell=0.3, log_sf2=0.0, sigma2=0.1, inducing=Z)
+    p.close()
+    assert abs(ev.l - ref["l"]) <= TOL_L * abs(ref["l"])
+    assert relinf(ev.grad, ref["grad"]) <= TOL_GRAD
