@@ -473,8 +473,9 @@ void do_pass1(gprhip_problem* p, const gprhip_hypers* h, int want_grad, int64_t 
       tstop(p);
     }
     tstart(p, "p1_rows");
-    Pass1RowArgs<TS> ra;
-    ra.V = nullptr; ra.part = reuse ? nullptr : p->rp1; ra.npart = 2 * (mp / TILE); ra.y = h->model_only ? nullptr : p->y + base; ra.rows = (int)rows; ra.mp = mp;
+    Pass1RowArgs ra;
+    ra.part = reuse ? nullptr : p->rp1; ra.npart = 2 * (mp / TILE); ra.ld = rows_p;
+    ra.y = h->model_only ? nullptr : p->y + base; ra.rows = (int)rows;
     ra.sf2 = p->cp.sf2; ra.sigma2 = h->sigma2;
     ra.r = p->r + base; ra.is = p->is + base; ra.yis = p->yis + base; ra.partial = p->rowpart;
     launch_pass1_rows(ra, s);
@@ -554,10 +555,10 @@ void do_pass2(gprhip_problem* p, const double* ar1, double* ar2) {
       launch_gemm(OP_NN, q, s);
       tstop(p);
       tstart(p, "p2_rows");
-      Pass2RowArgs<TS> ra;
-      ra.Q = nullptr; ra.part_sq = p->rp1; ra.part_dot = p->rp2; ra.npart = 2 * (mp / TILE); ra.b = p->bvec;
+      Pass2RowArgs ra;
+      ra.part_sq = p->rp1; ra.part_dot = p->rp2; ra.npart = 2 * (mp / TILE); ra.ld = rows_p;
       ra.y = mo ? nullptr : p->y + base; ra.is = p->is + base; ra.r = p->r + base;
-      ra.rows = (int)rows; ra.mp = mp; ra.variational = p->h.variational;
+      ra.rows = (int)rows; ra.variational = p->h.variational;
       ra.sf2 = p->cp.sf2; ra.es = proj ? p->es + base : nullptr;
       ra.w = p->w + base; ra.v = p->v + base; ra.partial = p->rowpart;
       launch_pass2_rows(ra, s);

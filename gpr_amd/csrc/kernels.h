@@ -59,13 +59,13 @@ void launch_logdet(const double* A, int mp, int m, double* out, hipStream_t s);
 void launch_triu_matvec(const double* A, int mp, const double* x, double* y, int trans, hipStream_t s);
 
 // ---- row kernels (rowops.hip)
-template <typename TS>
 struct Pass1RowArgs {
-  const TS* V;           // [rows_p][mp]; null = keep r of the previous evaluation (update_sigma2)
-  const double* part;    // alternative to V: [rows_p][npart] partial row sums of V^2 from the GEMM epilogue
+  const double* part;    // [npart][ld] partial row sums of V^2 from the epilogue of the V product (part-major);
+                         //   null = keep r of the previous evaluation (update_sigma2)
   int npart;
+  int64_t ld;
   const double* y;       // [rows] targets of this chunk (may be null: model-only)
-  int rows, mp;
+  int rows;
   double sf2, sigma2;
   double* r;             // out [rows]
   double* is;            // out [rows_p] (padding rows get 0)
@@ -73,28 +73,24 @@ struct Pass1RowArgs {
   double* partial;       // out [nblocks][4]: sum log s, sum is*y^2, sum is*r, unused
 };
 int pass1_row_blocks(int rows);
-template <typename TS>
-void launch_pass1_rows(const Pass1RowArgs<TS>& a, hipStream_t s);
+void launch_pass1_rows(const Pass1RowArgs& a, hipStream_t s);
 
-template <typename TS>
 struct Pass2RowArgs {
-  const TS* Q;           // [rows_p][mp]  K_chunk * Rinv (null when the partial sums below are given)
-  const double* part_sq;  // [rows_p][npart] partial row sums of Q'^2 from the GEMM epilogue, or null
-  const double* part_dot; // [rows_p][npart] partial row sums of Q' .* b
+  const double* part_sq;  // [npart][ld] partial row sums of Q'^2 from the epilogue of the Q' product
+  const double* part_dot; // [npart][ld] partial row sums of Q' .* b  (b = Rinv^T c = Q_n^T y~ of the reference)
   int npart;
-  const double* b;       // [mp]          Rinv^T c  (= Q_n^T y~ of the reference)
+  int64_t ld;
   const double* y;       // [rows] or null
   const double* is;      // [rows_p]
   const double* r;       // [rows]
-  int rows, mp, variational;
+  int rows, variational;
   double sf2;
   double* es;            // optional out [rows_p]: rowsum(X .* K) = q - v (sf2 - r) - w (K t)  (Proj gradient)
   double* w;             // out [rows_p]  (padding 0)
   double* v;             // out [rows_p]  (padding 0)
   double* partial;       // out [nblocks][4]: sum v, sum is, sum w*(y-Kt) (= sum is*res^2), sum v1
 };
-template <typename TS>
-void launch_pass2_rows(const Pass2RowArgs<TS>& a, hipStream_t s);
+void launch_pass2_rows(const Pass2RowArgs& a, hipStream_t s);
 
 // Per row of M [rows_p][mp]: sumsq[row] = sum_c M^2, dot[row] = sum_c M*b (either output may be null).
 // Prediction path: Means.calc / Variances.calc (lib/fitc_gp.ml:418-425, :498-518).

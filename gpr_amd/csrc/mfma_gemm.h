@@ -56,8 +56,9 @@ struct GemmArgsT {
   const T* epi_mat = nullptr;
   int64_t epi_ldm = 0;
   // optional per-row reductions of the result tile, fused into the plain-store epilogue:
-  //   rp_sumsq[row*(2*N/128) + 2*bn + wc] = sum of C[row][c]^2 over the 64 columns wave column wc owns in tile bn
-  //   rp_dot  [same index]               = sum of C[row][c] * rp_vec[c] over the same columns
+  //   rp_sumsq[(2*bn + wc) * M + row] = sum of C[row][c]^2 over the 64 columns wave column wc owns in tile bn
+  //   rp_dot  [same index]            = sum of C[row][c] * rp_vec[c] over the same columns
+  // (part-major: the 64 lanes of a wavefront write 64 consecutive rows)
   // (diag(Q_nn)-type row quantities without re-reading the n x m result: lib/fitc_gp.ml:222-223, :1048, :1164)
   // optional weighted column sums of the raw A operand, computed by the diagonal-tile blocks of an upper_only TN
   // launch while they stream A anyway:  cs_out[slice * N + c] = sum_{k in slice} A[k][c] * cs_w[k]

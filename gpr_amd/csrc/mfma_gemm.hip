@@ -420,7 +420,6 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgsT<T> g) {
   if (g.rp_sumsq) {
     // wavefront row reductions over this wave's 64 columns: 4 values in-thread, then the 16 lanes of a
     // row group by xor-shuffles; lane l15 == 0 writes one partial per (row, tile, wave column)
-    const int npart = 2 * nbn;
     double bv[4] = {0.0, 0.0, 0.0, 0.0};
     if (g.rp_dot) {
 #pragma unroll
@@ -462,7 +461,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgsT<T> g) {
     fold(std::integral_constant<int, 4>{});
     fold(std::integral_constant<int, 2>{});
     fold(std::integral_constant<int, 1>{});
-    const int64_t idx = (int64_t)(rowb + (l15 >> 2) * 16 + G::crow(lq, l15 & 3)) * npart + 2 * bn + wc;
+    const int64_t idx = (int64_t)(2 * bn + wc) * g.M + (rowb + (l15 >> 2) * 16 + G::crow(lq, l15 & 3));
     g.rp_sumsq[idx] = s2[0];
     if (g.rp_dot) g.rp_dot[idx] = sd[0];
   }

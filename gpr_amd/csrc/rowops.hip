@@ -31,158 +31,114 @@ struct RowVec<float> {
   }
 };
 
-constexpr int ROWS_PER_BLOCK = 16;  // 4 wavefronts x 4 rows
+constexpr int ROWS_PER_BLOCK = 256;  // one training point per thread
 
 int pass1_row_blocks(int rows_p) { return (rows_p + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK; }
 
-// r = k_diag - rowsum(V.^2)            lib/fitc_gp.ml:222-223 (Mat.syrk_diag)
-// s = r + sigma2, is = 1/s, sum log s   lib/fitc_gp.ml:155-166
-template <typename TS>
-__global__ __launch_bounds__(256) void pass1_rows_kernel(Pass1RowArgs<TS> a, int rows_p) {
+// block sums of up to four per-thread values, wavefronts combined in a fixed order -> partial[block][4]
+__device__ __forceinline__ void block_sums4(double v0, double v1, double v2, double v3, double* out) {
   __shared__ double red[4][4];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  double p_log = 0.0, p_y2 = 0.0, p_isr = 0.0;
-  for (int q = 0; q < 4; ++q) {
-    const int row = blockIdx.x * ROWS_PER_BLOCK + wv * 4 + q;
-    if (row >= rows_p) break;
-    double s2 = 0.0;
-    if (a.part) {  // partial sums from the GEMM epilogue, combined in a fixed order
-      const double* pp = a.part + (int64_t)row * a.npart;
-      for (int c = lane; c < a.npart; c += 64) s2 += pp[c];
-      s2 = wave_sum(s2);
-    } else if (a.V) {
-      const TS* v = a.V + (int64_t)row * a.mp;
-      constexpr int NV = RowVec<TS>::N;
-      for (int c = lane * NV; c < a.mp; c += 64 * NV) {
-        double x[NV];
-        RowVec<TS>::load(v + c, x);
-#pragma unroll
-        for (int e = 0; e < NV; ++e) s2 += x[e] * x[e];
-      }
-      s2 = wave_sum(s2);
-    }
-    if (lane == 0) {
-      if (row < a.rows) {
-        // V == null: Model.update_sigma2 (lib/fitc_gp.ml:234-236) -- r of the previous evaluation is kept
-        const double r = (a.V || a.part) ? a.sf2 - s2 : a.r[row];
-        const double s = r + a.sigma2;
-        const double is = 1.0 / s;
-        const double y = a.y ? a.y[row] : 0.0;
-        a.r[row] = r;
-        a.is[row] = is;
-        a.yis[row] = is * y;
-        p_log += log(s);
-        p_y2 += is * y * y;
-        p_isr += is * r;
-      } else {
-        a.r[row] = 0.0;
-        a.is[row] = 0.0;
-        a.yis[row] = 0.0;
-      }
-    }
-  }
+  v0 = wave_sum(v0);
+  v1 = wave_sum(v1);
+  v2 = wave_sum(v2);
+  v3 = wave_sum(v3);
   if (lane == 0) {
-    red[wv][0] = p_log;
-    red[wv][1] = p_y2;
-    red[wv][2] = p_isr;
-  }
-  __syncthreads();
-  if (threadIdx.x < 3) {
-    const int k = threadIdx.x;
-    a.partial[(int64_t)blockIdx.x * 4 + k] = (red[0][k] + red[1][k]) + (red[2][k] + red[3][k]);
-  }
-  if (threadIdx.x == 3) a.partial[(int64_t)blockIdx.x * 4 + 3] = 0.0;
-}
-
-template <typename TS>
-void launch_pass1_rows(const Pass1RowArgs<TS>& a, hipStream_t s) {
-  const int rows_p = (int)round_up(a.rows, TILE);
-  hipLaunchKernelGGL(pass1_rows_kernel<TS>, dim3(pass1_row_blocks(rows_p)), dim3(256), 0, s, a, rows_p);
-  GPR_HIP(hipGetLastError());
-}
-template void launch_pass1_rows<double>(const Pass1RowArgs<double>&, hipStream_t);
-template void launch_pass1_rows<float>(const Pass1RowArgs<float>&, hipStream_t);
-
-// q_diag, u, w, v of lib/fitc_gp.ml:1048, :1092-1108, :1158-1181 from Q' = K R^-1 (so that
-// Q_n = diag(sqrt is) Q'):  q_diag = is*|Q'_i|^2,  u/sqrt(is) = y - Q' b  (b = Q_n^T y~),
-// w = is*(y - Q' b),  v1 = is*(1-q) [variational: is*(2 - is*r - q)],  v = v1 - w^2.
-template <typename TS>
-__global__ __launch_bounds__(256) void pass2_rows_kernel(Pass2RowArgs<TS> a, int rows_p) {
-  __shared__ double red[4][4];
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  double p_v = 0.0, p_is = 0.0, p_res = 0.0, p_v1 = 0.0;
-  for (int q = 0; q < 4; ++q) {
-    const int row = blockIdx.x * ROWS_PER_BLOCK + wv * 4 + q;
-    if (row >= rows_p) break;
-    double s2 = 0.0, sb = 0.0;
-    if (a.part_sq) {
-      const double* p1 = a.part_sq + (int64_t)row * a.npart;
-      const double* p2 = a.part_dot + (int64_t)row * a.npart;
-      for (int c = lane; c < a.npart; c += 64) {
-        s2 += p1[c];
-        sb += p2[c];
-      }
-      s2 = wave_sum(s2);
-      sb = wave_sum(sb);
-    } else {
-      const TS* qr = a.Q + (int64_t)row * a.mp;
-      constexpr int NV = RowVec<TS>::N;
-      for (int c = lane * NV; c < a.mp; c += 64 * NV) {
-        double x[NV];
-        RowVec<TS>::load(qr + c, x);
-#pragma unroll
-        for (int e = 0; e < NV; ++e) {
-          s2 += x[e] * x[e];
-          sb += x[e] * a.b[c + e];
-        }
-      }
-      s2 = wave_sum(s2);
-      sb = wave_sum(sb);
-    }
-    if (lane == 0) {
-      if (row < a.rows) {
-        const double is = a.is[row];
-        const double qd = is * s2;
-        const double y = a.y ? a.y[row] : 0.0;
-        const double res = a.y ? (y - sb) : 0.0;
-        const double w = is * res;
-        double v1 = a.variational ? is * (2.0 - is * a.r[row] - qd) : is * (1.0 - qd);
-        const double v = v1 - w * w;
-        a.w[row] = w;
-        a.v[row] = v;
-        if (a.es) a.es[row] = qd - v * (a.sf2 - a.r[row]) - w * sb;
-        p_v += v;
-        p_is += is;
-        p_res += w * res;
-        p_v1 += v1;
-      } else {
-        a.w[row] = 0.0;
-        a.v[row] = 0.0;
-        if (a.es) a.es[row] = 0.0;
-      }
-    }
-  }
-  if (lane == 0) {
-    red[wv][0] = p_v;
-    red[wv][1] = p_is;
-    red[wv][2] = p_res;
-    red[wv][3] = p_v1;
+    red[wv][0] = v0;
+    red[wv][1] = v1;
+    red[wv][2] = v2;
+    red[wv][3] = v3;
   }
   __syncthreads();
   if (threadIdx.x < 4) {
     const int k = threadIdx.x;
-    a.partial[(int64_t)blockIdx.x * 4 + k] = (red[0][k] + red[1][k]) + (red[2][k] + red[3][k]);
+    out[k] = (red[0][k] + red[1][k]) + (red[2][k] + red[3][k]);
   }
 }
 
-template <typename TS>
-void launch_pass2_rows(const Pass2RowArgs<TS>& a, hipStream_t s) {
+// r = k_diag - rowsum(V.^2)            lib/fitc_gp.ml:222-223 (Mat.syrk_diag)
+// s = r + sigma2, is = 1/s, sum log s   lib/fitc_gp.ml:155-166
+// rowsum(V.^2) arrives as `npart` partial sums per row from the epilogue of the V product, part-major
+// ([npart][ld]: adjacent threads read adjacent addresses).
+__global__ __launch_bounds__(256) void pass1_rows_kernel(Pass1RowArgs a, int rows_p) {
+  const int row = blockIdx.x * ROWS_PER_BLOCK + threadIdx.x;
+  double p_log = 0.0, p_y2 = 0.0, p_isr = 0.0;
+  if (row < rows_p) {
+    if (row < a.rows) {
+      double r;
+      if (a.part) {
+        double s2 = 0.0;
+        for (int c = 0; c < a.npart; ++c) s2 += a.part[(int64_t)c * a.ld + row];
+        r = a.sf2 - s2;
+      } else {
+        r = a.r[row];  // Model.update_sigma2 (lib/fitc_gp.ml:234-236): r of the previous evaluation is kept
+      }
+      const double s = r + a.sigma2;
+      const double is = 1.0 / s;
+      const double y = a.y ? a.y[row] : 0.0;
+      a.r[row] = r;
+      a.is[row] = is;
+      a.yis[row] = is * y;
+      p_log = log(s);
+      p_y2 = is * y * y;
+      p_isr = is * r;
+    } else {
+      a.r[row] = 0.0;
+      a.is[row] = 0.0;
+      a.yis[row] = 0.0;
+    }
+  }
+  block_sums4(p_log, p_y2, p_isr, 0.0, a.partial + (int64_t)blockIdx.x * 4);
+}
+
+void launch_pass1_rows(const Pass1RowArgs& a, hipStream_t s) {
   const int rows_p = (int)round_up(a.rows, TILE);
-  hipLaunchKernelGGL(pass2_rows_kernel<TS>, dim3(pass1_row_blocks(rows_p)), dim3(256), 0, s, a, rows_p);
+  hipLaunchKernelGGL(pass1_rows_kernel, dim3(pass1_row_blocks(rows_p)), dim3(256), 0, s, a, rows_p);
   GPR_HIP(hipGetLastError());
 }
-template void launch_pass2_rows<double>(const Pass2RowArgs<double>&, hipStream_t);
-template void launch_pass2_rows<float>(const Pass2RowArgs<float>&, hipStream_t);
+
+// q_diag, u, w, v of lib/fitc_gp.ml:1048, :1092-1108, :1158-1181 from Q' = K R^-1 (so that
+// Q_n = diag(sqrt is) Q'):  q_diag = is*|Q'_i|^2,  u/sqrt(is) = y - Q' b  (b = Q_n^T y~),
+// w = is*(y - Q' b),  v1 = is*(1-q) [variational: is*(2 - is*r - q)],  v = v1 - w^2.
+// |Q'_i|^2 and Q'_i . b arrive as partial sums from the epilogue of the Q' product (part-major, as above).
+__global__ __launch_bounds__(256) void pass2_rows_kernel(Pass2RowArgs a, int rows_p) {
+  const int row = blockIdx.x * ROWS_PER_BLOCK + threadIdx.x;
+  double p_v = 0.0, p_is = 0.0, p_res = 0.0, p_v1 = 0.0;
+  if (row < rows_p) {
+    if (row < a.rows) {
+      double s2 = 0.0, sb = 0.0;
+      for (int c = 0; c < a.npart; ++c) {
+        s2 += a.part_sq[(int64_t)c * a.ld + row];
+        sb += a.part_dot[(int64_t)c * a.ld + row];
+      }
+      const double is = a.is[row];
+      const double qd = is * s2;
+      const double y = a.y ? a.y[row] : 0.0;
+      const double res = a.y ? (y - sb) : 0.0;
+      const double w = is * res;
+      const double v1 = a.variational ? is * (2.0 - is * a.r[row] - qd) : is * (1.0 - qd);
+      const double v = v1 - w * w;
+      a.w[row] = w;
+      a.v[row] = v;
+      if (a.es) a.es[row] = qd - v * (a.sf2 - a.r[row]) - w * sb;
+      p_v = v;
+      p_is = is;
+      p_res = w * res;
+      p_v1 = v1;
+    } else {
+      a.w[row] = 0.0;
+      a.v[row] = 0.0;
+      if (a.es) a.es[row] = 0.0;
+    }
+  }
+  block_sums4(p_v, p_is, p_res, p_v1, a.partial + (int64_t)blockIdx.x * 4);
+}
+
+void launch_pass2_rows(const Pass2RowArgs& a, hipStream_t s) {
+  const int rows_p = (int)round_up(a.rows, TILE);
+  hipLaunchKernelGGL(pass2_rows_kernel, dim3(pass1_row_blocks(rows_p)), dim3(256), 0, s, a, rows_p);
+  GPR_HIP(hipGetLastError());
+}
 
 template <typename TS>
 __global__ __launch_bounds__(256) void row_sumsq_dot_kernel(const TS* __restrict__ M,
