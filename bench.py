@@ -200,6 +200,14 @@ def main():
                              "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s per GPU",
                              "frac": F / (dt / args.steps) * 1e-12 / world / PEAK_FP64_MFMA_TFLOPS,
                              "mfma_engine_ms_per_step": engine_ms},
+            # the K_nm builder is the one HBM-bound kernel of the path: bytes written / its time
+            "roofline_k_builder": {"bound": "hbm", "kernel": "gprhip::cov_cross_kernel",
+                                   "achieved": float(n_local) * m * 8 / (np.mean(tim["p1_cov"]) * 1e-3) * 1e-9
+                                   if "p1_cov" in tim else None,
+                                   "peak": 8000.0, "unit": "GB/s",
+                                   "frac": float(n_local) * m * 8 / (np.mean(tim["p1_cov"]) * 1e-3) * 1e-9 / 8000.0
+                                   if "p1_cov" in tim else None,
+                                   "algorithmic_bytes_per_step": float(n_local) * m * 8},
             "stage_ms": {k_: float(np.mean(v_)) for k_, v_ in sorted(tim.items())},
             "evidence_only": {"value": n * nl_steps / dt_nl, "unit": "training-points/s",
                               "ms_per_step": dt_nl / nl_steps * 1e3, "steps": nl_steps,

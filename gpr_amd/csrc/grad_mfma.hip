@@ -30,19 +30,22 @@ __device__ __forceinline__ double wsum(double v) {
 }
 
 constexpr int G_SLAB = 256;  // must equal grad_slab_rows()
-constexpr int G_RC = 32;     // rows per staged chunk
+constexpr int G_RC = 64;     // rows per staged chunk
 
 // KS4 = ceil(d / 4) k-steps of the distance product, DT = ceil(d / 16) tiles of point dimensions,
 // BT = ceil(D / 16) tiles of original input dimensions (0: no projection hypers)
 template <int KS4, int DT, int BT, typename TS>
-__global__ __launch_bounds__(256) void grad_mfma_kernel(GradArgs<TS> a) {
+__global__ __launch_bounds__(256, (DT + BT <= 4 && KS4 <= 8) ? 2 : 1) void grad_mfma_kernel(GradArgs<TS> a) {
   constexpr int DP = DT * 16, LDP = DP + 1;
   constexpr int BP = BT > 0 ? BT * 16 : 1, LDB = BP + 1;
   __shared__ double ps[G_RC * LDP];
   __shared__ double bs[BT > 0 ? G_RC * LDB : 1];
   __shared__ double pn[G_RC];
   __shared__ double red[4][2];
+  __shared__ double sh[DP];  // the expansion offset, zero-padded
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  if (tid < DP) sh[tid] = (a.shift && tid < a.d) ? a.shift[tid] : 0.0;
+  __syncthreads();
   const int l15 = lane & 15, lq = lane >> 4;
   const int cb = blockIdx.x * 128 + wv * 32;
 
@@ -56,7 +59,7 @@ __global__ __launch_bounds__(256) void grad_mfma_kernel(GradArgs<TS> a) {
 #pragma unroll
     for (int s = 0; s < KS4; ++s) {
       const int k = 4 * s + lq;
-      const double z = (live_c[jt] && k < a.d) ? a.Z[(int64_t)col * a.d + k] - (a.shift ? a.shift[k] : 0.0) : 0.0;
+      const double z = (live_c[jt] && k < a.d) ? a.Z[(int64_t)col * a.d + k] - sh[k] : 0.0;
       zf[jt][s] = z;
       s2 += z * z;
     }
@@ -82,7 +85,7 @@ __global__ __launch_bounds__(256) void grad_mfma_kernel(GradArgs<TS> a) {
     for (int idx = tid; idx < G_RC * DP; idx += 256) {
       const int r = idx / DP, k = idx % DP;
       ps[r * LDP + k] =
-          (k < a.d && rb + r < r1) ? a.pts[(int64_t)(rb + r) * a.d + k] - (a.shift ? a.shift[k] : 0.0) : 0.0;
+          (k < a.d && rb + r < r1) ? a.pts[(int64_t)(rb + r) * a.d + k] - sh[k] : 0.0;
     }
     if (BT > 0) {
       for (int idx = tid; idx < G_RC * BP; idx += 256) {
@@ -97,7 +100,7 @@ __global__ __launch_bounds__(256) void grad_mfma_kernel(GradArgs<TS> a) {
       pn[tid] = s2;
     }
     __syncthreads();
-#pragma unroll
+#pragma unroll 1  // one row tile's worth of registers: two wavefronts per SIMD stay resident
     for (int rt = 0; rt < G_RC / 16; ++rt) {
       if (rb + rt * 16 >= r1) break;
       double xv[2][4];
@@ -159,7 +162,7 @@ __global__ __launch_bounds__(256) void grad_mfma_kernel(GradArgs<TS> a) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int dim = t * 16 + lq + 4 * r;
-        if (dim < a.d) cp[(int64_t)(1 + dim) * a.mp + col] = g[t][jt][r] + (a.shift ? a.shift[dim] * c : 0.0);
+        if (dim < a.d) cp[(int64_t)(1 + dim) * a.mp + col] = g[t][jt][r] + sh[dim] * c;
       }
     if (BT > 0) {
 #pragma unroll
