@@ -65,7 +65,7 @@ def measured_traffic():
     best = None
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_bench*.json"))):
         for r in json.load(open(path)):
-            if r["kernel"].startswith("gprhip::gemm_kernel<double, 2") and (best is None or r["avg_ms"] > best["avg_ms"]):
+            if r["kernel"].startswith("gprhip::gemm_kernel<double, 2, true>") and (best is None or r["avg_ms"] > best["avg_ms"]):
                 best = r
     if best is None:
         return None
@@ -169,13 +169,16 @@ def main():
         ms_per_step = dt / args.steps * 1e3
         value = n * args.steps / dt
         F = algorithmic_flops(n, m, d)
-        # dominant kernel by time per launch: gemm_kernel<OP_TN> -- the two SYRK-shaped accumulations over
-        # the shard's training points (one launch per pass, HIP events on the library's own stream);
-        # algorithmic flops per launch = n_local * m^2 ("SYRK B nm^2", "weighted-SYRK W nm^2")
+        # dominant kernel by time per launch: gprhip::gemm_kernel<double, 2, true> -- the pass-1 SYRK-shaped
+        # accumulation B~ = V^T diag(1/s) V over the shard's training points (one launch per evaluation, timed
+        # with HIP events on the library's own stream; this instantiation is launched nowhere else, so the
+        # rocprofv3 --stats average of that kernel name is directly comparable).  The pass-2 SYRK is the same
+        # kernel without the c~ column sums (<double, 2, false>, a name it shares with the short potrf updates).
+        # Algorithmic flops per launch = n_local * m^2 ("SYRK B nm^2")
         chunk = min(int(os.environ.get("GPRHIP_CHUNK_ROWS", "32768")), hi - lo)
         n_local = hi - lo
-        syrk_ms = (np.mean(tim.get("p1_syrk_B", [0.0])) + np.mean(tim.get("p2_syrk_W", [0.0])))
-        launches = 2
+        syrk_ms = float(np.mean(tim.get("p1_syrk_B", [0.0])))
+        launches = 1
         flops_per_launch = float(n_local) * m * m
         achieved = flops_per_launch / (syrk_ms / launches * 1e-3) * 1e-12 if syrk_ms > 0 else None
         engine_ms = sum(np.mean(tim.get(k_, [0.0])) for k_ in
@@ -189,7 +192,8 @@ def main():
                                    "(BASELINE.json configs[1]); n row-sharded over %d GPU(s)" % (n, m, d, world),
                        "n": n, "m": m, "d": d, "n_hypers": int(ev.grad.shape[0]) + 1,
                        "chunk_rows": chunk},
-            "roofline": {"bound": "mfma", "kernel": "gprhip::gemm_kernel<OP_TN> (SYRK over training points)",
+            "roofline": {"bound": "mfma", "kernel": "gprhip::gemm_kernel<double, 2, true>  (OP_TN: SYRK over training points)",
+                         "launches_per_step": launches,
                          "achieved": achieved, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": (achieved / PEAK_FP64_MFMA_TFLOPS) if achieved else None,
                          "traffic": measured_traffic() if (n, m, d, world) == (1_000_000, 2048, 8, 1) else None,
