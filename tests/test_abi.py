@@ -62,3 +62,14 @@ def test_cpp_mirror_program_is_built_and_links():
     assert os.path.exists(exe), "run `make -C gpr_amd/csrc` (or __graft_entry__.build())"
     out = subprocess.run([exe], capture_output=True, text=True, timeout=60)
     assert out.returncode == 2 and "usage" in out.stderr
+
+
+def test_header_is_plain_c(tmp_path):
+    """include/gprhip.h is the boundary an OCaml stub (C) includes: it must compile as C99 without C++."""
+    import subprocess
+    src = tmp_path / "use.c"
+    src.write_text('#include "gprhip.h"\nint main(void) { gprhip_hypers h; gprhip_result r; (void)h; (void)r; '
+                   'return sizeof(h) + sizeof(r) == 0; }\n')
+    out = subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"),
+                          "-c", str(src), "-o", str(tmp_path / "use.o")], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
