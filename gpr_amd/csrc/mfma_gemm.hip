@@ -287,6 +287,18 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgsT<T> g) {
   const int diag_first = (g.tri == TRI_KHI_BN && k_hi == (bn + 1) * TILE) ? nk - TILE / BK
                          : (g.tri == TRI_KLO_BN && k_lo == bn * TILE) ? 0 : -(1 << 30);
   const int cj0 = wc;  // first owned column sub-tile; sub-tile j of this wave is 2j + wc
+  // Diagonal tile of an upper_only (SYRK-shaped) launch: only the 16x16 sub-tiles on or above the diagonal are
+  // consumed (row sub-tile 4*wr + i <= column sub-tile wc + 2j); the others are not computed.  Bit i*4+j.
+  unsigned sub_live = 0xFFFFu;
+  // (not in the column-sum variant: measured slower there, its diagonal blocks already carry the extra sums)
+  if (!CS && g.upper_only && bm == bn) {
+    sub_live = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (4 * wr + i <= wc + 2 * j) sub_live |= 1u << (i * 4 + j);
+  }
   auto compute = [&](int stage, int t) {
     const T* As = smem + stage * 2 * STAGE;
     const T* Bs = As + STAGE;
@@ -296,7 +308,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgsT<T> g) {
       if (g.tri == TRI_KHI_BN) jlo = (BK * u) / 16; else jhi = (BK * u + BK - 1) / 16;
     }
     if (jlo > cj0 + 6 || jhi < cj0) return;
-    if (jlo <= cj0 && jhi >= cj0 + 6) {
+    if (jlo <= cj0 && jhi >= cj0 + 6 && sub_live == 0xFFFFu) {
       // every sub-tile live: the common case, one straight MFMA stream
 #pragma unroll
       for (int kk = 0; kk < BK / 4; ++kk) {
@@ -325,7 +337,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgsT<T> g) {
         if (cj0 + 2 * j >= jlo && cj0 + 2 * j <= jhi) {
 #pragma unroll
           for (int i = 0; i < 4; ++i)
-            acc[i][j] = G::mfma(af[i], bf[j], acc[i][j]);
+            if (sub_live >> (i * 4 + j) & 1u) acc[i][j] = G::mfma(af[i], bf[j], acc[i][j]);
         }
       }
     }
