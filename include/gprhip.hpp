@@ -309,7 +309,18 @@ struct Make_deriv {
     MatP inducing;
   };
   struct Variances_t { Vec variances; double sigma2; };
-  struct Covariances_t { MatP points; Mat covariances; double sigma2; };
+  struct Covariances_t { MatP points; Mat covariances; double sigma2; std::shared_ptr<Problem> problem; };
+  // Mean_predictor.t / Co_variance_predictor.t built from stored numbers (lib/fitc_gp.ml:377-391, :429-447) rather
+  // than from a model on the device -- the `test` flow of bin/ocaml_gpr.ml:373-413.  The device problem that serves
+  // it is created on first use, sized for the batch it is asked about.
+  struct Standalone_t {
+    MatP inducing;
+    std::optional<Vec> coeffs;
+    std::optional<Kernel> kernel;
+    std::optional<std::pair<Mat, Mat>> cov_coeffs;  // (chol_km, r_mat)
+    std::shared_ptr<std::shared_ptr<Problem>> prob = std::make_shared<std::shared_ptr<Problem>>();
+  };
+  struct Cov_sampler_t { Vec means; Covariances_t covariances; double add_diag; };
 
   // one evaluation on the device: multim_f / multim_dcommon, lib/fitc_gp.ml:1601-1636
   static Evaluation run(const Model_t& model, const Vec* targets, bool want_grad, std::shared_ptr<const void> owner) {
@@ -482,7 +493,67 @@ struct Make_deriv {
       Model::ensure_state(m);
       return *m.inputs.problem;
     }
+    static Problem& problem_for(const Standalone_t& sa, const Inputs_t& in, const char* who, double sigma2 = 0.0) {
+      if (in.inducing.points != sa.inducing)
+        throw Failure(GPRHIP_EBADARG, std::string(who) + ": predictor and inputs disagree about inducing points");
+      const Kernel& k = sa.kernel ? *sa.kernel : in.inducing.kernel;
+      const Mat& pts = *in.points;
+      std::shared_ptr<Problem>& prob = *sa.prob;
+      if (!prob || prob->D != pts.rows || prob->n < pts.cols)
+        prob = std::make_shared<Problem>(Spec::cov_kind, std::max(pts.cols, 1024), pts.rows, sa.inducing->rows,
+                                         sa.inducing->cols);
+      gprhip_hypers h{};
+      Spec::fill(k, h);
+      h.sigma2 = sigma2;
+      h.inducing = sa.inducing->data();
+      h.jitter = cholesky_jitter;
+      check(gprhip_load_predictor(prob->get(), &h, sa.coeffs ? sa.coeffs->data() : nullptr,
+                                  sa.cov_coeffs ? sa.cov_coeffs->first.data() : nullptr,
+                                  sa.cov_coeffs ? sa.cov_coeffs->second.data() : nullptr));
+      prob->state_owner = sa.prob;
+      return *prob;
+    }
+    static Problem& problem_of(const Trained_t& t, const Inputs_t& in, const char* who, double) {
+      return problem_for(t, in, who);
+    }
+    static Problem& problem_of(const Model_t& m, const Inputs_t& in, const char* who, double) {
+      return problem_for(m, in, who);
+    }
+    static Problem& problem_of(const Standalone_t& sa, const Inputs_t& in, const char* who, double sigma2) {
+      return problem_for(sa, in, who, sigma2);
+    }
+    static std::shared_ptr<Problem> owner_problem(const Trained_t& t) { return t.model.inputs.problem; }
+    static std::shared_ptr<Problem> owner_problem(const Model_t& m) { return m.inputs.problem; }
+    static std::shared_ptr<Problem> owner_problem(const Standalone_t& sa) { return *sa.prob; }
+    struct Mean_predictor {
+      static const Trained_t& calc_trained(const Trained_t& t) { return t; }  // :380-384
+      static Standalone_t calc(MatP inducing_points, const Vec& coeffs) {     // :386-391
+        if ((size_t)inducing_points->cols != coeffs.size())
+          throw Failure(GPRHIP_EBADARG, "Mean_predictor.calc: number of inducing points disagrees with dimension of "
+                                        "coefficients");
+        Standalone_t sa;
+        sa.inducing = std::move(inducing_points);
+        sa.coeffs = coeffs;
+        return sa;
+      }
+    };
+    struct Co_variance_predictor {
+      static const Model_t& calc_model(const Model_t& m) { return m; }        // :438-444
+      static Standalone_t calc(const Kernel& kernel, MatP inducing_points, const std::pair<Mat, Mat>& coeffs) {  // :446-447
+        Standalone_t sa;
+        sa.inducing = std::move(inducing_points);
+        sa.kernel = kernel;
+        sa.cov_coeffs = coeffs;
+        return sa;
+      }
+    };
     struct Means {
+      static Vec calc(const Standalone_t& mean_predictor, const Inputs_t& in) {
+        Problem& p = problem_for(mean_predictor, in, "Means.calc");
+        Vec means((size_t)in.points->cols);
+        check(gprhip_predict(p.get(), in.points->data(), in.points->rows, in.points->cols, 0, means.data(), nullptr));
+        return means;
+      }
       static Vec calc(const Trained_t& mean_predictor, const Inputs_t& in) {  // :418-425
         Problem& p = problem_for(mean_predictor, in, "Means.calc");
         Vec means((size_t)in.points->cols);
@@ -493,7 +564,7 @@ struct Make_deriv {
     struct Variances {
       template <class Owner>
       static Variances_t calc(const Owner& cvp, double sigma2, const Inputs_t& in) {  // :498-518
-        Problem& p = problem_for(cvp, in, "Variances.calc");
+        Problem& p = problem_of(cvp, in, "Variances.calc", sigma2);
         Variances_t v{Vec((size_t)in.points->cols), sigma2};
         check(gprhip_predict(p.get(), in.points->data(), in.points->rows, in.points->cols, 0, nullptr,
                              v.variances.data()));
@@ -509,8 +580,9 @@ struct Make_deriv {
     struct Covariances {  // FITC_covariances / FIC_covariances, :565-627
       template <class Owner>
       static Covariances_t calc(const Owner& cvp, double sigma2, const Inputs_t& in) {
-        Problem& p = problem_for(cvp, in, CovKind ? "FIC_covariances.calc" : "FITC_covariances.calc");
-        Covariances_t c{in.points, Mat(in.points->cols, in.points->cols), sigma2};
+        Problem& p = problem_of(cvp, in, CovKind ? "FIC_covariances.calc" : "FITC_covariances.calc", sigma2);
+        Covariances_t c{in.points, Mat(in.points->cols, in.points->cols), sigma2,
+                        owner_problem(cvp)};
         check(gprhip_covariances(p.get(), in.points->data(), in.points->rows, in.points->cols, CovKind, 0,
                                  c.covariances.data()));
         return c;
@@ -519,6 +591,24 @@ struct Make_deriv {
         Mat out = c.covariances;
         if (predictive)
           for (int i = 0; i < out.rows; ++i) out(i, i) += c.sigma2;
+        return out;
+      }
+    };
+    struct Cov_sampler {  // Common_cov_sampler, lib/fitc_gp.ml:656-697; the standard normal draws z are the caller's
+      static Cov_sampler_t calc(const Vec& means, const Covariances_t& cov, bool predictive = true) {  // :659-675
+        if ((int)means.size() != cov.covariances.rows)
+          throw Failure(GPRHIP_EBADARG, "Cov_sampler: means and covariances disagree about input points");
+        Cov_sampler_t s{means, cov, predictive ? cov.sigma2 : 0.0};
+        Mat z0(cov.covariances.rows, 1);
+        (void)samples(s, z0);  // factor now: a potrf failure surfaces in calc, as in the reference
+        return s;
+      }
+      static Mat samples(const Cov_sampler_t& s, const Mat& z) {  // :685-697: means + cov_chol^T z, per column
+        const int nt = s.covariances.covariances.rows;
+        if (z.rows != nt) throw Failure(GPRHIP_EBADARG, "Cov_sampler.samples: z has the wrong number of rows");
+        Mat out(nt, z.cols);
+        check(gprhip_cov_samples(s.covariances.problem->get(), s.covariances.covariances.data(), nt, nt, s.add_diag,
+                                 cholesky_jitter, s.means.data(), z.data(), z.cols, out.data()));
         return out;
       }
     };

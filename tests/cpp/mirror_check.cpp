@@ -86,6 +86,23 @@ static void exercise(const Dump& dm, const typename Spec::Kernel& kernel) {
   auto cc = V::Model::calc_co_variance_coeffs(model);
   put("chol_km", cc.first.a);
   put("r_mat", cc.second.a);
+  if (dm.nt > 0) {
+    // predictors rebuilt from stored numbers alone (the `test` flow of bin/ocaml_gpr.ml:373-413) and the sampler
+    auto tin = V::Inputs::calc(inducing, Xt, /*train=*/false);
+    auto mp = V::Mean_predictor::calc(Z, V::Trained::calc_mean_coeffs(trained));
+    put("standalone_means", V::Means::calc(mp, tin));
+    auto cvp = V::Co_variance_predictor::calc(kernel, Z, cc);
+    put("standalone_variances", V::Variances::get(V::Variances::calc(cvp, dm.sigma2, tin), false));
+    // sampler on the FITC covariances (FIC_covariances.calc as the reference writes it need not be positive definite)
+    auto cov = GP::FITC::Covariances::calc(model, dm.sigma2, tin);
+    auto smp = V::Cov_sampler::calc(V::Means::calc(trained, tin), cov, true);
+    Mat z((int)dm.nt, 2);
+    for (int i = 0; i < (int)dm.nt; ++i) {
+      z(i, 0) = std::sin(1.0 + i);
+      z(i, 1) = std::cos(2.0 * i);
+    }
+    put("samples", V::Cov_sampler::samples(smp, z).a);
+  }
   // update_sigma2 keeps K_nm, V, r on the device
   auto model2 = V::Model::update_sigma2(model, 2.0 * dm.sigma2);
   put("l_sigma2x2", V::Trained::calc_log_evidence(V::Trained::calc(model2, dm.y)));
@@ -113,7 +130,6 @@ static void exercise(const Dump& dm, const typename Spec::Kernel& kernel) {
     dim = std::string(e.what()).find("Vec.dim targets") != std::string::npos;
   }
   put("error_checks", Vec{neg, dim});
-  (void)sizeof(GP);
 }
 
 int main(int argc, char** argv) {

@@ -843,6 +843,12 @@ def test_cpp_host_mirror(tmp_path, name):
     assert relinf(np.triu(res["r_mat"].reshape(m, m).T), np.triu(ref["model"]["r_mat"])) <= 1e-9
     ref2 = O.evaluate(k, g["Z"], g["X"], g["y"], 2 * s2, variational=variational, want_grad=False)
     assert abs(res["l_sigma2x2"][0] - ref2["l"]) <= TOL_L * abs(ref2["l"])
+    mean_ref = O.predict_means(k, g["Z"], ref["coeffs"], Xt)
+    assert relinf(res["standalone_means"], mean_ref) <= 1e-8
+    assert relinf(res["standalone_variances"], var) <= 1e-8
+    zz = np.stack([np.sin(1.0 + np.arange(nt)), np.cos(2.0 * np.arange(nt))], axis=1)
+    smp = O.cov_sampler_calc(mean_ref, O.fitc_covariances(k, g["Z"], ref["model"], Xt), s2, predictive=True)
+    assert relinf(res["samples"].reshape(2, nt).T, O.cov_sampler_samples(smp, zz)) <= 1e-8
     assert res["phys_equal_check"][0] == 1.0 and res["self_test"][0] == 1.0
     assert np.array_equal(res["error_checks"], [1.0, 1.0])
 
