@@ -925,3 +925,18 @@ def test_inputs_with_a_large_common_offset():
     p.close()
     assert abs(ev.l - ref["l"]) <= TOL_L * abs(ref["l"])
     assert relinf(ev.grad, ref["grad"]) <= TOL_GRAD
+
+
+def test_zero_noise_is_accepted_like_the_reference():
+    """Model.check_sigma2 only rejects sigma2 < 0 (lib/fitc_gp.ml:148-149): sigma2 = 0 leaves s = r, which the
+    Cholesky jitter keeps positive.  Parity with the oracle at that corner (looser: s spans many decades)."""
+    n, m, d = 800, 25, 2
+    X, y, Z = synth(37, n, m, d)
+    ref = O.evaluate_fast(O.SeIsoKernel(0.1, 0.0), Z, X, y, 0.0)
+    p = gpr_amd.Problem(gpr_amd.COV_SE_ISO, n, d, d, m)
+    p.set_inputs(X)
+    p.set_targets(y)
+    ev = p.eval(log_ell=0.1, log_sf2=0.0, sigma2=0.0, inducing=Z)
+    p.close()
+    assert np.isfinite(ev.l) and abs(ev.l - ref["l"]) <= 1e-7 * abs(ref["l"])
+    assert relinf(ev.grad, ref["grad"]) <= 1e-5
