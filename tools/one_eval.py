@@ -8,7 +8,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import gpr_amd  # noqa: E402
 from bench import synth  # noqa: E402
 
-n, m, d = 16384, 2048, 8
+n, m, d = int(os.environ.get("N", 16384)), 2048, 8
 X, y, Z = synth(2, n, m, d)
 p = gpr_amd.Problem(gpr_amd.COV_SE_ISO, n, d, d, m)
 p.set_inputs(X)
