@@ -93,6 +93,10 @@ void launch_build_w(const double* binv, const double* t, const double* G, int mp
 //   part[slab][2+k][c] = sum_r W_rc K_rc (z_kr - z_kc)        -> `Sparse_rows trace / (2*scale)
 // W and K_m are full symmetric here, so the reference's upper-triangle bookkeeping
 // (lib/utils.ml:196-220: 2*sum_{r != c} + diagonal) becomes a plain column sum.
+// rows of W .* K_m one block walks: short slabs, so that the m x m pass spreads over the whole chip
+constexpr int KM_SLAB = 32;
+int km_slab_rows() { return KM_SLAB; }
+
 template <int DT>
 __global__ __launch_bounds__(256) void km_traces_kernel(const double* __restrict__ W,
                                                         const double* __restrict__ km,
@@ -108,7 +112,7 @@ __global__ __launch_bounds__(256) void km_traces_kernel(const double* __restrict
     g[k] = 0.0;
   }
   double s0 = 0.0, s1 = 0.0;
-  const int r0 = blockIdx.y * 256, r1 = min(m, r0 + 256);
+  const int r0 = blockIdx.y * KM_SLAB, r1 = min(m, r0 + KM_SLAB);
   if (live) {
     for (int r = r0; r < r1; ++r) {
       // upper tiles of km are the valid ones; km is written full by cov_upper, W full by build_w
@@ -153,7 +157,7 @@ __global__ __launch_bounds__(256) void km_traces_ms_kernel(const double* __restr
     gm[k] = 0.0;
   }
   double s0 = 0.0;
-  const int r0 = blockIdx.y * 256, r1 = min(m, r0 + 256);
+  const int r0 = blockIdx.y * KM_SLAB, r1 = min(m, r0 + KM_SLAB);
   if (live) {
     for (int r = r0; r < r1; ++r) {
       const double wk = W[(int64_t)r * mp + c] * km[(int64_t)r * mp + c];
@@ -186,7 +190,7 @@ __global__ __launch_bounds__(256) void km_traces_ms_kernel(const double* __restr
 
 void launch_km_traces_ms(const double* W, const double* km, const double* Z, const double* ms, int m, int mp,
                          int d, double* part, hipStream_t s) {
-  dim3 grid((mp + 255) / 256, (m + 255) / 256);
+  dim3 grid((mp + 255) / 256, (m + KM_SLAB - 1) / KM_SLAB);
   auto go = [&](auto dt) {
     hipLaunchKernelGGL((km_traces_ms_kernel<decltype(dt)::value>), grid, dim3(256), 0, s, W, km, Z, ms, m, mp,
                        d, part);
@@ -201,7 +205,7 @@ void launch_km_traces_ms(const double* W, const double* km, const double* Z, con
 
 void launch_km_traces(const double* W, const double* km, const double* Z, int m, int mp, int d,
                       double* part, double* /*unused*/, hipStream_t s) {
-  dim3 grid((mp + 255) / 256, (m + 255) / 256);
+  dim3 grid((mp + 255) / 256, (m + KM_SLAB - 1) / KM_SLAB);
   auto go = [&](auto dt) {
     hipLaunchKernelGGL((km_traces_kernel<decltype(dt)::value>), grid, dim3(256), 0, s, W, km, Z, m, mp,
                        d, part);

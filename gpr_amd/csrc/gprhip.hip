@@ -645,7 +645,7 @@ void do_finish(gprhip_problem* p, const double* ar2, gprhip_result* res, double*
   const double* ar2_col = ar2 + mm;
   const double* ar2_proj = ar2_col + p->col_rows() * mp;
   const double* ar2_tail = ar2_proj + (int64_t)p->dbig() * d;
-  const int nkslab = (m + 255) / 256;
+  const int nkslab = (m + km_slab_rows() - 1) / km_slab_rows();
   if (p->want_grad) {
     tstart(p, "finish");
     launch_build_w(p->binv, p->ttil, ar2, mp, p->wtil, s);
@@ -1236,7 +1236,7 @@ int gprhip_problem_create_ex(int device, int cov_kind, int precision, int64_t n,
     p->colpart = p->alloc<double>(nslab * p->col_rows() * mp);
     p->scalpart = p->alloc<double>(nslab * (mp / TILE) * 2);
     p->zshift = p->alloc<double>(64);
-    p->kmpart = p->alloc<double>((int64_t)((m + 255) / 256) * p->km_rows() * mp);
+    p->kmpart = p->alloc<double>((int64_t)((m + km_slab_rows() - 1) / km_slab_rows()) * p->km_rows() * mp);
     p->kmred = p->alloc<double>(p->km_rows() * mp);
     p->ar1 = p->alloc<double>(mm + mp + A1_TAIL);
     p->ar2 = p->alloc<double>(gprhip_ar2_len(p));
