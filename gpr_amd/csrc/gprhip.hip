@@ -300,7 +300,18 @@ void triu_xxt(gprhip_problem* p, const double* X, double* C) {
   GemmArgs g;
   g.A = X; g.lda = p->mp; g.B = X; g.ldb = p->mp; g.C = C; g.ldc = p->mp;
   g.M = p->mp; g.N = p->mp; g.K = p->mp; g.tri = TRI_KLO_MAX; g.upper_only = 1;
-  launch_gemm(OP_NT, g, p->stream);
+  // few tiles, long triangular k-ranges: four k-slices (ending on block boundaries) fill the chip
+  const int64_t mm = (int64_t)p->mp * p->mp;
+  const int ks = (p->mp >= 1024 && 4 * mm * 8 <= p->slices_bytes) ? 4 : 1;
+  if (ks > 1) {
+    g.C = static_cast<double*>(p->slices);
+    g.kslices = ks;
+    g.slice_stride = mm;
+    launch_gemm(OP_NT, g, p->stream);
+    launch_sum_slices<double>(nullptr, static_cast<double*>(p->slices), ks, mm, p->mp, C, p->stream);
+  } else {
+    launch_gemm(OP_NT, g, p->stream);
+  }
 }
 
 void upload_hypers(gprhip_problem* p, const gprhip_hypers* h) {
