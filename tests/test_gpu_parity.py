@@ -940,3 +940,36 @@ def test_zero_noise_is_accepted_like_the_reference():
     p.close()
     assert np.isfinite(ev.l) and abs(ev.l - ref["l"]) <= 1e-7 * abs(ref["l"])
     assert relinf(ev.grad, ref["grad"]) <= 1e-5
+
+
+@pytest.mark.parametrize("d", [12, 20, 40])
+def test_wide_point_dimensions(d):
+    """Point dimensions 12 / 20 / 40 select the 16-, 32- and 64-wide instantiations of the covariance kernels and the
+    (k-steps, dimension-tile) variants of the matrix-core gradient kernel; Cov_se_fat with a full D x d projection
+    (D = d + 3) adds the projection-gradient tiles."""
+    n, m = 1500, 70
+    X, y, Z = synth(41, n, m, d)
+    le = 0.5 * np.log(d)
+    ref = O.evaluate_fast(O.SeIsoKernel(le, 0.1), Z, X, y, 0.2)
+    p = gpr_amd.Problem(gpr_amd.COV_SE_ISO, n, d, d, m)
+    p.set_inputs(X)
+    p.set_targets(y)
+    ev = p.eval(log_ell=le, log_sf2=0.1, sigma2=0.2, inducing=Z)
+    p.close()
+    assert abs(ev.l - ref["l"]) <= TOL_L * abs(ref["l"])
+    assert relinf(ev.grad, ref["grad"]) <= TOL_GRAD
+    rng = np.random.default_rng(d)
+    D = d + 3
+    Xb = np.asfortranarray(rng.normal(size=(D, n)))
+    P = np.asfortranarray(rng.normal(size=(D, d)) / np.sqrt(D * d))
+    kf = O.SeFatKernel(d, 0.1, P)
+    Zf = np.asfortranarray(O.se_fat_project(kf, Xb[:, :m]) + 0.01 * rng.normal(size=(d, m)))
+    yb = np.sin(Xb.sum(0)) + 0.1 * rng.normal(size=n)
+    reff = O.evaluate_fast(kf, Zf, Xb, yb, 0.2)
+    q = gpr_amd.Problem(gpr_amd.COV_SE_FAT, n, D, d, m)
+    q.set_inputs(Xb)
+    q.set_targets(yb)
+    evf = q.eval(log_sf2=0.1, sigma2=0.2, inducing=Zf, tproj=P)
+    q.close()
+    assert abs(evf.l - reff["l"]) <= TOL_L * abs(reff["l"])
+    assert evf.grad.shape == reff["grad"].shape and relinf(evf.grad, reff["grad"]) <= TOL_GRAD
