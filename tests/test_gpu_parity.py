@@ -973,3 +973,30 @@ def test_wide_point_dimensions(d):
     q.close()
     assert abs(evf.l - reff["l"]) <= TOL_L * abs(reff["l"])
     assert evf.grad.shape == reff["grad"].shape and relinf(evf.grad, reff["grad"]) <= TOL_GRAD
+
+
+def test_fp32_bulk_posterior_paths():
+    """Prediction, training-set statistics and covariances on a problem created in the fp32-bulk mode (the n x m
+    work of prediction and statistics runs in fp32 there; covariances are always fp64), against the fp64 oracle
+    within the fp32 tolerances."""
+    n, m, d, nt = 4000, 120, 3, 500
+    X, y, Z = synth(43, n, m, d)
+    Xt = np.asfortranarray(np.random.default_rng(2).normal(size=(d, nt)))
+    k = O.SeIsoKernel(0.4, 0.1)
+    ref = O.evaluate(k, Z, X, y, 0.2, want_grad=False, keep=True)
+    p = gpr_amd.Problem(gpr_amd.COV_SE_ISO, n, d, d, m, precision=gpr_amd.F32_BULK, chunk_rows=1024)
+    p.set_inputs(X)
+    p.set_targets(y)
+    ev = p.eval(log_ell=0.4, log_sf2=0.1, sigma2=0.2, inducing=Z, want_grad=False)
+    assert abs(ev.l - ref["l"]) <= TOL32_L * abs(ref["l"])
+    mean, var = p.predict(Xt, predictive=False)
+    assert relinf(mean, O.predict_means(k, Z, ref["coeffs"], Xt)) <= TOL32_COEFF
+    vref = O.predict_variances(k, Z, ref["model"], Xt, predictive=False)
+    assert np.max(np.abs(var - vref)) <= 1e-3 * np.max(np.abs(vref))
+    sums, tm = p.train_stats(want_means=True)
+    knm, _ = O.spec_calc_shared_cross(k, X, Z)
+    assert relinf(tm, knm @ ref["coeffs"]) <= TOL32_COEFF
+    cov = p.covariances(Xt[:, :64], kind="FITC")
+    cref = O.fitc_covariances(k, Z, ref["model"], Xt[:, :64])
+    assert np.max(np.abs(np.triu(cov) - cref)) <= 1e-3 * np.max(np.abs(cref))
+    p.close()
