@@ -95,7 +95,7 @@ struct gprhip_problem {
   double *r = nullptr, *is = nullptr, *yis = nullptr, *w = nullptr, *v = nullptr, *es = nullptr;
   double* projpart = nullptr;
   double* zshift = nullptr;  // [64] centroid of the inducing points (gradient kernel's expansion offset)
-  double *rp1 = nullptr, *rp2 = nullptr;  // per-row partial sums from the GEMM epilogues [chunk][2*mp/128]
+  double *rp1 = nullptr, *rp2 = nullptr;  // per-row partial sums from the GEMM epilogues [parts*mp/128][chunk]
   double *xt = nullptr, *pt = nullptr, *prow = nullptr;  // prediction: test-point chunk, its projection, 3 row vectors
   bool have_model = false;
   bool have_factors = false;  // U^-1 / R~^-1 valid (false after a means-only gprhip_load_predictor)
@@ -485,7 +485,7 @@ void do_pass1(gprhip_problem* p, const gprhip_hypers* h, int want_grad, int64_t 
     }
     tstart(p, "p1_rows");
     Pass1RowArgs ra;
-    ra.part = reuse ? nullptr : p->rp1; ra.npart = 2 * (mp / TILE); ra.ld = rows_p;
+    ra.part = reuse ? nullptr : p->rp1; ra.npart = gemm_row_parts_per_tile() * (mp / TILE); ra.ld = rows_p;
     ra.y = h->model_only ? nullptr : p->y + base; ra.rows = (int)rows;
     ra.sf2 = p->cp.sf2; ra.sigma2 = h->sigma2;
     ra.r = p->r + base; ra.is = p->is + base; ra.yis = p->yis + base; ra.partial = p->rowpart;
@@ -567,7 +567,7 @@ void do_pass2(gprhip_problem* p, const double* ar1, double* ar2) {
       tstop(p);
       tstart(p, "p2_rows");
       Pass2RowArgs ra;
-      ra.part_sq = p->rp1; ra.part_dot = p->rp2; ra.npart = 2 * (mp / TILE); ra.ld = rows_p;
+      ra.part_sq = p->rp1; ra.part_dot = p->rp2; ra.npart = gemm_row_parts_per_tile() * (mp / TILE); ra.ld = rows_p;
       ra.y = mo ? nullptr : p->y + base; ra.is = p->is + base; ra.r = p->r + base;
       ra.rows = (int)rows; ra.variational = p->h.variational;
       ra.sf2 = p->cp.sf2; ra.es = proj ? p->es + base : nullptr;
@@ -1233,7 +1233,7 @@ int gprhip_problem_create_ex(int device, int cov_kind, int precision, int64_t n,
       p->es = p->alloc<double>(npad);
       p->projpart = p->alloc<double>(((chunk + 255) / 256) * (int64_t)D * d);
     }
-    p->rp1 = p->alloc<double>(chunk * 2 * (mp / TILE)); p->rp2 = p->alloc<double>(chunk * 2 * (mp / TILE));
+    p->rp1 = p->alloc<double>(chunk * 4 * (mp / TILE)); p->rp2 = p->alloc<double>(chunk * 4 * (mp / TILE));
     p->bufA = p->alloc<char>(chunk * mp * p->esz); p->bufB = p->alloc<char>(chunk * mp * p->esz);
     if (p->f32) {
       p->uinv_f = p->alloc<float>(mm);

@@ -56,7 +56,8 @@ struct GemmArgsT {
   const T* epi_mat = nullptr;
   int64_t epi_ldm = 0;
   // optional per-row reductions of the result tile, fused into the plain-store epilogue:
-  //   rp_sumsq[(2*bn + wc) * M + row] = sum of C[row][c]^2 over the 64 columns wave column wc owns in tile bn
+  //   rp_sumsq[(P*bn + wc) * M + row] = sum of C[row][c]^2 over the columns wave column wc owns in tile bn,
+  //   P = gemm_row_parts_per_tile() wave columns per tile
   //   rp_dot  [same index]            = sum of C[row][c] * rp_vec[c] over the same columns
   // (part-major: the 64 lanes of a wavefront write 64 consecutive rows)
   // (diag(Q_nn)-type row quantities without re-reading the n x m result: lib/fitc_gp.ml:222-223, :1048, :1164)
@@ -68,6 +69,7 @@ struct GemmArgsT {
   double* rp_sumsq = nullptr;
   double* rp_dot = nullptr;
   const double* rp_vec = nullptr;
+  int lab_noadvance = 0;  // tools/gemm_check.hip only: timing ablation, results are meaningless
 };
 using GemmArgs = GemmArgsT<double>;
 using GemmArgsF = GemmArgsT<float>;
@@ -76,7 +78,10 @@ using GemmArgsF = GemmArgsT<float>;
 void launch_gemm(GemmOp op, const GemmArgs& g, hipStream_t stream);
 void launch_gemm(GemmOp op, const GemmArgsF& g, hipStream_t stream);
 
-// One-time per-process setup (raises the dynamic-LDS limit of the kernels).
+// Partial row sums the fused row reductions emit per 128-column tile (= wave columns of the engine geometry).
+int gemm_row_parts_per_tile();
+
+// One-time per-process setup (raises the dynamic-LDS limit of the kernels; fixes the engine geometry).
 void gemm_init();
 
 }  // namespace gprhip

@@ -71,7 +71,7 @@ void timeit(GemmOp op, int M, int N, int K, int tri, int upper, int kslices, con
   hipMemset(dC, 0, (int64_t)M * N * 8 * std::max(1, kslices));
   double* dS = nullptr; if (scale) { hipMalloc(&dS, (int64_t)K * 8); hipMemcpy(dS, h.data(), (int64_t)K * 8, hipMemcpyHostToDevice); }
   GemmArgs g; g.scale_k = dS; g.A = dA; g.lda = ac; g.B = dB; g.ldb = bc; g.C = dC; g.ldc = N; g.M = M; g.N = N; g.K = K;
-  g.tri = tri; g.upper_only = upper; g.kslices = kslices; g.order = getenv("ORD") ? atoi(getenv("ORD")) : 0; g.slice_stride = (int64_t)M * N; g.beta = kslices > 1 ? 1.0 : 0.0;
+  g.tri = tri; g.upper_only = upper; g.kslices = kslices; g.order = getenv("ORD") ? atoi(getenv("ORD")) : 0; g.slice_stride = (int64_t)M * N; g.lab_noadvance = getenv("NOADV") ? 1 : 0;
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   for (int i = 0; i < 2; ++i) launch_gemm(op, g, 0);
   hipEventRecord(e0, 0);
@@ -161,8 +161,62 @@ void timeit_f32(GemmOp op, int M, int N, int K, int tri, int upper, int kslices,
   hipFree(dA); hipFree(dB); hipFree(dC);
 }
 
+
+// Register-only MFMA stream: the matrix-pipe ceiling at the clock the chip sustains under this load
+// (no LDS, no global traffic).  16 independent accumulators per wavefront, 4 wavefronts per block.
+typedef double d4_t __attribute__((ext_vector_type(4)));
+template <int WPS>
+__global__ __launch_bounds__(256, WPS) void mfma_peak_kernel(double* out, int iters, double a0, double b0) {
+  d4_t acc[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) acc[i] = (d4_t){0, 0, 0, 0};
+  double a = a0 + threadIdx.x * 1e-9, b = b0 - threadIdx.x * 1e-9;
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i & 7] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i & 7], 0, 0, 0);
+  }
+  double s = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+  if (s == 12345.678) out[0] = s;
+}
+template <int WPS>
+void peak(int blocks_per_cu, const char* name) {
+  double* d; hipMalloc(&d, 8);
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  const int iters = 20000;  // 20000 x 16 MFMA x 64 cyc = 20.5 M cycles per wave alone
+  const int grid = 256 * blocks_per_cu;
+  hipLaunchKernelGGL(mfma_peak_kernel<WPS>, dim3(grid), dim3(256), 0, 0, d, 2000, 1.0, 1.0);
+  hipEventRecord(e0, 0);
+  hipLaunchKernelGGL(mfma_peak_kernel<WPS>, dim3(grid), dim3(256), 0, 0, d, iters, 1.0, 1.0);
+  hipEventRecord(e1, 0); hipEventSynchronize(e1);
+  float ms; hipEventElapsedTime(&ms, e0, e1);
+  double flops = (double)grid * 4 * iters * 16 * 2048.0;
+  printf("peak %-20s grid=%d : %.3f ms  %.1f TFLOP/s\n", name, grid, ms, flops / ms * 1e-9);
+  hipFree(d);
+}
+
 int main() {
+  setvbuf(stdout, nullptr, _IOLBF, 0);
   gemm_init();
+  if (getenv("PEAK")) {
+    peak<1>(1, "1 wave/SIMD");
+    peak<2>(2, "2 waves/SIMD");
+    peak<3>(3, "3 waves/SIMD");
+    peak<4>(4, "4 waves/SIMD");
+    return 0;
+  }
+  if (getenv("LAB")) {
+    for (int rep = 0; rep < 2; ++rep) {
+      timeit(OP_NN, 4096, 4096, 4096, TRI_NONE, 0, 1, "square NN 4096");
+      timeit(OP_NN, 8192, 8192, 8192, TRI_NONE, 0, 1, "square NN 8192");
+      timeit(OP_NN, 16384, 16384, 16384, TRI_NONE, 0, 1, "square NN 16384");
+      timeit(OP_NN, 32768, 2048, 2048, TRI_KHI_BN, 0, 1, "K*Uinv triu");
+      timeit(OP_NT, 32768, 2048, 2048, TRI_KLO_BN, 0, 1, "V*Uinv^T triu");
+      timeit(OP_TN, 2048, 2048, 1000064, TRI_NONE, 1, 256, "syrk upper K=1M ks256 scaled", true);
+    }
+    return 0;
+  }
   if (getenv("F32")) {
     int bad = 0;
     bad += check_f32(OP_NN, 256, 256, 64, TRI_NONE, false, false);
