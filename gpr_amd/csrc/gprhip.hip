@@ -102,6 +102,7 @@ struct gprhip_problem {
   // n x m storage: double, or float in the fp32-bulk mode (element size `esz`)
   void *bufA = nullptr, *bufB = nullptr, *Vstore = nullptr;
   float *uinv_f = nullptr, *rinv_f = nullptr;  // fp32 copies of U^-1 / R~^-1 (fp32-bulk mode)
+  float *is_f = nullptr, *yis_f = nullptr, *v_f = nullptr;  // fp32 copies of the SYRK row weights (fp32-bulk mode)
   int f32 = 0;
   size_t esz = 8;
   void* slices = nullptr;
@@ -158,6 +159,13 @@ namespace {
 template <typename TS> const TS* inv_u(const gprhip_problem* p);
 template <> const double* inv_u<double>(const gprhip_problem* p) { return p->uinv; }
 template <> const float* inv_u<float>(const gprhip_problem* p) { return p->uinv_f; }
+// per-row weights of the SYRK-shaped launches in the engine's element type
+template <typename TS> const TS* row_weights(gprhip_problem* p, const double* w, float* wf);
+template <> const double* row_weights<double>(gprhip_problem*, const double* w, float*) { return w; }
+template <> const float* row_weights<float>(gprhip_problem* p, const double* w, float* wf) {
+  launch_to_float(w, wf, (int64_t)p->nchunks * p->chunk, p->stream);
+  return wf;
+}
 template <typename TS> const TS* inv_r(const gprhip_problem* p);
 template <> const double* inv_r<double>(const gprhip_problem* p) { return p->rinv; }
 template <> const float* inv_r<float>(const gprhip_problem* p) { return p->rinv_f; }
@@ -500,10 +508,10 @@ void do_pass1(gprhip_problem* p, const gprhip_hypers* h, int want_grad, int64_t 
   tstart(p, "p1_syrk_B");
   GemmArgsT<TS> b;
   b.A = Vstore; b.lda = mp; b.B = Vstore; b.ldb = mp; b.C = slices; b.ldc = mp;
-  b.M = mp; b.N = mp; b.K = (int)ktot; b.beta = 0.0; b.scale_k = p->is; b.upper_only = 1;
+  b.M = mp; b.N = mp; b.K = (int)ktot; b.beta = 0.0; b.scale_k = row_weights<TS>(p, p->is, p->is_f); b.upper_only = 1;
   b.kslices = ks; b.slice_stride = mm;
   // c~ rides along: the diagonal-tile blocks of every k-slice also sum V[k][c] * (is*y)[k] over their rows
-  b.cs_w = p->yis; b.cs_out = p->gemvpart;
+  b.cs_w = row_weights<TS>(p, p->yis, p->yis_f); b.cs_out = p->gemvpart;
   launch_gemm(OP_TN, b, s);
   launch_reduce_rows(p->gemvpart, ks, mp, ar1_c, 1, s);
   tstop(p);
@@ -635,7 +643,7 @@ void do_pass2(gprhip_problem* p, const double* ar1, double* ar2) {
     tstart(p, "p2_syrk_W");
     GemmArgsT<TS> wg;
     wg.A = Vstore; wg.lda = mp; wg.B = Vstore; wg.ldb = mp; wg.C = slices; wg.ldc = mp;
-    wg.M = mp; wg.N = mp; wg.K = (int)ktot; wg.beta = 0.0; wg.scale_k = p->v; wg.upper_only = 1;
+    wg.M = mp; wg.N = mp; wg.K = (int)ktot; wg.beta = 0.0; wg.scale_k = row_weights<TS>(p, p->v, p->v_f); wg.upper_only = 1;
     wg.kslices = p->ks_used; wg.slice_stride = mm;
     launch_gemm(OP_TN, wg, s);
     tstop(p);
@@ -1238,6 +1246,7 @@ int gprhip_problem_create_ex(int device, int cov_kind, int precision, int64_t n,
     if (p->f32) {
       p->uinv_f = p->alloc<float>(mm);
       p->rinv_f = p->alloc<float>(mm);
+      p->is_f = p->alloc<float>(npad); p->yis_f = p->alloc<float>(npad); p->v_f = p->alloc<float>(npad);
     }
     p->slices_bytes = (int64_t)p->kslices * mm * p->esz;
     p->slices = p->alloc<char>(p->slices_bytes);

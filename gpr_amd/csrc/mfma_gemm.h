@@ -40,7 +40,7 @@ struct GemmArgsT {
   int M = 0, N = 0, K = 0;
   double alpha = 1.0;
   double beta = 0.0;              // 0: overwrite, otherwise C = alpha*AB + beta*C
-  const double* scale_k = nullptr;  // OP_TN only: per-k weight on the A operand (may be null)
+  const T* scale_k = nullptr;     // OP_TN only: per-k weight on the A operand (may be null); length K, 16-byte aligned
   int tri = TRI_NONE;
   int upper_only = 0;    // compute only tiles with row tile <= column tile
   int order = 0;         // block -> tile order of full grids (see tile_of_block)
@@ -64,12 +64,12 @@ struct GemmArgsT {
   // optional weighted column sums of the raw A operand, computed by the diagonal-tile blocks of an upper_only TN
   // launch while they stream A anyway:  cs_out[slice * N + c] = sum_{k in slice} A[k][c] * cs_w[k]
   // (c~ = V^T (y ./ s) without a separate pass over V; lib/fitc_gp.ml:285: gemv ~trans:`T q_mat y~)
-  const double* cs_w = nullptr;
+  const T* cs_w = nullptr;
   double* cs_out = nullptr;
   double* rp_sumsq = nullptr;
   double* rp_dot = nullptr;
   const double* rp_vec = nullptr;
-  int lab_noadvance = 0;  // tools/gemm_check.hip only: timing ablation, results are meaningless
+  int lab_skip = 0;  // tools/gemm_check.hip only (timing ablation): 1 = no epilogue at all, 2 = epilogue without its stores
 };
 using GemmArgs = GemmArgsT<double>;
 using GemmArgsF = GemmArgsT<float>;

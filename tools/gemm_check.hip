@@ -71,7 +71,7 @@ void timeit(GemmOp op, int M, int N, int K, int tri, int upper, int kslices, con
   hipMemset(dC, 0, (int64_t)M * N * 8 * std::max(1, kslices));
   double* dS = nullptr; if (scale) { hipMalloc(&dS, (int64_t)K * 8); hipMemcpy(dS, h.data(), (int64_t)K * 8, hipMemcpyHostToDevice); }
   GemmArgs g; g.scale_k = dS; g.A = dA; g.lda = ac; g.B = dB; g.ldb = bc; g.C = dC; g.ldc = N; g.M = M; g.N = N; g.K = K;
-  g.tri = tri; g.upper_only = upper; g.kslices = kslices; g.order = getenv("ORD") ? atoi(getenv("ORD")) : 0; g.slice_stride = (int64_t)M * N; g.lab_noadvance = getenv("NOADV") ? 1 : 0;
+  g.tri = tri; g.upper_only = upper; g.kslices = kslices; g.order = getenv("ORD") ? atoi(getenv("ORD")) : 0; g.slice_stride = (int64_t)M * N; g.lab_skip = getenv("SKIP") ? atoi(getenv("SKIP")) : 0;
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   for (int i = 0; i < 2; ++i) launch_gemm(op, g, 0);
   hipEventRecord(e0, 0);
@@ -106,22 +106,25 @@ int check_f32(GemmOp op, int M, int N, int K, int tri, bool scale, bool epi) {
   int64_t br = op == OP_NT ? N : K, bc = op == OP_NT ? K : N;
   std::vector<float> hA(ar * ac), hB(br * bc), hM((int64_t)M * N);
   std::vector<double> hs(std::max(K, M)), hcol(N);
+  std::vector<float> hsf(std::max(K, M));
   for (auto& v : hA) v = (float)frand();
   for (auto& v : hB) v = (float)frand();
   for (auto& v : hM) v = (float)frand();
   for (auto& v : hs) v = frand();
+  for (size_t i = 0; i < hs.size(); ++i) { hsf[i] = (float)hs[i]; hs[i] = hsf[i]; }
   for (auto& v : hcol) v = frand();
   if (tri == TRI_KHI_BN) for (int k = 0; k < K; ++k) for (int j = 0; j < N; ++j) if (k > j) hB[(int64_t)k * bc + j] = 0;
   if (tri == TRI_KLO_BN) for (int j = 0; j < N; ++j) for (int k = 0; k < K; ++k) if (k < j) hB[(int64_t)j * bc + k] = 0;
-  float *dA, *dB, *dC, *dM; double *dR, *ds, *dcol;
+  float *dA, *dB, *dC, *dM, *dsf; double *dR, *ds, *dcol;
   hipMalloc(&dA, hA.size() * 4); hipMalloc(&dB, hB.size() * 4); hipMalloc(&dC, (int64_t)M * N * 4); hipMalloc(&dM, (int64_t)M * N * 4);
-  hipMalloc(&dR, (int64_t)M * N * 8); hipMalloc(&ds, hs.size() * 8); hipMalloc(&dcol, N * 8);
+  hipMalloc(&dR, (int64_t)M * N * 8); hipMalloc(&ds, hs.size() * 8); hipMalloc(&dcol, N * 8); hipMalloc(&dsf, hs.size() * 4);
+  hipMemcpy(dsf, hsf.data(), hsf.size() * 4, hipMemcpyHostToDevice);
   hipMemcpy(dA, hA.data(), hA.size() * 4, hipMemcpyHostToDevice); hipMemcpy(dB, hB.data(), hB.size() * 4, hipMemcpyHostToDevice);
   hipMemcpy(dM, hM.data(), hM.size() * 4, hipMemcpyHostToDevice);
   hipMemcpy(ds, hs.data(), hs.size() * 8, hipMemcpyHostToDevice); hipMemcpy(dcol, hcol.data(), N * 8, hipMemcpyHostToDevice);
   hipMemset(dC, 0, (int64_t)M * N * 4);
   GemmArgsF g; g.A = dA; g.lda = ac; g.B = dB; g.ldb = bc; g.C = dC; g.ldc = N; g.M = M; g.N = N; g.K = K; g.tri = tri;
-  g.scale_k = scale ? ds : nullptr;
+  g.scale_k = scale ? dsf : nullptr;
   if (epi) { g.epi_rows_a = ds; g.epi_rows_b = ds; g.epi_rows_c = ds; g.epi_col = dcol; g.epi_mat = dM; g.epi_ldm = N; }
   launch_gemm(op, g, 0);
   naive_t<float><<<dim3((N + 255) / 256, M), 256>>>(op, dA, ac, dB, bc, dR, N, M, N, K, scale ? ds : nullptr);
@@ -161,6 +164,47 @@ void timeit_f32(GemmOp op, int M, int N, int K, int tri, int upper, int kslices,
   hipFree(dA); hipFree(dB); hipFree(dC);
 }
 
+
+// weighted SYRK-shaped split-K launch with column sums on the diagonal tiles (the pass-1 accumulation)
+template <typename T>
+int check_syrk_cs(int N, int K, int ks) {
+  std::vector<T> hA((int64_t)K * N), hw(K), hw2(K);
+  for (auto& v : hA) v = (T)frand();
+  for (auto& v : hw) v = (T)(0.5 + 0.5 * frand());
+  for (auto& v : hw2) v = (T)frand();
+  T *dA, *dw, *dw2, *dC; double* dcs;
+  hipMalloc(&dA, hA.size() * sizeof(T)); hipMalloc(&dw, K * sizeof(T)); hipMalloc(&dw2, K * sizeof(T));
+  hipMalloc(&dC, (int64_t)ks * N * N * sizeof(T)); hipMalloc(&dcs, (int64_t)ks * N * 8);
+  hipMemcpy(dA, hA.data(), hA.size() * sizeof(T), hipMemcpyHostToDevice);
+  hipMemcpy(dw, hw.data(), K * sizeof(T), hipMemcpyHostToDevice);
+  hipMemcpy(dw2, hw2.data(), K * sizeof(T), hipMemcpyHostToDevice);
+  hipMemset(dC, 0, (int64_t)ks * N * N * sizeof(T)); hipMemset(dcs, 0, (int64_t)ks * N * 8);
+  GemmArgsT<T> g; g.A = dA; g.lda = N; g.B = dA; g.ldb = N; g.C = dC; g.ldc = N; g.M = N; g.N = N; g.K = K;
+  g.scale_k = dw; g.upper_only = 1; g.kslices = ks; g.slice_stride = (int64_t)N * N; g.cs_w = dw2; g.cs_out = dcs;
+  launch_gemm(OP_TN, g, 0);
+  std::vector<T> hC((int64_t)ks * N * N); std::vector<double> hcs((int64_t)ks * N);
+  hipMemcpy(hC.data(), dC, hC.size() * sizeof(T), hipMemcpyDeviceToHost);
+  hipMemcpy(hcs.data(), dcs, hcs.size() * 8, hipMemcpyDeviceToHost);
+  double maxerr = 0, maxcs = 0;
+  for (int i = 0; i < N; ++i)
+    for (int j = i / 128 * 128; j < N; ++j) {   // upper tiles
+      double ref = 0, got = 0;
+      for (int k = 0; k < K; ++k) ref += (double)hA[(int64_t)k * N + i] * hw[k] * hA[(int64_t)k * N + j];
+      for (int z = 0; z < ks; ++z) got += hC[(int64_t)z * N * N + (int64_t)i * N + j];
+      maxerr = std::max(maxerr, fabs(ref - got));
+    }
+  for (int c = 0; c < N; ++c) {
+    double ref = 0, got = 0;
+    for (int k = 0; k < K; ++k) ref += (double)hA[(int64_t)k * N + c] * hw2[k];
+    for (int z = 0; z < ks; ++z) got += hcs[(int64_t)z * N + c];
+    maxcs = std::max(maxcs, fabs(ref - got));
+  }
+  const double tol = (sizeof(T) == 8 ? 1e-10 : 2e-5) * K;
+  bool ok = maxerr < tol && maxcs < tol;
+  printf("check syrk+colsums %s N=%d K=%d ks=%d maxerr=%.3e colsum err=%.3e %s\n", sizeof(T) == 8 ? "f64" : "f32", N, K, ks, maxerr, maxcs, ok ? "OK" : "FAIL");
+  hipFree(dA); hipFree(dw); hipFree(dw2); hipFree(dC); hipFree(dcs);
+  return ok ? 0 : 1;
+}
 
 // Register-only MFMA stream: the matrix-pipe ceiling at the clock the chip sustains under this load
 // (no LDS, no global traffic).  16 independent accumulators per wavefront, 4 wavefronts per block.
@@ -208,12 +252,15 @@ int main() {
   }
   if (getenv("LAB")) {
     for (int rep = 0; rep < 2; ++rep) {
-      timeit(OP_NN, 4096, 4096, 4096, TRI_NONE, 0, 1, "square NN 4096");
       timeit(OP_NN, 8192, 8192, 8192, TRI_NONE, 0, 1, "square NN 8192");
-      timeit(OP_NN, 16384, 16384, 16384, TRI_NONE, 0, 1, "square NN 16384");
       timeit(OP_NN, 32768, 2048, 2048, TRI_KHI_BN, 0, 1, "K*Uinv triu");
       timeit(OP_NT, 32768, 2048, 2048, TRI_KLO_BN, 0, 1, "V*Uinv^T triu");
       timeit(OP_TN, 2048, 2048, 1000064, TRI_NONE, 1, 256, "syrk upper K=1M ks256 scaled", true);
+      timeit(OP_NN, 16384, 16384, 8192, TRI_NONE, 0, 1, "NN 16384x16384x8192");
+      timeit(OP_NN, 32768, 2048, 1088, TRI_NONE, 0, 1, "full, K=1088 (68 stages)");
+      timeit(OP_NN, 32768, 2048, 128, TRI_NONE, 0, 1, "full, K=128 (8 stages)");
+      timeit(OP_NN, 32768, 2048, 512, TRI_NONE, 0, 1, "full, K=512 (32 stages)");
+      timeit(OP_NN, 32768, 2048, 2048, TRI_NONE, 0, 1, "full, K=2048 (128 stages)");
     }
     return 0;
   }
@@ -224,6 +271,9 @@ int main() {
     bad += check_f32(OP_TN, 256, 256, 160, TRI_NONE, true, false);
     bad += check_f32(OP_NN, 384, 256, 256, TRI_KHI_BN, false, false);
     bad += check_f32(OP_NT, 384, 256, 256, TRI_KLO_BN, false, true);
+    bad += check_f32(OP_TN, 128, 128, 32, TRI_NONE, false, false);
+    bad += check_syrk_cs<float>(256, 1056, 8);
+    bad += check_syrk_cs<float>(384, 4096 + 96, 3);
     printf("f32 checks failed: %d\n", bad);
     timeit_f32(OP_NN, 8192, 8192, 8192, TRI_NONE, 0, 1, "square NN 8192");
     timeit_f32(OP_NN, 32768, 4096, 4096, TRI_KHI_BN, 0, 1, "K*Uinv triu m4096");
@@ -239,6 +289,10 @@ int main() {
   bad += check(OP_NT, 384, 256, 256, TRI_KLO_BN, false);
   bad += check(OP_NN, 256, 128, 256, TRI_KLO_BM, false);
   bad += check(OP_NT, 256, 256, 256, TRI_KLO_MAX, false);
+  bad += check(OP_TN, 128, 128, 16, TRI_NONE, false);
+  bad += check(OP_NN, 128, 256, 48, TRI_NONE, false);
+  bad += check_syrk_cs<double>(256, 1040, 8);
+  bad += check_syrk_cs<double>(384, 4096 + 48, 3);
   printf("checks failed: %d\n", bad);
   timeit(OP_NN, 8192, 8192, 8192, TRI_NONE, 0, 1, "square NN 8192");
   timeit(OP_NN, 32768, 2048, 2048, TRI_NONE, 0, 1, "K*Uinv full");

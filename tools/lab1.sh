@@ -1,4 +1,11 @@
 #!/bin/bash
-out=gpurun_out/lab5; mkdir -p $out
-for w in 4 8; do GPRHIP_ENG_WAVES=$w LAB=1 ./build/gemm_check > $out/lab_w$w.txt 2>&1; GPRHIP_ENG_WAVES=$w NOADV=1 LAB=1 ./build/gemm_check > $out/lab_noadv_w$w.txt 2>&1; done
-tail -n 6 $out/lab_w4.txt $out/lab_noadv_w4.txt $out/lab_w8.txt $out/lab_noadv_w8.txt
+out=gpurun_out/lab11; mkdir -p $out
+timeout 120 ./build/gemm_check > $out/check.txt 2>&1; echo "rc=$?" >> $out/check.txt
+F32=1 timeout 120 ./build/gemm_check > $out/check_f32.txt 2>&1; echo "rc=$?" >> $out/check_f32.txt
+LAB=1 timeout 120 ./build/gemm_check > $out/lab.txt 2>&1
+python -m pytest tests -m gpu -x -q > $out/pytest.txt 2>&1
+python bench.py --steps 5 --warmup 2 --no-cpu-baseline > $out/bench.json 2> $out/bench.err
+grep -v "^check.*OK" $out/check.txt $out/check_f32.txt; tail -9 $out/lab.txt; tail -5 $out/pytest.txt; python - <<'PY'
+import json
+d=json.loads(open("gpurun_out/lab11/bench.json").read()); print(d["ms_per_step"], d["stage_ms"])
+PY
