@@ -11,10 +11,16 @@ with fresh theta and inducing points every step (as under an optimiser) and the 
 already resident in HBM.  With N > 1 the n training points are row-sharded over the ranks
 (strong scaling of the same n) with two RCCL all-reduces per step.
 Rank 0 prints ONE JSON line.
+
+The timed region carries one HIP-event pair per step (around the dominant kernel, on the library's own stream);
+the per-stage times (`stage_ms`), the evidence-only rate, the collective times and the other BASELINE configurations
+(`configs`) are measured in separate passes after it.
 """
 import argparse
+import glob
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -23,7 +29,9 @@ sys.path.insert(0, ROOT)
 
 import numpy as np  # noqa: E402
 
-PEAK_FP64_MFMA_TFLOPS = 78.6   # MI355X fp64 matrix peak (256 CU x 2.4 GHz x 128 flop/clk/CU)
+PEAK_FP64_MFMA_TFLOPS = 78.6    # MI355X fp64 matrix peak (256 CU x 2.4 GHz x 128 flop/clk/CU)
+PEAK_FP32_MFMA_TFLOPS = 157.3   # fp32-input MFMA (v_mfma_f32_16x16x4_f32): the fp32 vector rate
+DOMINANT = {"f64": "gprhip::gemm_f64_tn_ws", "f32": "gprhip::gemm_f32_tn_ws"}
 
 
 def synth(seed, n, m, d):
@@ -40,36 +48,120 @@ def algorithmic_flops(n, m, d):
     return n * (6.0 * m * m + 4.0 * m * d) + 2.0 * m ** 3
 
 
-def cpu_baseline(n_full, m, d, seed):
-    """The CPU oracle (numpy/scipy-LAPACK port of the reference's operation sequence) timed on this
-    host's cores on a bounded row sample of the same workload; cost is linear in n."""
-    from oracle import fitc_oracle as O
-    n_cpu = int(os.environ.get("BENCH_CPU_ROWS", "12288"))
-    X, y, Z = synth(seed, n_cpu, m, d)
-    k = O.SeIsoKernel(0.5 * np.log(d), 0.0)
-    t0 = time.time()
-    out = O.evaluate_fast(k, Z, X, y, 0.1)
-    dt = time.time() - t0
-    assert np.isfinite(out["l"])
-    return {"value": n_cpu / dt, "unit": "training-points/s", "cores": os.cpu_count(), "kind": "port",
-            "sample": "oracle.evaluate_fast (reference LAPACK sequence: potrf, trsm, geqrf+orgqr, potri x2, "
-                      "trsm x2, syrk x2, traces) on n=%d rows of the same m=%d d=%d workload, %.1f s, "
-                      "scipy OpenBLAS threads" % (n_cpu, m, d, dt)}
+def cpu_baseline(m, d, seed):
+    """The C restatement of the reference's LAPACK sequence (oracle/fitc_ref.c: direct-difference covariance loops,
+    potrf, trsm, stacked geqrf + orgqr, potri x2, trsm x2, syrk x2, per-hyper traces) over scipy's OpenBLAS, timed on
+    this host's cores on a bounded row sample of the same workload (its cost is linear in n).  A short run sizes the
+    sample for ~15 s; a single-thread figure is measured on a smaller sample."""
+    from oracle import fitc_ref as R
+    cores = os.cpu_count() or 1
+    le = 0.5 * np.log(d)
+
+    def run(n_rows, threads):
+        X, y, Z = synth(seed, n_rows, m, d)
+        t0 = time.time()
+        out = R.iso_eval(X, y, Z, le, 0.0, 0.1, threads=threads)
+        dt = time.time() - t0
+        assert np.isfinite(out["l"])
+        return dt, out
+
+    budget = float(os.environ.get("BENCH_CPU_SECONDS", "15"))
+    run(2048, cores)                      # loads and warms the BLAS threads
+    dt0, _ = run(8192, cores)
+    n_cpu = int(os.environ.get("BENCH_CPU_ROWS", "0")) or int(min(131072, max(8192, 8192 * budget / dt0)) // 1024 * 1024)
+    # the restatement holds ~12 dense n x m fp64 matrices
+    try:
+        avail = int(open("/proc/meminfo").read().split("MemAvailable:")[1].split()[0]) * 1024
+        n_cpu = int(min(n_cpu, max(8192, 0.5 * avail / (12 * m * 8)) // 1024 * 1024))
+    except Exception:
+        pass
+    dt, out = run(n_cpu, cores)
+    n1 = 4096
+    dt1, _ = run(n1, 1)
+    return {"value": n_cpu / dt, "unit": "training-points/s", "cores": int(out["blas_threads"]), "kind": "port",
+            "host_cores": cores, "omp_threads": int(out["omp_threads"]),
+            "single_thread": {"value": n1 / dt1, "unit": "training-points/s", "rows": n1},
+            "seconds": {k: float(v) for k, v in zip(("covariances", "chol_V_QR", "trained_inverses", "U_S_W_X",
+                                                     "per_hyper_traces", "total"), out["secs"])},
+            "sample": "oracle/fitc_ref.c (reference LAPACK sequence: potrf, trsm, geqrf+orgqr, potri x2, trsm x2, "
+                      "syrk x2, per-hyper traces; covariance loops under OpenMP) on n=%d rows of the same m=%d d=%d "
+                      "workload, %.1f s, scipy OpenBLAS, %d BLAS threads on %d host cores"
+                      % (n_cpu, m, d, dt, int(out["blas_threads"]), cores)}
 
 
-def measured_traffic():
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
-    (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, collected in separate --pmc runs of this same
-    command: tools/pmc_summary.py -> profiles/*pmc_bench*.json).  None if no profile is committed."""
-    import glob
-    best = None
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_bench*.json"))):
-        for r in json.load(open(path)):
-            if r["kernel"].startswith("gprhip::gemm_kernel<double, 2, true>") and (best is None or r["avg_ms"] > best["avg_ms"]):
-                best = r
-    if best is None:
+def profile_traffic(n, m):
+    """HBM bytes per launch of the SYRK-shaped launches, from the newest committed rocprofv3 PMC passes of this same
+    command (tools/profile_round.sh -> profiles/*pmc_bench*.json: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE in
+    separate --pmc runs).  Labelled from_profile: it is a property of that committed run, not of this one."""
+    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_bench*.json")))
+    if not paths:
         return None
-    return best["hbm_fetch_bytes_per_launch"] + best["hbm_write_bytes_per_launch"]
+    path = paths[-1]
+    rows = [r for r in json.load(open(path)) if "gemm_f64_tn_w" in r["kernel"] and r["avg_ms"] > 5.0]
+    if not rows:
+        return None
+    try:
+        rev = subprocess.check_output(["git", "-C", ROOT, "log", "-1", "--format=%h", "--", path], text=True).strip()
+    except Exception:
+        rev = None
+    algo = float(n) * m * 8
+    out = {"from_profile": os.path.relpath(path, ROOT), "profile_commit": rev or None, "launches": []}
+    for r in rows:
+        b = r["hbm_fetch_bytes_per_launch"] + r["hbm_write_bytes_per_launch"]
+        out["launches"].append({"kernel": r["kernel"], "avg_ms": r["avg_ms"], "fetch_bytes": r["hbm_fetch_bytes_per_launch"],
+                                "write_bytes": r["hbm_write_bytes_per_launch"], "bytes_over_algorithmic": b / algo,
+                                "mfma_util": r.get("mfma_util"), "clock_ghz": r.get("clock_ghz")})
+    return out
+
+
+def other_configs(gpr_amd, steps=2):
+    """BASELINE.json configs[2] (cov_se_fat ARD, n=1M m=4096 d=32, fp32 bulk and fp64) and the per-GPU shard of
+    configs[3] (cov_se_iso, n=1M of 8M, m=4096, d=16, fp64), outside the headline's timed region: one warm-up + `steps`
+    timed evaluations each, the dominant kernel timed with HIP events on the library's stream."""
+    out = []
+
+    def measure(label, prob, kwargs, n, m, d, dtype):
+        prob.set_timing(1)
+        prob.eval(**kwargs)
+        ks, t0 = [], time.perf_counter()
+        for _ in range(steps):
+            ev = prob.eval(**kwargs)
+            ks.append(prob.last_timings().get("kernel_p1_syrk_B", 0.0))
+        dt = (time.perf_counter() - t0) / steps
+        peak = PEAK_FP64_MFMA_TFLOPS if dtype == "f64" else PEAK_FP32_MFMA_TFLOPS
+        kms = float(np.mean(ks))
+        ach = float(n) * m * m / (kms * 1e-3) * 1e-12 if kms > 0 else None
+        F = algorithmic_flops(n, m, d)
+        out.append({"config": label, "dtype": dtype, "ms_per_eval": dt * 1e3, "points_per_s": n / dt,
+                    "job_tflops": F / dt * 1e-12, "job_frac": F / dt * 1e-12 / peak,
+                    "dominant_kernel": DOMINANT[dtype], "dominant_kernel_ms": kms,
+                    "dominant_kernel_tflops": ach, "dominant_kernel_frac": ach / peak if ach else None,
+                    "l": float(ev.l), "grad_norm": float(np.linalg.norm(ev.grad))})
+        prob.close()
+
+    n, m, d = 1_000_000, 4096, 32
+    rng = np.random.default_rng(3)
+    X = np.asfortranarray(rng.normal(size=(d, n)))
+    y = np.sin(X.sum(0)) + 0.1 * rng.normal(size=n)
+    ell = rng.uniform(-0.5, 0.5, size=d)
+    P = np.asfortranarray(np.diag(np.exp(-ell)) / np.sqrt(d))
+    Z = np.asfortranarray((P.T @ X[:, rng.permutation(n)[:m]]) + 0.01 * rng.normal(size=(d, m)))
+    for prec, dtype in ((gpr_amd.F32_BULK, "f32"), (gpr_amd.F64, "f64")):
+        p = gpr_amd.Problem(gpr_amd.COV_SE_FAT, n, d, d, m, precision=prec)
+        p.set_inputs(X)
+        p.set_targets(y)
+        measure("C3: cov_se_fat ARD (tproj = diag(1/ell)) FITC nLML+grad, n=1000000 m=4096 d=32, %s"
+                % ("fp32 bulk (n x m contractions fp32, m x m work fp64)" if dtype == "f32" else "fp64"),
+                p, dict(log_sf2=0.0, sigma2=0.1, inducing=Z, tproj=P), n, m, d, dtype)
+    del X, y, Z
+    n, m, d = 1_000_000, 4096, 16
+    X, y, Z = synth(4, n, m, d)
+    p = gpr_amd.Problem(gpr_amd.COV_SE_ISO, n, d, d, m)
+    p.set_inputs(X)
+    p.set_targets(y)
+    measure("C4 shard: cov_se_iso FITC nLML+grad, one GPU's n=1000000 rows of n=8000000, m=4096 d=16, fp64",
+            p, dict(log_ell=0.5 * np.log(d), log_sf2=0.0, sigma2=0.1, inducing=Z), n, m, d, "f64")
+    return out
 
 
 def main():
@@ -82,13 +174,14 @@ def main():
     ap.add_argument("--inducing", dest="m", type=int, default=2048)
     ap.add_argument("--dims", dest="d", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    # validation aids (tests/test_gpu_parity.py runs the N=2 code path on a 1-GPU box with them); the
+    ap.add_argument("--no-configs", action="store_true", help="skip the C3 / C4-shard block")
+    # validation aids (tests/test_gpu_parity.py runs the N>1 code path on a 1-GPU box with them); the
     # driver's runs use the defaults: RCCL, one device per rank
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"])
     ap.add_argument("--share-device", action="store_true", help="all ranks use cuda:0 (testing only)")
     args = ap.parse_args()
 
-    os.environ.setdefault("GPRHIP_TIMING", "1")  # per-kernel HIP events on the library's own stream
+    os.environ.pop("GPRHIP_TIMING", None)
     import torch
     import torch.distributed as dist
     import gpr_amd
@@ -105,7 +198,8 @@ def main():
     if args.share_device:
         local_rank = 0
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    launched = "RANK" in os.environ  # under torch.distributed.run a process group exists even with one rank
+    if launched:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
@@ -122,67 +216,93 @@ def main():
     rng = np.random.default_rng(1234)  # same stream on every rank: identical theta everywhere
     le0 = 0.5 * np.log(d)
 
-    def step():
+    def step(want_grad=True):
         Z = Z0 + 1e-3 * rng.normal(size=Z0.shape)
         return sp.eval(log_ell=le0 + 1e-3 * rng.normal(), log_sf2=1e-3 * rng.normal(),
-                       sigma2=0.1 * np.exp(1e-3 * rng.normal()), inducing=Z)
+                       sigma2=0.1 * np.exp(1e-3 * rng.normal()), inducing=Z, want_grad=want_grad)
 
     def barrier():
-        if world > 1:
+        if launched:
             dist.barrier()
         torch.cuda.synchronize()
 
+    def max_over_ranks(x):
+        if not launched or world == 1:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    # ---- the headline: K timed steps, one event pair per step around the dominant kernel
+    sp.local.set_timing(1)
     for _ in range(args.warmup):
         step()
     barrier()
     t0 = time.perf_counter()
-    tim = {}
+    kernel_ms = []
     for _ in range(args.steps):
         ev = step()
-        for k_, v_ in sp.local.last_timings().items():
-            tim.setdefault(k_, []).append(v_)
+        kernel_ms.append(sp.local.last_timings().get("kernel_p1_syrk_B", 0.0))
     barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
+    dt = max_over_ranks(time.perf_counter() - t0)
     assert np.isfinite(ev.l) and np.all(np.isfinite(ev.grad))
 
-    # reported beside the headline, outside its timed region: log evidence only (the reference's
-    # multim_f, lib/fitc_gp.ml:1601-1610) -- one pass over the training points instead of two
+    # ---- separate passes (not part of the headline): per-stage times, evidence only, collective times
+    sp.local.set_timing(2)
+    tim = {}
+    for _ in range(3):
+        step()
+        for k_, v_ in sp.local.last_timings().items():
+            tim.setdefault(k_, []).append(v_)
+    sp.local.set_timing(0)
     nl_steps = 3
     barrier()
     t1 = time.perf_counter()
     for _ in range(nl_steps):
-        Z = Z0 + 1e-3 * rng.normal(size=Z0.shape)
-        ev0 = sp.eval(log_ell=le0, log_sf2=0.0, sigma2=0.1, inducing=Z, want_grad=False)
+        ev0 = step(want_grad=False)
     barrier()
-    dt_nl = time.perf_counter() - t1
-    if world > 1:
-        tmax = torch.tensor([dt_nl], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt_nl = float(tmax.item())
+    dt_nl = max_over_ranks(time.perf_counter() - t1)
     assert np.isfinite(ev0.l)
+    comm = None
+    if launched:
+        sp.timing = True
+        c0 = sp.collectives
+        step()
+        per_eval = sp.collectives - c0
+        ar = [list(sp.last_comm_ms)]
+        for _ in range(2):
+            step()
+            ar.append(list(sp.last_comm_ms))
+        sp.timing = False
+        c1 = sp.collectives
+        step(want_grad=False)
+        comm = {"backend": args.backend, "rccl_ranks": world if args.backend == "nccl" else 0,
+                "collectives_per_gradient_eval": per_eval, "collectives_per_evidence_eval": sp.collectives - c1,
+                "allreduce_ms": [float(np.mean([a[i] for a in ar if len(a) > i])) for i in range(len(ar[0]))],
+                "allreduce_bytes": [int(sp.ar1.numel() * 8), int(sp.ar2.numel() * 8)],
+                "replicated_mxm_ms": float(np.mean(tim.get("km_chol", [0.0])) + np.mean(tim.get("b_chol", [0.0]))
+                                           + np.mean(tim.get("inverses", [0.0])) + np.mean(tim.get("finish", [0.0])))}
+    n_local = hi - lo
+    sp.close()
 
+    line = None
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
         value = n * args.steps / dt
         F = algorithmic_flops(n, m, d)
-        # dominant kernel by time per launch: gprhip::gemm_kernel<double, 2, true> -- the pass-1 SYRK-shaped
-        # accumulation B~ = V^T diag(1/s) V over the shard's training points (one launch per evaluation, timed
-        # with HIP events on the library's own stream; this instantiation is launched nowhere else, so the
-        # rocprofv3 --stats average of that kernel name is directly comparable).  The pass-2 SYRK is the same
-        # kernel without the c~ column sums (<double, 2, false>, a name it shares with the short potrf updates).
-        # Algorithmic flops per launch = n_local * m^2 ("SYRK B nm^2")
-        chunk = min(int(os.environ.get("GPRHIP_CHUNK_ROWS", "32768")), hi - lo)
-        n_local = hi - lo
-        syrk_ms = float(np.mean(tim.get("p1_syrk_B", [0.0])))
-        launches = 1
+        # dominant kernel by time per launch: gprhip::gemm_f64_tn_ws -- the pass-1 SYRK-shaped accumulation
+        # B~ = V^T diag(1/s) V over the shard's training points (one launch per evaluation; launched nowhere else, so the
+        # rocprofv3 --stats average of that kernel name is directly comparable).  Algorithmic flops per launch =
+        # n_local * m^2 ("SYRK B nm^2"); time: HIP events on the library's stream inside the timed region.
+        syrk_ms = float(np.mean(kernel_ms)) if kernel_ms else 0.0
         flops_per_launch = float(n_local) * m * m
-        achieved = flops_per_launch / (syrk_ms / launches * 1e-3) * 1e-12 if syrk_ms > 0 else None
-        engine_ms = sum(np.mean(tim.get(k_, [0.0])) for k_ in
+        achieved = flops_per_launch / (syrk_ms * 1e-3) * 1e-12 if syrk_ms > 0 else None
+        stage = {k_: float(np.mean(v_)) for k_, v_ in sorted(tim.items()) if not k_.startswith("kernel_")}
+        engine_ms = sum(stage.get(k_, 0.0) for k_ in
                         ("p1_syrk_B", "p2_syrk_W", "p1_trmm_V", "p2_trmm_Q", "p2_trmm_S", "p2_trmm_X"))
+        cov_ms = stage.get("p1_cov")
+        traffic = profile_traffic(n_local, m) if (n, m, d, world) == (1_000_000, 2048, 8, 1) else None
+        first = traffic["launches"][0] if traffic and traffic["launches"] else None
         line = {
             "metric": "FITC nLML+grad training-points/sec at n=1M m=2048 d=8",
             "value": value, "unit": "training-points/s", "n_gpus": world, "steps": args.steps,
@@ -190,40 +310,42 @@ def main():
             "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "cov_se_iso FITC nLML + full hyper-gradient, n=%d m=%d d=%d fp64 "
                                    "(BASELINE.json configs[1]); n row-sharded over %d GPU(s)" % (n, m, d, world),
-                       "n": n, "m": m, "d": d, "n_hypers": int(ev.grad.shape[0]) + 1,
-                       "chunk_rows": chunk},
-            "roofline": {"bound": "mfma", "kernel": "gprhip::gemm_kernel<double, 2, true>  (OP_TN: SYRK over training points)",
-                         "launches_per_step": launches,
+                       "n": n, "m": m, "d": d, "n_hypers": int(ev.grad.shape[0]) + 1},
+            "roofline": {"bound": "mfma", "kernel": DOMINANT["f64"] + "  (OP_TN: weighted SYRK over training points + c~ column sums)",
+                         "launches_per_step": 1,
                          "achieved": achieved, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": (achieved / PEAK_FP64_MFMA_TFLOPS) if achieved else None,
-                         "traffic": measured_traffic() if (n, m, d, world) == (1_000_000, 2048, 8, 1) else None,
+                         "traffic": (first["fetch_bytes"] + first["write_bytes"]) if first else None,
+                         "traffic_source": traffic,
                          "algorithmic_bytes_per_launch": float(n_local) * m * 8,
-                         "avg_launch_ms": syrk_ms / launches if launches else None,
-                         "flops_per_launch": flops_per_launch},
+                         "avg_launch_ms": syrk_ms, "flops_per_launch": flops_per_launch},
             "roofline_job": {"algorithmic_flops_per_step": F, "achieved": F / (dt / args.steps) * 1e-12 / world,
                              "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s per GPU",
                              "frac": F / (dt / args.steps) * 1e-12 / world / PEAK_FP64_MFMA_TFLOPS,
                              "mfma_engine_ms_per_step": engine_ms},
-            # the K_nm builder is the one HBM-bound kernel of the path: bytes written / its time
-            "roofline_k_builder": {"bound": "hbm", "kernel": "gprhip::cov_cross_kernel",
-                                   "achieved": float(n_local) * m * 8 / (np.mean(tim["p1_cov"]) * 1e-3) * 1e-9
-                                   if "p1_cov" in tim else None,
+            # the K_nm builder: HBM-bound while the point dimension is small (d = 8: 2d+~30 flops per 8-byte element),
+            # fp64-VALU/exp-bound from d >= 16; bytes written / its time
+            "roofline_k_builder": {"bound": "hbm" if d < 16 else "valu", "kernel": "gprhip::cov_cross_kernel",
+                                   "achieved": float(n_local) * m * 8 / (cov_ms * 1e-3) * 1e-9 if cov_ms else None,
                                    "peak": 8000.0, "unit": "GB/s",
-                                   "frac": float(n_local) * m * 8 / (np.mean(tim["p1_cov"]) * 1e-3) * 1e-9 / 8000.0
-                                   if "p1_cov" in tim else None,
+                                   "frac": float(n_local) * m * 8 / (cov_ms * 1e-3) * 1e-9 / 8000.0 if cov_ms else None,
                                    "algorithmic_bytes_per_step": float(n_local) * m * 8},
-            "stage_ms": {k_: float(np.mean(v_)) for k_, v_ in sorted(tim.items())},
+            "stage_ms": stage,
             "evidence_only": {"value": n * nl_steps / dt_nl, "unit": "training-points/s",
                               "ms_per_step": dt_nl / nl_steps * 1e3, "steps": nl_steps,
                               "algorithmic_flops_per_step": n * (2.0 * m * m + 2.0 * m * d) + 2.0 / 3.0 * m ** 3},
             "last_eval": {"l": float(ev.l), "dl_dsigma2": float(ev.dl_dsigma2),
                           "grad_norm": float(np.linalg.norm(ev.grad))},
         }
+        if comm:
+            line["multi_gpu"] = comm
+        if world == 1 and not args.no_configs:
+            line["configs"] = other_configs(gpr_amd)
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(n, m, d, seed)
+            line["cpu_baseline"] = cpu_baseline(m, d, seed)
         print(json.dumps(line))
-    sp.close()
-    if world > 1:
+    if launched:
+        dist.barrier()
         dist.destroy_process_group()
 
 

@@ -76,6 +76,7 @@ SIGNATURES = {
     "gprhip_eval_finish": (C.c_int, [_vp, _vp, C.POINTER(Result), _dp, _dp]),
     "gprhip_sync": (C.c_int, [_vp]),
     "gprhip_stream": (_vp, [_vp]),
+    "gprhip_set_timing": (C.c_int, [_vp, C.c_int]),
     "gprhip_predict": (C.c_int, [_vp, _dp, C.c_int64, C.c_int64, C.c_int, _dp, _dp]),
     "gprhip_train_stats": (C.c_int, [_vp, _dp, _dp]),
     "gprhip_covariances": (C.c_int, [_vp, _dp, C.c_int64, C.c_int64, C.c_int, C.c_int, _dp]),

@@ -39,4 +39,12 @@ constexpr int BK = 16;     // fp64 MFMA engine k-depth per LDS stage (fp32: 32)
 
 static inline int64_t round_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
 
+// Exchange buffers carry a symmetric mp x mp accumulation as its upper 128-tiles only, tile after tile (tile (bm, bn),
+// bm <= bn, at index bn(bn+1)/2 + bm, 128 x 128 row-major): half the all-reduce payload of the full square.
+static inline int64_t packed_upper_len(int mp) { return (int64_t)(mp / TILE) * (mp / TILE + 1) / 2 * TILE * TILE; }
+__host__ __device__ static inline int64_t packed_upper_off(int r, int c) {
+  const int bm = r / TILE, bn = c / TILE;
+  return ((int64_t)bn * (bn + 1) / 2 + bm) * (TILE * TILE) + (int64_t)(r % TILE) * TILE + (c % TILE);
+}
+
 }  // namespace gprhip

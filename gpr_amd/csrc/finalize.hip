@@ -3,33 +3,36 @@
 
 namespace gprhip {
 
-// dst = base + sum_z slices[z] on upper tiles (row tile <= column tile), 0 elsewhere.
+// dst = base + sum_z slices[z] on upper tiles (row tile <= column tile); dst is the mp x mp square (0 elsewhere) or,
+// packed, the upper tiles alone (packed_upper_off: the layout of the exchange buffers).
 template <typename TS>
 __global__ __launch_bounds__(256) void sum_slices_kernel(const double* __restrict__ base,
                                                          const TS* __restrict__ slices, int nslices,
-                                                         int64_t stride, int mp,
+                                                         int64_t stride, int mp, int packed,
                                                          double* __restrict__ dst) {
   const int c = blockIdx.x * 256 + threadIdx.x;
   const int r = blockIdx.y;
   if (c >= mp) return;
   const int64_t off = (int64_t)r * mp + c;
+  const bool upper = r / TILE <= c / TILE;
   double acc = 0.0;
-  if (r / TILE <= c / TILE) {
+  if (upper) {
     acc = base ? base[off] : 0.0;
     for (int z = 0; z < nslices; ++z) acc += (double)slices[(int64_t)z * stride + off];
   }
-  dst[off] = acc;
+  if (!packed) dst[off] = acc;
+  else if (upper) dst[packed_upper_off(r, c)] = acc;
 }
 
 template <typename TS>
 void launch_sum_slices(const double* base, const TS* slices, int nslices, int64_t stride, int mp,
-                       double* dst, hipStream_t s) {
+                       double* dst, hipStream_t s, int packed) {
   hipLaunchKernelGGL(sum_slices_kernel<TS>, dim3((mp + 255) / 256, mp), dim3(256), 0, s, base, slices,
-                     nslices, stride, mp, dst);
+                     nslices, stride, mp, packed, dst);
   GPR_HIP(hipGetLastError());
 }
-template void launch_sum_slices<double>(const double*, const double*, int, int64_t, int, double*, hipStream_t);
-template void launch_sum_slices<float>(const double*, const float*, int, int64_t, int, double*, hipStream_t);
+template void launch_sum_slices<double>(const double*, const double*, int, int64_t, int, double*, hipStream_t, int);
+template void launch_sum_slices<float>(const double*, const float*, int, int64_t, int, double*, hipStream_t, int);
 
 // dst[b][r][c] = sum_z slices[z][b][r][c] over a rows x cols rectangle (leading dimension ld, batch stride bs;
 // slices and dst share offsets): combines the split-K partial products of small GEMM launches in a fixed order.
@@ -77,8 +80,8 @@ __global__ __launch_bounds__(256) void build_w_kernel(const double* __restrict__
     rr = c;
     cc = r;
   }
-  const int64_t off = (int64_t)rr * mp + cc;
-  W[(int64_t)r * mp + c] = (r == c ? 1.0 : 0.0) - binv[off] - t[rr] * t[cc] - G[off];
+  const int64_t off = (int64_t)rr * mp + cc;  // G: packed upper tiles (the exchange-2 buffer)
+  W[(int64_t)r * mp + c] = (r == c ? 1.0 : 0.0) - binv[off] - t[rr] * t[cc] - G[packed_upper_off(rr, cc)];
 }
 
 void launch_build_w(const double* binv, const double* t, const double* G, int mp, double* W,

@@ -40,19 +40,20 @@ __global__ __launch_bounds__(256) void dot_kernel(const double* __restrict__ x,
   if (threadIdx.x == 0) out[0] = red[0];
 }
 
-// dst = I + a on upper tiles, 0 elsewhere
+// dst = I + a on upper tiles, 0 elsewhere; a: packed upper tiles (the exchange-1 buffer)
 __global__ void add_identity_upper_kernel(const double* __restrict__ a, int mp, double* __restrict__ dst) {
   const int c = blockIdx.x * 256 + threadIdx.x;
   const int r = blockIdx.y;
   if (c >= mp) return;
   const int64_t off = (int64_t)r * mp + c;
-  dst[off] = (r / TILE <= c / TILE) ? a[off] + (r == c ? 1.0 : 0.0) : 0.0;
+  dst[off] = (r / TILE <= c / TILE) ? a[packed_upper_off(r, c)] + (r == c ? 1.0 : 0.0) : 0.0;
 }
 
 }  // namespace gprhip
 
 using namespace gprhip;
 
+extern "C" int64_t gprhip_ar1_len(const gprhip_problem* p);
 extern "C" int64_t gprhip_ar2_len(const gprhip_problem* p);
 
 namespace {
@@ -70,7 +71,10 @@ enum { A2_SUMV = 0, A2_SUMIS = 1, A2_WRES = 2, A2_SUMV1 = 3, A2_SUME = 4, A2_SUM
 
 struct Timer {
   std::vector<std::pair<std::string, std::pair<hipEvent_t, hipEvent_t>>> ev;
-  bool on = false;
+  bool on = false;       // level 2: an event pair around every stage of the evaluation
+  bool kernel = false;   // level 1: one event pair around the dominant kernel alone (the pass-1 SYRK launch)
+  hipEvent_t k0 = nullptr, k1 = nullptr;
+  bool k_recorded = false;
 };
 
 }  // namespace
@@ -99,6 +103,7 @@ struct gprhip_problem {
   double *xt = nullptr, *pt = nullptr, *prow = nullptr;  // prediction: test-point chunk, its projection, 3 row vectors
   bool have_model = false;
   bool have_factors = false;  // U^-1 / R~^-1 valid (false after a means-only gprhip_load_predictor)
+  bool have_v = false;        // Vstore / r hold V = K_nm U^-1 of the current kernel and inducing points (reuse_v)
   // n x m storage: double, or float in the fp32-bulk mode (element size `esz`)
   void *bufA = nullptr, *bufB = nullptr, *Vstore = nullptr;
   float *uinv_f = nullptr, *rinv_f = nullptr;  // fp32 copies of U^-1 / R~^-1 (fp32-bulk mode)
@@ -185,6 +190,13 @@ void tstop(gprhip_problem* p) {
 void tcollect(gprhip_problem* p) {
   p->tnames.clear();
   p->tms.clear();
+  if (p->timer.k_recorded) {
+    float ms = 0;
+    hipEventElapsedTime(&ms, p->timer.k0, p->timer.k1);
+    p->tnames.push_back("kernel_p1_syrk_B");
+    p->tms.push_back(ms);
+    p->timer.k_recorded = false;
+  }
   for (auto& e : p->timer.ev) {
     float ms = 0;
     hipEventElapsedTime(&ms, e.second.first, e.second.second);
@@ -439,18 +451,25 @@ void cov_chunk(gprhip_problem* p, int c, TS* K) {
 
 template <typename TS>
 void do_pass1(gprhip_problem* p, const gprhip_hypers* h, int want_grad, int64_t n_total, double* ar1) {
+  if (!h || !h->inducing) {
+    set_error("gprhip: hypers/inducing pointer is NULL");
+    throw HipFail{ST_BAD_ARG};
+  }
   if (!p->have_inputs || (!p->have_targets && !h->model_only)) {
     set_error("gprhip: inputs/targets not set");
     throw HipFail{ST_STATE};
   }
   GPR_HIP(hipSetDevice(p->device));
   hipStream_t s = p->stream;
+  // the state of the previous evaluation is void from here on; finish() re-validates it
+  p->have_model = p->have_factors = false;
+  p->stage = 0;
   upload_hypers(p, h);
   p->want_grad = want_grad;
   p->n_total = n_total;
   const int mp = p->mp;
   const int64_t mm = (int64_t)mp * mp;
-  double* ar1_c = ar1 + mm;
+  double* ar1_c = ar1 + packed_upper_len(mp);
   double* ar1_tail = ar1_c + mp;
   if (!p->Vstore)  // V = K U^-1 for all rows of the shard stays resident (one SYRK launch; pass 2 re-reads it)
     p->Vstore = p->alloc<TS>((int64_t)p->nchunks * p->chunk * mp);
@@ -459,10 +478,11 @@ void do_pass1(gprhip_problem* p, const gprhip_hypers* h, int want_grad, int64_t 
   TS* const slices = static_cast<TS*>(p->slices);
 
   const bool reuse = h->reuse_v != 0;
-  if (reuse && !p->have_model) {
-    set_error("gprhip: reuse_v set but there is no previous evaluation on this problem");
+  if (reuse && !p->have_v) {
+    set_error("gprhip: reuse_v set but this problem holds no V of a previous evaluation");
     throw HipFail{ST_STATE};
   }
+  p->have_v = false;
   tstart(p, "km_chol");
   GPR_HIP(hipMemsetAsync(p->info, 0, 2 * sizeof(int), s));
   GPR_HIP(hipMemsetAsync(p->scal, 0, NSCAL * sizeof(double), s));
@@ -512,12 +532,24 @@ void do_pass1(gprhip_problem* p, const gprhip_hypers* h, int want_grad, int64_t 
   b.kslices = ks; b.slice_stride = mm;
   // c~ rides along: the diagonal-tile blocks of every k-slice also sum V[k][c] * (is*y)[k] over their rows
   b.cs_w = row_weights<TS>(p, p->yis, p->yis_f); b.cs_out = p->gemvpart;
+  if (p->timer.kernel) {
+    if (!p->timer.k0) {
+      GPR_HIP(hipEventCreate(&p->timer.k0));
+      GPR_HIP(hipEventCreate(&p->timer.k1));
+    }
+    GPR_HIP(hipEventRecord(p->timer.k0, s));
+  }
   launch_gemm(OP_TN, b, s);
+  if (p->timer.kernel) {
+    GPR_HIP(hipEventRecord(p->timer.k1, s));
+    p->timer.k_recorded = true;
+  }
   launch_reduce_rows(p->gemvpart, ks, mp, ar1_c, 1, s);
   tstop(p);
   p->ks_used = ks;
-  launch_sum_slices<TS>(nullptr, slices, ks, mm, mp, ar1, s);
+  launch_sum_slices<TS>(nullptr, slices, ks, mm, mp, ar1, s, 1);
   p->stage = 1;
+  p->have_v = true;  // (revoked by finish() if the factorisation of K_m turns out to have failed)
 }
 
 template <typename TS>
@@ -530,8 +562,8 @@ void do_pass2(gprhip_problem* p, const double* ar1, double* ar2) {
   hipStream_t s = p->stream;
   const int mp = p->mp;
   const int64_t mm = (int64_t)mp * mp;
-  const double* ar1_c = ar1 + mm;
-  double* ar2_col = ar2 + mm;
+  const double* ar1_c = ar1 + packed_upper_len(mp);
+  double* ar2_col = ar2 + packed_upper_len(mp);
   double* ar2_proj = ar2_col + p->col_rows() * mp;
   double* ar2_tail = ar2_proj + (int64_t)p->dbig() * p->d;
   const bool mo = p->h.model_only != 0;
@@ -556,7 +588,10 @@ void do_pass2(gprhip_problem* p, const double* ar1, double* ar2) {
   hipLaunchKernelGGL(dot_kernel, dim3(1), dim3(256), 0, s, p->bvec, p->bvec, mp, p->scal + SC_BB);
   tstop(p);
 
-  GPR_HIP(hipMemsetAsync(ar2, 0, (size_t)gprhip_ar2_len(p) * sizeof(double), s));
+  // evidence-only evaluations (multim_f) carry nothing in the second exchange buffer: only its scalar tail is cleared,
+  // and the caller need not reduce it
+  if (p->want_grad) GPR_HIP(hipMemsetAsync(ar2, 0, (size_t)gprhip_ar2_len(p) * sizeof(double), s));
+  else GPR_HIP(hipMemsetAsync(ar2_tail, 0, (size_t)A2_TAIL * sizeof(double), s));
   if (p->want_grad) {
     tstart(p, "inverses");
     triu_xxt(p, p->rinv, p->binv);  // B~^-1 (upper tiles)
@@ -647,7 +682,7 @@ void do_pass2(gprhip_problem* p, const double* ar1, double* ar2) {
     wg.kslices = p->ks_used; wg.slice_stride = mm;
     launch_gemm(OP_TN, wg, s);
     tstop(p);
-    launch_sum_slices<TS>(nullptr, slices, p->ks_used, mm, mp, ar2, s);
+    launch_sum_slices<TS>(nullptr, slices, p->ks_used, mm, mp, ar2, s, 1);
   }
   p->stage = 2;
 }
@@ -661,7 +696,7 @@ void do_finish(gprhip_problem* p, const double* ar2, gprhip_result* res, double*
   hipStream_t s = p->stream;
   const int mp = p->mp, m = p->m, d = p->d;
   const int64_t mm = (int64_t)mp * mp;
-  const double* ar2_col = ar2 + mm;
+  const double* ar2_col = ar2 + packed_upper_len(mp);
   const double* ar2_proj = ar2_col + p->col_rows() * mp;
   const double* ar2_tail = ar2_proj + (int64_t)p->dbig() * d;
   const int nkslab = (m + km_slab_rows() - 1) / km_slab_rows();
@@ -671,8 +706,7 @@ void do_finish(gprhip_problem* p, const double* ar2, gprhip_result* res, double*
     GemmArgs y;  // Y = W~ U^-T
     y.A = p->wtil; y.lda = mp; y.B = p->uinv; y.ldb = mp; y.C = p->kj; y.ldc = mp;  // kj is free after potrf; R~ stays in bmat
     y.M = mp; y.N = mp; y.K = mp; y.tri = TRI_KLO_BN;
-    int wks = ((int64_t)(mp / TILE) * (mp / TILE) <= 256 && mp >= 1024) ? 4 : 1;
-    if (const char* e = getenv("GPRHIP_WKS")) wks = atoi(e);
+    const int wks = ((int64_t)(mp / TILE) * (mp / TILE) <= 256 && mp >= 1024) ? 4 : 1;
     gemm_splitk(p, OP_NT, y, wks);
     GemmArgs w;  // W = U^-1 Y   (lib/fitc_gp.ml:1196-1203)
     w.A = p->uinv; w.lda = mp; w.B = p->kj; w.ldb = mp; w.C = p->wmat; w.ldc = mp;
@@ -707,14 +741,13 @@ void do_finish(gprhip_problem* p, const double* ar2, gprhip_result* res, double*
                              sizeof(double), (size_t)m, hipMemcpyDeviceToHost, s));
   }
   // scalar tail of the (reduced) exchange-1 buffer, kept in p->ar1 by pass 2
-  GPR_HIP(hipMemcpyAsync(ha1tail.data(), p->ar1 + mm + mp, A1_TAIL * sizeof(double),
+  GPR_HIP(hipMemcpyAsync(ha1tail.data(), p->ar1 + packed_upper_len(mp) + mp, A1_TAIL * sizeof(double),
                          hipMemcpyDeviceToHost, s));
   GPR_HIP(hipStreamSynchronize(s));
   p->stage = 0;
-  p->have_model = true;
-  p->have_factors = true;
-  if (p->timer.on) tcollect(p);
+  if (p->timer.on || p->timer.kernel) tcollect(p);
   if (hinfo[0] != 0 || hinfo[1] != 0) {
+    p->have_v = false;  // V came out of a failed factor
     char buf[160];
     snprintf(buf, sizeof buf,
              "Lacaml.D.potrf: leading minor of order %d of %s is not positive definite",
@@ -722,6 +755,8 @@ void do_finish(gprhip_problem* p, const double* ar2, gprhip_result* res, double*
     set_error(buf);
     throw HipFail{ST_NOT_POSDEF};
   }
+  p->have_model = true;
+  p->have_factors = true;
   const bool mo = p->h.model_only != 0;
   const double sum_log_s = ha1tail[A1_SUMLOGS], sum_isr = ha1tail[A1_ISR], sum_isy2 = ha1tail[A1_ISY2];
   // l1: lib/fitc_gp.ml:204-208 with log|R^T R| - log|K_m| = log|B~| ; variational: :262-263
@@ -1111,6 +1146,7 @@ void do_load_predictor(gprhip_problem* p, const gprhip_hypers* h, const double* 
   hipStream_t s = p->stream;
   const int mp = p->mp, m = p->m;
   const int64_t mm = (int64_t)mp * mp;
+  p->have_model = p->have_factors = p->have_v = false;
   upload_hypers(p, h);
   std::vector<double> t(mp, 0.0);
   if (coeffs) std::memcpy(t.data(), coeffs, (size_t)m * sizeof(double));
@@ -1143,12 +1179,22 @@ void do_load_predictor(gprhip_problem* p, const gprhip_hypers* h, const double* 
   p->h.model_only = coeffs ? 0 : 1;
 }
 
+void tdrop(gprhip_problem* p) {  // a failed evaluation leaves its stage timers behind
+  if (!p) return;
+  for (auto& e : p->timer.ev) {
+    hipEventDestroy(e.second.first);
+    hipEventDestroy(e.second.second);
+  }
+  p->timer.ev.clear();
+}
+
 template <typename F>
-int guarded(F&& f) {
+int guarded(F&& f, gprhip_problem* p = nullptr) {
   try {
     f();
     return GPRHIP_OK;
   } catch (const HipFail& e) {
+    tdrop(p);
     return e.status;
   } catch (const std::bad_alloc&) {
     set_error("gprhip: host allocation failed");
@@ -1212,7 +1258,10 @@ int gprhip_problem_create_ex(int device, int cov_kind, int precision, int64_t n,
     p->kslices = (int)std::max<int64_t>(8, std::min<int64_t>((round_up(n, p->slice_rows) / p->slice_rows + 23) / 8 * 8,
                                                               (40LL << 30) / (p->mp * (int64_t)p->mp * 8) / 8 * 8));
     if (const char* e = getenv("GPRHIP_KSLICES")) p->kslices = std::max(8, atoi(e) / 8 * 8);
-    if (const char* e = getenv("GPRHIP_TIMING")) p->timer.on = atoi(e) != 0;
+    if (const char* e = getenv("GPRHIP_TIMING")) {
+      p->timer.on = atoi(e) >= 2;
+      p->timer.kernel = atoi(e) >= 1;
+    }
     if (const char* e = getenv("GPRHIP_TILE_ORDER")) p->tile_order = atoi(e);
     if (const char* e = getenv("GPRHIP_GRAD_SCALAR")) p->grad_scalar = atoi(e);
     GPR_HIP(hipStreamCreate(&p->stream));
@@ -1258,7 +1307,7 @@ int gprhip_problem_create_ex(int device, int cov_kind, int precision, int64_t n,
     p->zshift = p->alloc<double>(64);
     p->kmpart = p->alloc<double>((int64_t)((m + km_slab_rows() - 1) / km_slab_rows()) * p->km_rows() * mp);
     p->kmred = p->alloc<double>(p->km_rows() * mp);
-    p->ar1 = p->alloc<double>(mm + mp + A1_TAIL);
+    p->ar1 = p->alloc<double>(gprhip_ar1_len(p));
     p->ar2 = p->alloc<double>(gprhip_ar2_len(p));
     GPR_HIP(hipMemsetAsync(p->y, 0, (size_t)npad * sizeof(double), p->stream));
     GPR_HIP(hipStreamSynchronize(p->stream));
@@ -1271,6 +1320,10 @@ void gprhip_problem_destroy(gprhip_problem* p) {
   if (p->stream) {
     hipStreamSynchronize(p->stream);
     hipStreamDestroy(p->stream);
+  }
+  if (p->timer.k0) {
+    hipEventDestroy(p->timer.k0);
+    hipEventDestroy(p->timer.k1);
   }
   for (void* a : p->allocs) hipFree(a);
   delete p;
@@ -1339,9 +1392,9 @@ int64_t gprhip_n_hypers(const gprhip_problem* p, int flags) {
          ((flags & 4) ? (int64_t)p->d * p->m : 0);
 }
 
-int64_t gprhip_ar1_len(const gprhip_problem* p) { return (int64_t)p->mp * p->mp + p->mp + A1_TAIL; }
+int64_t gprhip_ar1_len(const gprhip_problem* p) { return p ? packed_upper_len(p->mp) + p->mp + A1_TAIL : 0; }
 int64_t gprhip_ar2_len(const gprhip_problem* p) {
-  return (int64_t)p->mp * p->mp + p->col_rows() * p->mp + (int64_t)p->dbig() * p->d + A2_TAIL;
+  return p ? packed_upper_len(p->mp) + p->col_rows() * p->mp + (int64_t)p->dbig() * p->d + A2_TAIL : 0;
 }
 
 int gprhip_eval_pass1(gprhip_problem* p, const gprhip_hypers* h, int want_grad, int64_t n_total,
@@ -1353,7 +1406,7 @@ int gprhip_eval_pass1(gprhip_problem* p, const gprhip_hypers* h, int want_grad, 
     }
     if (p->f32) do_pass1<float>(p, h, want_grad, n_total, d_ar1);
     else do_pass1<double>(p, h, want_grad, n_total, d_ar1);
-  });
+  }, p);
 }
 
 int gprhip_eval_pass2(gprhip_problem* p, const double* d_ar1, double* d_ar2) {
@@ -1368,7 +1421,7 @@ int gprhip_eval_pass2(gprhip_problem* p, const double* d_ar1, double* d_ar2) {
                              hipMemcpyDeviceToDevice, p->stream));
     if (p->f32) do_pass2<float>(p, p->ar1, d_ar2);
     else do_pass2<double>(p, p->ar1, d_ar2);
-  });
+  }, p);
 }
 
 int gprhip_eval_finish(gprhip_problem* p, const double* d_ar2, gprhip_result* res, double* grad,
@@ -1379,7 +1432,7 @@ int gprhip_eval_finish(gprhip_problem* p, const double* d_ar2, gprhip_result* re
       throw HipFail{ST_BAD_ARG};
     }
     do_finish(p, d_ar2, res, grad, coeffs);
-  });
+  }, p);
 }
 
 int gprhip_eval(gprhip_problem* p, const gprhip_hypers* h, int want_grad, gprhip_result* res,
@@ -1397,7 +1450,7 @@ int gprhip_eval(gprhip_problem* p, const gprhip_hypers* h, int want_grad, gprhip
       do_pass2<double>(p, p->ar1, p->ar2);
     }
     do_finish(p, p->ar2, res, grad, coeffs);
-  });
+  }, p);
 }
 
 int gprhip_predict(gprhip_problem* p, const double* test_inputs, int64_t ld, int64_t nt, int predictive,
@@ -1468,6 +1521,10 @@ int gprhip_load_predictor(gprhip_problem* p, const gprhip_hypers* h, const doubl
 
 int gprhip_sync(gprhip_problem* p) {
   return guarded([&] {
+    if (!p) {
+      set_error("gprhip_sync: NULL problem");
+      throw HipFail{ST_BAD_ARG};
+    }
     GPR_HIP(hipSetDevice(p->device));
     GPR_HIP(hipStreamSynchronize(p->stream));
   });
@@ -1475,8 +1532,23 @@ int gprhip_sync(gprhip_problem* p) {
 
 void* gprhip_stream(gprhip_problem* p) { return p ? (void*)p->stream : nullptr; }
 
+int gprhip_set_timing(gprhip_problem* p, int level) {
+  return guarded([&] {
+    if (!p || level < 0 || level > 2) {
+      set_error("gprhip_set_timing: invalid arguments");
+      throw HipFail{ST_BAD_ARG};
+    }
+    p->timer.kernel = level >= 1;
+    p->timer.on = level >= 2;
+  });
+}
+
 int gprhip_debug_fetch(gprhip_problem* p, const char* name, double* out, int64_t len) {
   return guarded([&] {
+    if (!p || !out) {
+      set_error("gprhip_debug_fetch: NULL argument");
+      throw HipFail{ST_BAD_ARG};
+    }
     const double* src = nullptr;
     int64_t avail = 0;
     std::string nm = name ? name : "";
@@ -1507,6 +1579,7 @@ int gprhip_debug_fetch(gprhip_problem* p, const char* name, double* out, int64_t
 }
 
 int gprhip_last_timings(gprhip_problem* p, const char** names, float* ms, int cap) {
+  if (!p || !names || !ms) return 0;
   int n = (int)std::min<size_t>(p->tnames.size(), (size_t)cap);
   for (int i = 0; i < n; ++i) {
     names[i] = p->tnames[i].c_str();

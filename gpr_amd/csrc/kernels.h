@@ -159,7 +159,7 @@ void launch_grad_fused(const GradArgs<TS>& a, hipStream_t s);
 // dst (upper tiles) = base + sum_z slices[z]
 template <typename TS>
 void launch_sum_slices(const double* base, const TS* slices, int nslices, int64_t stride, int mp,
-                       double* dst, hipStream_t s);
+                       double* dst, hipStream_t s, int packed = 0);
 // dst (float) = src (double), n elements: fp32 copies of U^-1 / R~^-1 for the fp32 contractions
 void launch_to_float(const double* src, float* dst, int64_t n, hipStream_t s);
 // W~ = I - B~^-1 - t~ t~^T - G~ as a full symmetric matrix (inputs valid on upper tiles);

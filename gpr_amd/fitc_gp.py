@@ -54,7 +54,8 @@ class _Inputs:
 
     @property
     def problem(self):
-        if self._problem is None:
+        # (the functor's cache may have evicted and closed the problem since: make it again)
+        if self._problem is None or not self._problem.is_open():
             self._problem = self._make_problem()
         return self._problem
 
@@ -120,6 +121,10 @@ def _run(model, targets, want_grad, owner):
     # this very kernel object and inducing matrix, only sigma2 changed -> K_nm, V, r stay on the device
     sig = (id(kernel), id(inputs.inducing.points))
     reuse = getattr(prob, "_last_sig", None) == sig
+    # the device state belongs to nobody while the evaluation runs: if it raises (e.g. NotPositiveDefinite, which the
+    # optimiser driver catches and survives), no earlier model may go on predicting from -- or reusing V of -- a
+    # half-overwritten state
+    prob._last_sig = prob._state_owner = None
     ev = prob.eval(sigma2=model.sigma2, inducing=inputs.inducing.points, variational=model.variational,
                    model_only=targets is None, want_grad=want_grad, jitter=prob._jitter, reuse_v=reuse,
                    **spec.eval_args(kernel))
@@ -178,7 +183,7 @@ def _make_variant(spec, variational, functor, cov_kind="FITC"):
         if inducing.points.shape[0] != d:
             raise ValueError("Inputs.calc: inducing points have dimension %d, kernel space has %d"
                              % (inducing.points.shape[0], d))
-        key = (id(points), points.shape, m, d, device)
+        key = (id(points), points.shape, m, d, device, chunk_rows)
 
         def make_problem():
             prob = functor._problems.get(key)
@@ -344,7 +349,7 @@ def _make_variant(spec, variational, functor, cov_kind="FITC"):
         except ValueError:
             raise ValueError("%s_covariances.calc: co-variance predictor and inputs disagree about "
                              "inducing points" % cov_kind) from None                # :537-546
-        return _Covariances(inputs.points, prob.covariances(inputs.points, kind=cov_kind), sigma2, prob)
+        return _Covariances(inputs.points, prob.covariances(inputs.points, kind=cov_kind, predictive=False), sigma2, prob)
 
     def covariances_get(c, predictive=True):
         if not predictive:

@@ -47,6 +47,14 @@ class Problem:
             self._lib.gprhip_problem_destroy(self._h)
             self._h = C.c_void_p()
 
+    def is_open(self):
+        return bool(self._h)
+
+    def _handle(self):
+        if not self._h:
+            raise _lib.GprHipError(_lib.ESTATE, "gpr_amd.Problem: the problem has been closed")
+        return self._h
+
     def __del__(self):
         try:
             self.close()
@@ -59,26 +67,26 @@ class Problem:
         x = np.asfortranarray(inputs, dtype=np.float64)
         if x.shape != (self.D, self.n):
             raise ValueError("set_inputs: expected shape (%d, %d), got %s" % (self.D, self.n, x.shape))
-        _lib.check(self._lib.gprhip_set_inputs(self._h, _f64_ptr(x), self.D))
+        _lib.check(self._lib.gprhip_set_inputs(self._handle(), _f64_ptr(x), self.D))
 
     def set_targets(self, targets):
         y = np.ascontiguousarray(targets, dtype=np.float64)
         if y.shape != (self.n,):
             # Trained.calc: Vec.dim targets <> n  (lib/fitc_gp.ml:283-284)
             raise ValueError("Trained.calc: Vec.dim targets (%d) <> n (%d)" % (y.shape[0], self.n))
-        _lib.check(self._lib.gprhip_set_targets(self._h, _f64_ptr(y)))
+        _lib.check(self._lib.gprhip_set_targets(self._handle(), _f64_ptr(y)))
 
     def set_inputs_device(self, ptr):
         """ptr: device address of a contiguous point-major [n][D] fp64 array (e.g. tensor.data_ptr())."""
-        _lib.check(self._lib.gprhip_set_inputs_device(self._h, C.c_void_p(ptr)))
+        _lib.check(self._lib.gprhip_set_inputs_device(self._handle(), C.c_void_p(ptr)))
 
     def set_targets_device(self, ptr):
-        _lib.check(self._lib.gprhip_set_targets_device(self._h, C.c_void_p(ptr)))
+        _lib.check(self._lib.gprhip_set_targets_device(self._handle(), C.c_void_p(ptr)))
 
     # ---- evaluation
     def n_hypers(self, has_tproj=False, has_hetero=False, has_multiscale=False):
         flags = int(has_tproj) | (int(has_hetero) << 1) | (int(has_multiscale) << 2)
-        return int(self._lib.gprhip_n_hypers(self._h, flags))
+        return int(self._lib.gprhip_n_hypers(self._handle(), flags))
 
     def _hypers(self, log_ell, log_sf2, sigma2, inducing, tproj, variational, model_only, jitter,
                 log_hetero_skedasticity=None, log_multiscales_m05=None, reuse_v=False):
@@ -122,7 +130,7 @@ class Problem:
         nh = self.n_hypers(tproj is not None, log_hetero_skedasticity is not None, log_multiscales_m05 is not None)
         grad = np.empty(nh if want_grad else 1, dtype=np.float64)
         coeffs = np.empty(self.m, dtype=np.float64)
-        _lib.check(self._lib.gprhip_eval(self._h, C.byref(h), int(want_grad), C.byref(res),
+        _lib.check(self._lib.gprhip_eval(self._handle(), C.byref(h), int(want_grad), C.byref(res),
                                          _f64_ptr(grad), _f64_ptr(coeffs)))
         del keep
         return Evaluation(res.l1, res.l2, res.l, res.dl_dsigma2 if want_grad else None,
@@ -138,7 +146,7 @@ class Problem:
         nt = xt.shape[1]
         means = np.empty(nt, dtype=np.float64)
         var = np.empty(nt, dtype=np.float64) if want_variances else None
-        _lib.check(self._lib.gprhip_predict(self._h, _f64_ptr(xt), self.D, nt, int(predictive), _f64_ptr(means),
+        _lib.check(self._lib.gprhip_predict(self._handle(), _f64_ptr(xt), self.D, nt, int(predictive), _f64_ptr(means),
                                             _f64_ptr(var) if want_variances else None))
         return means, var
 
@@ -148,11 +156,11 @@ class Problem:
         Returns (sums = [sse, sum|y-mean|, max|y-mean|, sum y^2], means or None)."""
         sums = np.empty(4, dtype=np.float64)
         means = np.empty(self.n, dtype=np.float64) if want_means else None
-        _lib.check(self._lib.gprhip_train_stats(self._h, _f64_ptr(means) if want_means else None,
+        _lib.check(self._lib.gprhip_train_stats(self._handle(), _f64_ptr(means) if want_means else None,
                                                 _f64_ptr(sums)))
         return sums, means
 
-    def covariances(self, test_inputs, kind="FITC", predictive=False):
+    def covariances(self, test_inputs, kind="FITC", predictive=True):
         """FITC_covariances.calc / FIC_covariances.calc (lib/fitc_gp.ml:585-599, :617-627): nt x nt posterior
         covariance between the test points (full symmetric matrix)."""
         xt = np.asfortranarray(test_inputs, dtype=np.float64)
@@ -160,7 +168,7 @@ class Problem:
             raise ValueError("covariances: expected test inputs of shape (%d, nt)" % self.D)
         nt = xt.shape[1]
         cov = np.empty((nt, nt), dtype=np.float64, order="F")
-        _lib.check(self._lib.gprhip_covariances(self._h, _f64_ptr(xt), self.D, nt, {"FITC": 0, "FIC": 1}[kind],
+        _lib.check(self._lib.gprhip_covariances(self._handle(), _f64_ptr(xt), self.D, nt, {"FITC": 0, "FIC": 1}[kind],
                                                 int(predictive), _f64_ptr(cov)))
         return cov
 
@@ -177,7 +185,7 @@ class Problem:
             raise ValueError("cov_samples: shapes of covariances/means/z disagree")
         ns = z.shape[1]
         out = np.empty((nt, ns), dtype=np.float64, order="F")
-        _lib.check(self._lib.gprhip_cov_samples(self._h, _f64_ptr(cov), nt, nt, float(add_diag), float(jitter),
+        _lib.check(self._lib.gprhip_cov_samples(self._handle(), _f64_ptr(cov), nt, nt, float(add_diag), float(jitter),
                                                 _f64_ptr(means), _f64_ptr(z), ns, _f64_ptr(out)))
         return out
 
@@ -187,7 +195,7 @@ class Problem:
         m x m upper-triangular Fortran matrix."""
         u = np.empty((self.m, self.m), dtype=np.float64, order="F")
         r = np.empty((self.m, self.m), dtype=np.float64, order="F")
-        _lib.check(self._lib.gprhip_co_variance_coeffs(self._h, _f64_ptr(u), _f64_ptr(r)))
+        _lib.check(self._lib.gprhip_co_variance_coeffs(self._handle(), _f64_ptr(u), _f64_ptr(r)))
         return u, r
 
     def load_predictor(self, *, log_sf2, sigma2, inducing, coeffs=None, co_variance_coeffs=None, log_ell=0.0,
@@ -208,59 +216,63 @@ class Problem:
             r = np.asfortranarray(co_variance_coeffs[1], dtype=np.float64)
             if u.shape != (self.m, self.m) or r.shape != (self.m, self.m):
                 raise ValueError("Co_variance_predictor.calc: expected two %d x %d factors" % (self.m, self.m))
-        _lib.check(self._lib.gprhip_load_predictor(self._h, C.byref(h), _f64_ptr(c) if c is not None else None,
+        _lib.check(self._lib.gprhip_load_predictor(self._handle(), C.byref(h), _f64_ptr(c) if c is not None else None,
                                                    _f64_ptr(u) if u is not None else None,
                                                    _f64_ptr(r) if r is not None else None))
         del keep
 
     # ---- staged evaluation (row-sharded across devices; see gpr_amd/dist.py)
     def ar1_len(self):
-        return int(self._lib.gprhip_ar1_len(self._h))
+        return int(self._lib.gprhip_ar1_len(self._handle()))
 
     def ar2_len(self):
-        return int(self._lib.gprhip_ar2_len(self._h))
+        return int(self._lib.gprhip_ar2_len(self._handle()))
 
     def eval_pass1(self, ar1_ptr, n_total, *, log_sf2, sigma2, inducing, log_ell=0.0, tproj=None,
                    variational=False, model_only=False, want_grad=True, jitter=CHOLESKY_JITTER,
-                   log_hetero_skedasticity=None, log_multiscales_m05=None):
+                   log_hetero_skedasticity=None, log_multiscales_m05=None, reuse_v=False):
         h, keep = self._hypers(log_ell, log_sf2, sigma2, inducing, tproj, variational, model_only, jitter,
-                               log_hetero_skedasticity, log_multiscales_m05)
+                               log_hetero_skedasticity, log_multiscales_m05, reuse_v)
         self._has_ms = log_multiscales_m05 is not None
         self._want_grad = bool(want_grad)
         self._has_tproj = tproj is not None
         self._has_het = log_hetero_skedasticity is not None
-        _lib.check(self._lib.gprhip_eval_pass1(self._h, C.byref(h), int(want_grad), int(n_total),
+        _lib.check(self._lib.gprhip_eval_pass1(self._handle(), C.byref(h), int(want_grad), int(n_total),
                                                C.c_void_p(ar1_ptr)))
         del keep  # the library copies borrowed host buffers before returning
 
     def eval_pass2(self, ar1_ptr, ar2_ptr):
-        _lib.check(self._lib.gprhip_eval_pass2(self._h, C.c_void_p(ar1_ptr), C.c_void_p(ar2_ptr)))
+        _lib.check(self._lib.gprhip_eval_pass2(self._handle(), C.c_void_p(ar1_ptr), C.c_void_p(ar2_ptr)))
 
     def eval_finish(self, ar2_ptr):
         res = Result()
         nh = self.n_hypers(self._has_tproj, self._has_het, self._has_ms)
         grad = np.empty(nh if self._want_grad else 1, dtype=np.float64)
         coeffs = np.empty(self.m, dtype=np.float64)
-        _lib.check(self._lib.gprhip_eval_finish(self._h, C.c_void_p(ar2_ptr), C.byref(res),
+        _lib.check(self._lib.gprhip_eval_finish(self._handle(), C.c_void_p(ar2_ptr), C.byref(res),
                                                 _f64_ptr(grad), _f64_ptr(coeffs)))
         return Evaluation(res.l1, res.l2, res.l, res.dl_dsigma2 if self._want_grad else None,
                           grad[:res.n_hypers] if self._want_grad else None, coeffs)
 
     def sync(self):
-        _lib.check(self._lib.gprhip_sync(self._h))
+        _lib.check(self._lib.gprhip_sync(self._handle()))
 
     def stream(self):
-        return self._lib.gprhip_stream(self._h)
+        return self._lib.gprhip_stream(self._handle())
 
     # ---- diagnostics
+    def set_timing(self, level):
+        """0: none; 1: HIP events around the dominant kernel (pass-1 SYRK); 2: around every stage."""
+        _lib.check(self._lib.gprhip_set_timing(self._handle(), int(level)))
+
     def debug_fetch(self, name):
         length = self.m if name == "t" else self.n
         out = np.empty(length, dtype=np.float64)
-        _lib.check(self._lib.gprhip_debug_fetch(self._h, name.encode(), _f64_ptr(out), length))
+        _lib.check(self._lib.gprhip_debug_fetch(self._handle(), name.encode(), _f64_ptr(out), length))
         return out
 
     def last_timings(self):
         names = (C.c_char_p * 32)()
         ms = (C.c_float * 32)()
-        k = self._lib.gprhip_last_timings(self._h, names, ms, 32)
+        k = self._lib.gprhip_last_timings(self._handle(), names, ms, 32)
         return {names[i].decode(): float(ms[i]) for i in range(k)}

@@ -201,8 +201,12 @@ int gprhip_load_predictor(gprhip_problem* p, const gprhip_hypers* h, const doubl
  *   "r" n, "is" n, "v" n, "w" n, "t" m.  Returns GPRHIP_EBADARG for an unknown name. */
 int gprhip_debug_fetch(gprhip_problem* p, const char* name, double* out, int64_t len);
 
-/* Per-stage timing of the last gprhip_eval (milliseconds, HIP events): fills up to `cap` entries of
- * names/ms; returns the count. */
+/* Timing of evaluations with HIP events on the problem's own stream.  level 0: none (default; GPRHIP_TIMING in the
+ * environment sets the initial level); 1: one event pair around the dominant kernel alone (the pass-1 SYRK launch over
+ * the shard's training points, reported as "kernel_p1_syrk_B"); 2: also a pair around every stage of the evaluation. */
+int gprhip_set_timing(gprhip_problem* p, int level);
+
+/* Timings of the last evaluation (milliseconds): fills up to `cap` entries of names/ms; returns the count. */
 int gprhip_last_timings(gprhip_problem* p, const char** names, float* ms, int cap);
 
 const char* gprhip_last_error(void);

@@ -48,6 +48,35 @@ def save(name, k, X, y, Z, sigma2, variational, extra):
     print(name, "l=%.12g" % out["l"], "n_hypers=%d" % len(out["grad"]))
 
 
+def mp_truth(k, X, y, Z, sigma2, dps=40):
+    """l1, l2 and the mean coefficients of FITC in `dps`-digit arithmetic from the dense definition
+    (doc/manual/gpr_manual.tex:694-701), starting from the double-precision covariance entries."""
+    import mpmath as mp
+    mp.mp.dps = dps
+    n, m = X.shape[1], Z.shape[1]
+    km, _ = O.spec_calc_shared_upper(k, Z)
+    km = np.triu(km) + np.triu(km, 1).T
+    knm, _ = O.spec_calc_shared_cross(k, X, Z)
+    Km = mp.matrix(km.tolist()) + mp.mpf(O.CHOLESKY_JITTER) * mp.eye(m)
+    Knm = mp.matrix(knm.tolist())
+    A1 = Knm * (Km ** -1)
+    s = [mp.mpf(k.sf2) - sum(A1[i, j] * Knm[i, j] for j in range(m)) + mp.mpf(sigma2) for i in range(n)]
+    B = Km.copy()
+    for i in range(n):
+        for a in range(m):
+            for b in range(a, m):
+                B[a, b] += Knm[i, a] * Knm[i, b] / s[i]
+    for a in range(m):
+        for b in range(a):
+            B[a, b] = B[b, a]
+    yv = [mp.mpf(float(v)) for v in y]
+    c = mp.matrix([sum(Knm[i, a] * yv[i] / s[i] for i in range(n)) for a in range(m)])
+    t = mp.lu_solve(B, c)
+    l1 = -mp.mpf(0.5) * (mp.log(mp.det(B)) - mp.log(mp.det(Km)) + sum(mp.log(si) for si in s) + n * mp.log(2 * mp.pi))
+    l2 = -mp.mpf(0.5) * (sum(yv[i] ** 2 / s[i] for i in range(n)) - sum(c[a] * t[a] for a in range(m)))
+    return float(l1), float(l2), np.array([float(v) for v in t])
+
+
 def save_posterior(name, k, X, y, Z, sigma2, Xt, z, extra):
     """Posterior quantities either side of the evidence path: Means/Variances,
     FITC_/FIC_covariances, Cov_sampler with the given draws z, Stats."""
@@ -123,6 +152,17 @@ def main():
     kn = O.SeFatKernel(4, -0.1, None)
     save("fat_noproj", kn, Xa, ya, np.asfortranarray(Xa[:, :16] + 0.01), 0.2, False,
          dict(kind="fat", d=4, log_sf2=-0.1))
+    # Jitter-dominated K_m (ell = e, cond(K_m + jitter) ~ 1e7 .. 4e7): the regime where forming B = K_m + K_mn S^-1 K_nm
+    # and factoring it loses 1e-5 (lib/fitc_gp.ml:170-182 is why the reference uses QR).  C1 shape with the
+    # oracle's values, and a small case that also carries a 40-digit evaluation.
+    X, y, Z = synth(1, 2000, 50, 3)
+    for tag, s2 in (("lo", 1e-4), ("hi", 1.0)):
+        save("illcond_c1_" + tag, O.SeIsoKernel(1.0, 0.0), X, y, Z, s2, False, dict(kind="iso", log_ell=1.0, log_sf2=0.0))
+    X, y, Z = synth(5, 200, 30, 3)
+    for tag, s2 in (("lo", 1e-4), ("hi", 1.0)):
+        l1, l2, t = mp_truth(O.SeIsoKernel(1.0, 0.0), X, y, Z, s2)
+        save("illcond_small_" + tag, O.SeIsoKernel(1.0, 0.0), X, y, Z, s2, False,
+             dict(kind="iso", log_ell=1.0, log_sf2=0.0, mp_l1=l1, mp_l2=l2, mp_coeffs=t))
     # posterior fixtures: iso at a ragged size, and Cov_se_fat with projection + hetero + multiscales
     # (K_tt of the covariances is the plain kernel of the projected test points, lib/cov_se_fat.ml:221)
     prng = np.random.default_rng(99)

@@ -115,7 +115,10 @@ def _worker(rank, world, port, q):
         sp.set_inputs(X[:, lo:hi])
         sp.set_targets(y[lo:hi])
         ev = sp.eval(log_ell=0.4, log_sf2=0.0, sigma2=0.1, inducing=Z)
+        c_grad = sp.collectives
         ev0 = sp.eval(log_ell=0.4, log_sf2=0.0, sigma2=0.1, inducing=Z, want_grad=False)
+        # two collectives per gradient evaluation, one per evidence-only evaluation
+        assert c_grad == 2 and sp.collectives - c_grad == 1, (c_grad, sp.collectives)
         q.put((rank, ev.l, ev.dl_dsigma2, ev.grad, ev0.l))
     finally:
         dist.destroy_process_group()

@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 
 from oracle import fitc_oracle as O
-from tests.util import (STAT_KEYS, golden_names, load_golden, oracle_kernel, posterior_golden_names, relinf,
+from tests.util import (STAT_KEYS, golden_names, illcond_golden_names, load_golden, oracle_kernel, posterior_golden_names, relinf,
                         synth)
 
 
@@ -305,3 +305,37 @@ def test_against_snelson_spgp_lik(shape):
     assert abs(g[1] - (-dfc)) < 1e-8 * scale                                          # eds_dlog_sf2
     assert abs(out["dl_dsigma2"] - (-dfsig / sigma2)) < 1e-8 * abs(out["dl_dsigma2"])  # eds_dsigma2
     assert np.max(np.abs(g[2:].reshape(m, d) - (-dfxb))) < 1e-8 * scale               # pseudo-inputs
+
+
+def test_c_restatement_agrees_with_numpy_oracle():
+    """oracle/fitc_ref.c (the reference's LAPACK sequence in C, also the timed CPU baseline) against
+    oracle/fitc_oracle.py on the C1 shape and on a ragged one: two independent restatements of lib/fitc_gp.ml."""
+    from oracle import fitc_ref as R
+    for seed, n, m, d, le, lsf, s2 in ((1, 2000, 50, 3, 0.5 * np.log(3), 0.0, 0.1), (7, 777, 33, 5, 0.9, -0.3, 0.02)):
+        rng = np.random.default_rng(seed)
+        X = np.asfortranarray(rng.normal(size=(d, n)))
+        y = np.sin(X.sum(0)) + 0.1 * rng.normal(size=n)
+        Z = np.asfortranarray(X[:, rng.permutation(n)[:m]] + 0.01 * rng.normal(size=(d, m)))
+        ref = O.evaluate(O.SeIsoKernel(le, lsf), Z, X, y, s2)
+        for threads in (1, 4):
+            got = R.iso_eval(X, y, Z, le, lsf, s2, threads=threads)
+            assert abs(got["l"] - ref["l"]) <= 1e-10 * abs(ref["l"])
+            assert abs(got["l1"] - ref["l1"]) <= 1e-10 * abs(ref["l1"])
+            assert abs(got["dl_dsigma2"] - ref["dl_dsigma2"]) <= 1e-9 * abs(ref["dl_dsigma2"])
+            assert np.max(np.abs(got["grad"] - ref["grad"])) <= 1e-9 * np.max(np.abs(ref["grad"]))
+            assert np.max(np.abs(got["coeffs"] - ref["coeffs"])) <= 1e-9 * np.max(np.abs(ref["coeffs"]))
+
+
+@pytest.mark.parametrize("name", illcond_golden_names())
+def test_ill_conditioned_fixtures(name):
+    """Jitter-dominated K_m (ell = e, cond ~ 1e7): the fixtures reproduce, and where a 40-digit evaluation is stored
+    the oracle's QR path (lib/fitc_gp.ml:170-182) stays within 1e-10 of it on l1 and l2 -- the accuracy the device path's
+    whitened SYRK + potrf has to match (tests/test_gpu_parity.py::test_ill_conditioned_regime)."""
+    g = load_golden(name)
+    out = O.evaluate(oracle_kernel(g), g["Z"], g["X"], g["y"], float(g["sigma2"]))
+    assert abs(out["l"] - float(g["l"])) <= 1e-12 * abs(float(g["l"]))
+    assert relinf(out["grad"], g["grad"]) <= 1e-10
+    if "mp_l1" in g:
+        assert abs(out["l1"] - float(g["mp_l1"])) <= 1e-10 * abs(float(g["mp_l1"]))
+        assert abs(out["l2"] - float(g["mp_l2"])) <= 1e-10 * abs(float(g["mp_l2"]))
+        assert relinf(out["coeffs"], g["mp_coeffs"]) <= 1e-9

@@ -14,7 +14,12 @@ def _names():
 
 def golden_names():
     """Evidence + gradient fixtures."""
-    return [n for n in _names() if not n.startswith("posterior_")]
+    return [n for n in _names() if not n.startswith("posterior_") and not n.startswith("illcond_")]
+
+
+def illcond_golden_names():
+    """Jitter-dominated K_m (ell = e): the regime SURVEY.md 7 singles out; own stated tolerances."""
+    return [n for n in _names() if n.startswith("illcond_")]
 
 
 def posterior_golden_names():

@@ -47,7 +47,7 @@ def main():
     t_var, (mu, var) = timed(lambda: p.predict(Xt, predictive=False))
     t_stats, (sums, _) = timed(lambda: p.train_stats())
     Xc = np.asfortranarray(Xt[:, :a.cov])
-    t_cov, cov = timed(lambda: p.covariances(Xc, kind="FITC"))
+    t_cov, cov = timed(lambda: p.covariances(Xc, kind="FITC", predictive=False))
     z = rng.normal(size=(a.cov, 64))
     t_smp, S = timed(lambda: p.cov_samples(cov, mu[:a.cov], z, add_diag=0.1))
     assert np.all(np.isfinite(S)) and np.all(var > -1e-9)

@@ -12,10 +12,10 @@ out=$root/gpurun_out
 mkdir -p "$out"
 python3 bench.py --steps 5 --warmup 2 > "$out/${tag}_bench.json" 2> "$out/${tag}_bench.err"
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -d "$out/${tag}_stats" -- python3 "$root/bench.py" --steps 2 --warmup 1 --no-cpu-baseline > "$out/${tag}_stats.log" 2>&1
-rocprofv3 --pmc FETCH_SIZE --kernel-trace -d "$out/${tag}_pmc_f" -- python3 "$root/bench.py" --steps 1 --warmup 1 --no-cpu-baseline > "$out/${tag}_pmc_f.log" 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace -d "$out/${tag}_pmc_w" -- python3 "$root/bench.py" --steps 1 --warmup 1 --no-cpu-baseline > "$out/${tag}_pmc_w.log" 2>&1
-rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_F64 --kernel-trace -d "$out/${tag}_pmc_m" -- python3 "$root/bench.py" --steps 1 --warmup 1 --no-cpu-baseline > "$out/${tag}_pmc_m.log" 2>&1
+rocprofv3 --kernel-trace --stats -d "$out/${tag}_stats" -- python3 "$root/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-configs > "$out/${tag}_stats.log" 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace -d "$out/${tag}_pmc_f" -- python3 "$root/bench.py" --steps 1 --warmup 1 --no-cpu-baseline --no-configs > "$out/${tag}_pmc_f.log" 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace -d "$out/${tag}_pmc_w" -- python3 "$root/bench.py" --steps 1 --warmup 1 --no-cpu-baseline --no-configs > "$out/${tag}_pmc_w.log" 2>&1
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_F64 --kernel-trace -d "$out/${tag}_pmc_m" -- python3 "$root/bench.py" --steps 1 --warmup 1 --no-cpu-baseline --no-configs > "$out/${tag}_pmc_m.log" 2>&1
 cd "$root"
 db() { ls "$out/$1"/*/*.db 2>/dev/null | head -1 || ls "$out/$1"/*.db | head -1; }
 python3 tools/rocpd_summary.py "$(db ${tag}_stats)" "$out/${tag}_kernel_stats.txt" > /dev/null
