@@ -16,7 +16,7 @@ toolchain exists in the build image, so the reference itself cannot be run.
 The oracle is pinned instead by (see tests/test_oracle.py):
   * Edward Snelson's SPGP routine test/spgp_lik.m -- the third-party code the
     reference keeps in its test directory and cross-checks itself against in
-    test/oct.m:183-191 -- restated in tests/snelson_spgp.py: evidence and the
+    test/oct.m:183-191 -- restated in oracle/snelson_spgp.py: evidence and the
     full gradient (length scale, amplitude, noise, every pseudo-input),
   * the algebraic identity  l1+l2 == dense textbook FITC log-likelihood,
   * central finite differences of that dense likelihood for every hyper,

@@ -73,3 +73,28 @@ def test_header_is_plain_c(tmp_path):
     out = subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"),
                           "-c", str(src), "-o", str(tmp_path / "use.o")], capture_output=True, text=True)
     assert out.returncode == 0, out.stderr
+
+
+def test_ocaml_stub_sources_cover_the_abi():
+    """bindings/gpr_hip_stubs.c (shipped uncompiled: no OCaml toolchain in the image) names only functions the header
+    declares, binds every entry point a host needs, and fills every field of gprhip_hypers."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    stubs = open(os.path.join(root, "bindings", "gpr_hip_stubs.c")).read()
+    header = open(os.path.join(root, "include", "gprhip.h")).read()
+    declared = set(re.findall(r"\b(gprhip_[a-z0-9_]+)\s*\(", header))
+    used = set(re.findall(r"\b(gprhip_(?!ml_)[a-z0-9_]+)\s*\(", stubs))
+    assert used <= declared, used - declared
+    needed = {"gprhip_problem_create_ex", "gprhip_problem_destroy", "gprhip_set_inputs", "gprhip_set_targets",
+              "gprhip_eval", "gprhip_n_hypers", "gprhip_predict", "gprhip_train_stats", "gprhip_covariances",
+              "gprhip_cov_samples", "gprhip_co_variance_coeffs", "gprhip_load_predictor", "gprhip_eval_pass1",
+              "gprhip_eval_pass2", "gprhip_eval_finish", "gprhip_ar1_len", "gprhip_ar2_len", "gprhip_last_error"}
+    assert needed <= used, needed - used
+    fields = re.search(r"typedef struct \{(.*?)\} gprhip_hypers;", header, re.S).group(1)
+    names = re.findall(r"(\w+);", fields)
+    assert len(names) == 11
+    for f in names:
+        assert "out->%s" % f in stubs, f
+    ml = open(os.path.join(root, "bindings", "gpr_hip.ml")).read()
+    for ext in re.findall(r'= "(gprhip_ml_[a-z0-9_]+)"', ml) + re.findall(r'"(gprhip_ml_[a-z0-9_]+)"\s+"', ml):
+        assert "value %s(" % ext in stubs, ext

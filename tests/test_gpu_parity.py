@@ -878,9 +878,9 @@ def test_cpp_host_mirror(tmp_path, name):
 
 
 def test_hip_path_against_snelson_spgp_lik():
-    """The HIP path against Edward Snelson's SPGP routine (test/spgp_lik.m, restated in tests/snelson_spgp.py) at the
+    """The HIP path against Edward Snelson's SPGP routine (test/spgp_lik.m, restated in oracle/snelson_spgp.py) at the
     BASELINE C1 shape -- the external cross-check the reference's own test/oct.m:183-191 performs."""
-    from tests.snelson_spgp import spgp_lik
+    from oracle.snelson_spgp import spgp_lik
     g = load_golden("iso_c1")
     X, y, Z = g["X"], g["y"], g["Z"]
     d, m = Z.shape

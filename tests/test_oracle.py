@@ -288,7 +288,7 @@ def test_against_snelson_spgp_lik(shape):
     """test/oct.m:183-191 compares the reference with Edward Snelson's SPGP routine (test/spgp_lik.m), which the
     reference ships in its test directory.  The same comparison here, for the oracle: evidence, d/dlog_ell,
     d/dlog_sf2, d/dsigma2 (oct.m's eds_* mappings) and, beyond oct.m, every pseudo-input coordinate."""
-    from tests.snelson_spgp import spgp_lik
+    from oracle.snelson_spgp import spgp_lik
     n, m, d = shape
     X, y, Z = synth(23, n, m, d)
     log_ell, log_sf2, sigma2 = 0.3, -0.2, 0.4
