@@ -174,22 +174,131 @@ __global__ __launch_bounds__(256) void cov_upper_kernel(CovParams cp, const doub
   }
 }
 
-// P[r][small] = sum_big tproj(big,small) * X[r][big]  -- dgemm ~transa:`T tproj inputs.
-// Accumulation order over `big` is increasing with FMA (BLAS dgemm does not promise an order).
-#pragma clang fp contract(fast)
-__global__ __launch_bounds__(256) void project_kernel(const double* __restrict__ X, int64_t n, int D,
-                                                      int d, const double* __restrict__ tproj,
-                                                      double* __restrict__ P) {
-  int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= n * d) return;
-  int64_t r = idx / d;
-  int small = (int)(idx % d);
-  const double* x = X + r * D;
-  const double* tp = tproj + (int64_t)small * D;
-  double acc = 0.0;
-  for (int b = 0; b < D; ++b) acc += tp[b] * x[b];
-  P[idx] = acc;
+// ---- point dimensions above 64 ("wide"): the dimension loop runs in chunks of 64 staged through LDS, the inducing
+// coordinates come from memory (cache-resident: 16 consecutive k share a line) instead of a register array.  Same
+// accumulation order as above (dimensions increasing, separate multiply and add).  No multiscales on this path.
+template <typename TS>
+__global__ __launch_bounds__(256) void cov_cross_wide_kernel(CovParams cp, const double* __restrict__ pts,
+                                                             int rows, int rows_p,
+                                                             const double* __restrict__ Z, int m, int mp,
+                                                             int d, TS* __restrict__ K) {
+  __shared__ double xs[32][64];
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  const int r0 = blockIdx.y * 32;
+  const bool live_col = j < m;
+  const double* zc = Z + (int64_t)min(j, m - 1) * d;
+  double acc[32];
+#pragma unroll
+  for (int i = 0; i < 32; ++i) acc[i] = 0.0;
+  for (int k0 = 0; k0 < d; k0 += 64) {
+    const int kc = min(64, d - k0);
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < 32 * 64; idx += 256) {
+      const int r = idx / 64, k = idx % 64;
+      xs[r][k] = (k < kc && r0 + r < rows) ? pts[(int64_t)(r0 + r) * d + k0 + k] : 0.0;
+    }
+    __syncthreads();
+    for (int k = 0; k < kc; ++k) {
+      const double z = zc[k0 + k];
+#pragma unroll
+      for (int i = 0; i < 32; ++i) {
+        const double diff = xs[i][k] - z;
+        acc[i] = acc[i] + diff * diff;
+      }
+    }
+  }
+  if (j >= mp) return;
+  const int nr = min(32, rows_p - r0);
+#pragma unroll
+  for (int i = 0; i < 32; ++i) {
+    if (i < nr) {
+      const double val = (r0 + i < rows && live_col) ? exp(cp.log_sf2 + cp.inv_ell2_05 * acc[i]) : 0.0;
+      K[(int64_t)(r0 + i) * mp + j] = (TS)val;
+    }
+  }
 }
+
+__global__ __launch_bounds__(256) void cov_upper_wide_kernel(CovParams cp, const double* __restrict__ Z, int m,
+                                                             int mp, int d, double jitter,
+                                                             const double* __restrict__ het,
+                                                             double* __restrict__ km, double* __restrict__ kj) {
+  __shared__ double xs[32][64];
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  const int r0 = blockIdx.y * 32;
+  const double* zc = Z + (int64_t)min(c, m - 1) * d;
+  double acc[32];
+#pragma unroll
+  for (int i = 0; i < 32; ++i) acc[i] = 0.0;
+  for (int k0 = 0; k0 < d; k0 += 64) {
+    const int kc = min(64, d - k0);
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < 32 * 64; idx += 256) {
+      const int r = idx / 64, k = idx % 64;
+      xs[r][k] = (k < kc && r0 + r < m) ? Z[(int64_t)(r0 + r) * d + k0 + k] : 0.0;
+    }
+    __syncthreads();
+    for (int k = 0; k < kc; ++k) {
+      const double z = zc[k0 + k];
+#pragma unroll
+      for (int i = 0; i < 32; ++i) {
+        const double diff = z - xs[i][k];
+        acc[i] = acc[i] + diff * diff;
+      }
+    }
+  }
+  if (c >= mp) return;
+#pragma unroll
+  for (int i = 0; i < 32; ++i) {
+    const int r = r0 + i;
+    if (r < mp) {
+      double val = 0.0, valj = 0.0;
+      if (r < m && c < m) {
+        if (r == c) {
+          val = cp.sf2;
+          valj = (het ? cp.sf2 + het[c] : cp.sf2) + jitter;
+        } else {
+          val = exp(cp.log_sf2 + cp.inv_ell2_05 * acc[i]);
+          valj = val;
+        }
+      } else if (r == c) {
+        valj = 1.0;
+      }
+      km[(int64_t)r * mp + c] = val;
+      kj[(int64_t)r * mp + c] = valj;
+    }
+  }
+}
+
+
+// P[r][small] = sum_big tproj(big,small) * X[r][big]  -- dgemm ~transa:`T tproj inputs (lib/cov_se_fat.ml:215-218), on
+// the matrix cores for any D and d: one wavefront per 16 x 16 output tile, v_mfma_f64_16x16x4_f64 over `big` in steps
+// of 4, operands straight from memory (the whole problem is 2 n D d flops: ~3e10 at n = 1M, D = 200, d = 80).
+__global__ __launch_bounds__(256) void project_mfma_kernel(const double* __restrict__ X, int64_t n, int D, int d,
+                                                           const double* __restrict__ tproj,
+                                                           double* __restrict__ P) {
+  typedef double d4 __attribute__((ext_vector_type(4)));
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int l15 = lane & 15, lq = lane >> 4;
+  const int64_t r0 = ((int64_t)blockIdx.x * 4 + wave) * 16;
+  if (r0 >= n) return;
+  const int64_t row = min(r0 + l15, n - 1);
+  for (int c0 = 0; c0 < d; c0 += 16) {
+    const int col = min(c0 + l15, d - 1);
+    d4 acc = {0.0, 0.0, 0.0, 0.0};
+    for (int k0 = 0; k0 < D; k0 += 4) {
+      const int k = k0 + lq;
+      const double a = (k < D) ? X[row * D + k] : 0.0;                       // A[i = l15][k = lq]
+      const double b = (k < D) ? tproj[(int64_t)col * D + k] : 0.0;          // B[k = lq][j = l15]
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {                                            // C[(l >> 4) + 4 r][l & 15]
+      const int64_t orow = r0 + lq + 4 * r;
+      if (orow < n && c0 + l15 < d) P[orow * d + c0 + l15] = acc[r];
+    }
+  }
+}
+
 
 template <typename F>
 static void dispatch_dt(int d, F&& f) {
@@ -198,8 +307,11 @@ static void dispatch_dt(int d, F&& f) {
   else if (d <= 16) f(std::integral_constant<int, 16>{});
   else if (d <= 32) f(std::integral_constant<int, 32>{});
   else if (d <= 64) f(std::integral_constant<int, 64>{});
-  else {
-    set_error("gprhip: input dimension d > 64 is not supported by the covariance kernels");
+  else f(std::integral_constant<int, 0>{});  // wide: dimension loop in chunks (no multiscales)
+}
+static void no_wide_multiscales(const CovParams& cp, int d) {
+  if (cp.ms && d > 64) {
+    set_error("gprhip: Cov_se_fat multiscales support kernel-space dimension d <= 64");
     throw HipFail{ST_BAD_ARG};
   }
 }
@@ -207,13 +319,15 @@ static void dispatch_dt(int d, F&& f) {
 void launch_cov_upper(const CovParams& cp, const double* Z, int m, int mp, int d, double jitter,
                       const double* het, double* km, double* kj, hipStream_t s) {
   dim3 grid(mp / 256 + (mp % 256 ? 1 : 0), (mp + 31) / 32);
+  no_wide_multiscales(cp, d);
   dispatch_dt(d, [&](auto dt) {
-    if (cp.ms)
-      hipLaunchKernelGGL((cov_upper_ms_kernel<decltype(dt)::value>), grid, dim3(256), 0, s, cp, Z, m, mp,
-                         d, jitter, het, km, kj);
+    constexpr int DT = decltype(dt)::value;
+    if constexpr (DT == 0)
+      hipLaunchKernelGGL(cov_upper_wide_kernel, grid, dim3(256), 0, s, cp, Z, m, mp, d, jitter, het, km, kj);
+    else if (cp.ms)
+      hipLaunchKernelGGL((cov_upper_ms_kernel<DT>), grid, dim3(256), 0, s, cp, Z, m, mp, d, jitter, het, km, kj);
     else
-      hipLaunchKernelGGL((cov_upper_kernel<decltype(dt)::value>), grid, dim3(256), 0, s, cp, Z, m, mp, d,
-                         jitter, het, km, kj);
+      hipLaunchKernelGGL((cov_upper_kernel<DT>), grid, dim3(256), 0, s, cp, Z, m, mp, d, jitter, het, km, kj);
   });
   GPR_HIP(hipGetLastError());
 }
@@ -222,13 +336,15 @@ template <typename TS>
 void launch_cov_cross(const CovParams& cp, const double* pts, int rows, int rows_p, const double* Z,
                       int m, int mp, int d, TS* K, hipStream_t s) {
   dim3 grid(mp / 256 + (mp % 256 ? 1 : 0), (rows_p + 31) / 32);
+  no_wide_multiscales(cp, d);
   dispatch_dt(d, [&](auto dt) {
-    if (cp.ms)
-      hipLaunchKernelGGL((cov_cross_ms_kernel<decltype(dt)::value, TS>), grid, dim3(256), 0, s, cp, pts,
-                         rows, rows_p, Z, m, mp, d, K);
+    constexpr int DT = decltype(dt)::value;
+    if constexpr (DT == 0)
+      hipLaunchKernelGGL((cov_cross_wide_kernel<TS>), grid, dim3(256), 0, s, cp, pts, rows, rows_p, Z, m, mp, d, K);
+    else if (cp.ms)
+      hipLaunchKernelGGL((cov_cross_ms_kernel<DT, TS>), grid, dim3(256), 0, s, cp, pts, rows, rows_p, Z, m, mp, d, K);
     else
-      hipLaunchKernelGGL((cov_cross_kernel<decltype(dt)::value, TS>), grid, dim3(256), 0, s, cp, pts, rows,
-                         rows_p, Z, m, mp, d, K);
+      hipLaunchKernelGGL((cov_cross_kernel<DT, TS>), grid, dim3(256), 0, s, cp, pts, rows, rows_p, Z, m, mp, d, K);
   });
   GPR_HIP(hipGetLastError());
 }
@@ -239,9 +355,7 @@ template void launch_cov_cross<float>(const CovParams&, const double*, int, int,
 
 void launch_project(const double* X, int64_t n, int D, int d, const double* tproj, double* P,
                     hipStream_t s) {
-  int64_t total = n * d;
-  hipLaunchKernelGGL(project_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, X, n, D, d,
-                     tproj, P);
+  hipLaunchKernelGGL(project_mfma_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, s, X, n, D, d, tproj, P);
   GPR_HIP(hipGetLastError());
 }
 

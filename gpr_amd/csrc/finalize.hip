@@ -142,6 +142,47 @@ __global__ __launch_bounds__(256) void km_traces_kernel(const double* __restrict
     if (k < d) p[(int64_t)(2 + k) * mp + c] = g[k];
 }
 
+// d > 64: the per-dimension accumulators run in passes of 32 dimensions (blockIdx.z); |z_r - z_c|^2 of the Log_ell
+// trace is recovered from K_m itself (pass 0).  No multiscales on this path.
+__global__ __launch_bounds__(256) void km_traces_wide_kernel(const double* __restrict__ W,
+                                                             const double* __restrict__ km,
+                                                             const double* __restrict__ Z, int m, int mp, int d,
+                                                             double log_sf2, double inv_ell2_05,
+                                                             double* __restrict__ part) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= mp) return;
+  const bool live = c < m;
+  const int dim0 = blockIdx.z * 32, nd = min(32, d - dim0);
+  double z[32], g[32];
+#pragma unroll
+  for (int k = 0; k < 32; ++k) {
+    z[k] = (k < nd && live) ? Z[(int64_t)c * d + dim0 + k] : 0.0;
+    g[k] = 0.0;
+  }
+  double s0 = 0.0, s1 = 0.0;
+  const int r0 = blockIdx.y * KM_SLAB, r1 = min(m, r0 + KM_SLAB);
+  if (live) {
+    for (int r = r0; r < r1; ++r) {
+      const double kv = km[(int64_t)r * mp + c];
+      const double wk = W[(int64_t)r * mp + c] * kv;
+      const double* zr = Z + (int64_t)r * d + dim0;
+#pragma unroll
+      for (int k = 0; k < 32; ++k)
+        if (k < nd) g[k] += wk * (zr[k] - z[k]);
+      s0 += wk;
+      if (r != c && kv > 0.0) s1 += wk * ((log(kv) - log_sf2) / inv_ell2_05);
+    }
+  }
+  double* p = part + (int64_t)blockIdx.y * (d + 2) * mp;
+  if (blockIdx.z == 0) {
+    p[c] = s0;
+    p[(int64_t)mp + c] = s1;
+  }
+#pragma unroll
+  for (int k = 0; k < 32; ++k)
+    if (k < nd) p[(int64_t)(2 + dim0 + k) * mp + c] = g[k];
+}
+
 template <int DT>
 __global__ __launch_bounds__(256) void km_traces_ms_kernel(const double* __restrict__ W,
                                                            const double* __restrict__ km,
@@ -193,6 +234,10 @@ __global__ __launch_bounds__(256) void km_traces_ms_kernel(const double* __restr
 
 void launch_km_traces_ms(const double* W, const double* km, const double* Z, const double* ms, int m, int mp,
                          int d, double* part, hipStream_t s) {
+  if (d > 64) {
+    set_error("gprhip: Cov_se_fat multiscales support kernel-space dimension d <= 64");
+    throw HipFail{ST_BAD_ARG};
+  }
   dim3 grid((mp + 255) / 256, (m + KM_SLAB - 1) / KM_SLAB);
   auto go = [&](auto dt) {
     hipLaunchKernelGGL((km_traces_ms_kernel<decltype(dt)::value>), grid, dim3(256), 0, s, W, km, Z, ms, m, mp,
@@ -207,8 +252,15 @@ void launch_km_traces_ms(const double* W, const double* km, const double* Z, con
 }
 
 void launch_km_traces(const double* W, const double* km, const double* Z, int m, int mp, int d,
-                      double* part, double* /*unused*/, hipStream_t s) {
+                      double* part, const CovParams& cp, hipStream_t s) {
   dim3 grid((mp + 255) / 256, (m + KM_SLAB - 1) / KM_SLAB);
+  if (d > 64) {
+    grid.z = (d + 31) / 32;
+    hipLaunchKernelGGL(km_traces_wide_kernel, grid, dim3(256), 0, s, W, km, Z, m, mp, d, cp.log_sf2, cp.inv_ell2_05,
+                       part);
+    GPR_HIP(hipGetLastError());
+    return;
+  }
   auto go = [&](auto dt) {
     hipLaunchKernelGGL((km_traces_kernel<decltype(dt)::value>), grid, dim3(256), 0, s, W, km, Z, m, mp,
                        d, part);

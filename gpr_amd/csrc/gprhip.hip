@@ -347,10 +347,6 @@ void upload_hypers(gprhip_problem* p, const gprhip_hypers* h) {
     set_error("gprhip: tproj given for Cov_se_iso");
     throw HipFail{ST_BAD_ARG};
   }
-  if (p->kind == GPRHIP_COV_SE_FAT && h->tproj && p->D > 64) {
-    set_error("gprhip: Cov_se_fat with tproj supports input dimension D <= 64");
-    throw HipFail{ST_BAD_ARG};
-  }
   if (p->kind == GPRHIP_COV_SE_FAT && !h->tproj && p->D != p->d) {
     set_error("gprhip: Cov_se_fat without tproj needs D == d");
     throw HipFail{ST_BAD_ARG};
@@ -652,7 +648,12 @@ void do_pass2(gprhip_problem* p, const double* ar1, double* ar2) {
       // matrix-core version unless multiscales (or > 64 dimensions) need the scalar kernel; GPRHIP_GRAD_SCALAR=1
       // forces the scalar one (parity tests run both)
       int nbx = p->grad_scalar ? 0 : grad_mfma_col_blocks(ga);
-      if (nbx > 0) launch_grad_mfma(ga, s);
+      if (p->d > 64 || ga.D > 64) {
+        // wide points: K of the chunk is rebuilt into the buffer X~ has left, and E = X .* K read from memory
+        cov_chunk<TS>(p, c, bufB);
+        launch_grad_wide(ga, static_cast<const TS*>(bufB), s);
+        nbx = (mp + 255) / 256;
+      } else if (nbx > 0) launch_grad_mfma(ga, s);
       else {
         launch_grad_fused(ga, s);
         nbx = (mp + 255) / 256;
@@ -716,7 +717,7 @@ void do_finish(gprhip_problem* p, const double* ar2, gprhip_result* res, double*
       launch_km_traces_ms(p->wmat, p->km, p->Z, p->ms, m, mp, d, p->kmpart, s);
       launch_reduce_rows(p->kmpart, nkslab, (2 * d + 2) * mp, p->kmred, 0, s);
     } else {
-      launch_km_traces(p->wmat, p->km, p->Z, m, mp, d, p->kmpart, nullptr, s);
+      launch_km_traces(p->wmat, p->km, p->Z, m, mp, d, p->kmpart, p->cp, s);
       launch_reduce_rows(p->kmpart, nkslab, (d + 2) * mp, p->kmred, 0, s);
     }
     tstop(p);
@@ -1235,8 +1236,8 @@ int gprhip_problem_create_ex(int device, int cov_kind, int precision, int64_t n,
     }
     if (!out || n < 1 || D < 1 || d < 1 || m < 1 ||
         (cov_kind != GPRHIP_COV_SE_ISO && cov_kind != GPRHIP_COV_SE_FAT) ||
-        (cov_kind == GPRHIP_COV_SE_ISO && d != D) || d > 64) {
-      set_error("gprhip_problem_create: invalid arguments (need n,D,d,m >= 1, d <= 64, d == D for Cov_se_iso)");
+        (cov_kind == GPRHIP_COV_SE_ISO && d != D)) {
+      set_error("gprhip_problem_create: invalid arguments (need n,D,d,m >= 1, d == D for Cov_se_iso)");
       throw HipFail{ST_BAD_ARG};
     }
     GPR_HIP(hipSetDevice(device));

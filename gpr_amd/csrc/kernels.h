@@ -147,6 +147,9 @@ void launch_proj_term2(const double* X, const double* P, const double* es, int e
 // es[row][k] = sum_slot rowes[row][slot][k]
 void launch_reduce_rowes(const double* rowes, int rows, int nslots, int d, double* es, hipStream_t s);
 int grad_slab_rows();
+// d > 64 or D > 64: E = X .* K with K of the chunk given in memory (see rowops.hip)
+template <typename TS>
+void launch_grad_wide(const GradArgs<TS>& a, const TS* K, hipStream_t s);
 // the same pass on the matrix cores (grad_mfma.hip): column blocks of 128, or 0 if the launch is not eligible
 template <typename TS>
 int grad_mfma_col_blocks(const GradArgs<TS>& a);
@@ -171,7 +174,7 @@ void launch_build_w(const double* binv, const double* t, const double* G, int mp
 int km_slab_rows();  // rows per slab of the km_traces partial buffers
 // q = 1: sum_r W_rc K_rc |z_r - z_c|^2, q = 2+k: sum_r W_rc K_rc (z_kr - z_kc).  W, km full symmetric.
 void launch_km_traces(const double* W, const double* km, const double* Z, int m, int mp, int d,
-                      double* part, double* unused, hipStream_t s);
+                      double* part, const CovParams& cp, hipStream_t s);
 // Multiscale variant (lib/cov_se_fat.ml:441-516): part[slab][q][c] with q = 0: sum_r W_rc K_rc,
 // q = 2+k: sum_{r!=c} W_rc K_rc (z_kr - z_kc)/(ms_kr + ms_kc - 1),
 // q = 2+d+k: sum_{r!=c} W_rc K_rc (iscale - sdiff^2), iscale = 1/(ms_kr + ms_kc - 1), sdiff = (z_kr - z_kc) iscale

@@ -435,6 +435,86 @@ void launch_reduce_rowes(const double* rowes, int rows, int nslots, int d, doubl
   GPR_HIP(hipGetLastError());
 }
 
+// ---- point dimensions above 64 ("wide").  K_nm of the chunk is in memory (the caller rebuilds it with the wide
+// covariance kernel: the chunk buffer that held X~ is free), so E = X .* K needs no distance loop, and the column
+// accumulators sum_r p_kr E_rc run in passes over 32 dimensions (blockIdx.z), first the d kernel-space dimensions,
+// then the D input dimensions of a projected kernel.  The squared distance of the Log_ell term is recovered from K:
+// |x - z|^2 = (log K - log sf2) / inv_ell2_05.  No multiscales on this path.
+template <typename TS>
+__global__ __launch_bounds__(256) void grad_wide_kernel(GradArgs<TS> a, const TS* __restrict__ K) {
+  __shared__ double red[4][2];
+  __shared__ double xs[32][32];
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  const int jj = min(j, a.mp - 1);
+  const bool live = (j < a.m);
+  const int nz = (a.d + 31) / 32;                 // passes over kernel-space dimensions
+  const bool big = (int)blockIdx.z >= nz;
+  const double* src = big ? a.big : a.pts;
+  const int ld = big ? a.D : a.d;
+  const int dim0 = (big ? (int)blockIdx.z - nz : (int)blockIdx.z) * 32;
+  const int nd = min(32, ld - dim0);
+  const int out0 = big ? a.d + 1 + dim0 : 1 + dim0;
+  double gx[32];
+#pragma unroll
+  for (int k = 0; k < 32; ++k) gx[k] = 0.0;
+  double cs = 0.0, sED = 0.0;
+  const int r0 = blockIdx.y * GRAD_SLAB;
+  const int r1 = min(a.rows, r0 + GRAD_SLAB);
+  for (int rb = r0; rb < r1; rb += 32) {
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < 32 * 32; idx += 256) {
+      const int r = idx / 32, k = idx % 32;
+      xs[r][k] = (k < nd && rb + r < r1) ? src[(int64_t)(rb + r) * ld + dim0 + k] : 0.0;
+    }
+    __syncthreads();
+    const int nr = min(32, r1 - rb);
+    for (int i = 0; i < nr; ++i) {
+      const double kv = (double)K[(int64_t)(rb + i) * a.mp + jj];
+      const double e = live ? (double)a.X[(int64_t)(rb + i) * a.mp + jj] * kv : 0.0;
+#pragma unroll
+      for (int k = 0; k < 32; ++k) gx[k] += xs[i][k] * e;
+      cs += e;
+      if (kv > 0.0) sED += e * ((log(kv) - a.log_sf2) / a.inv_ell2_05);
+    }
+  }
+  if (j < a.mp) {
+    double* cp = a.colpart + (int64_t)blockIdx.y * a.col_rows * a.mp;
+    if (blockIdx.z == 0) cp[j] = cs;
+#pragma unroll
+    for (int k = 0; k < 32; ++k)
+      if (k < nd) cp[(int64_t)(out0 + k) * a.mp + j] = gx[k];
+  }
+  if (blockIdx.z != 0) return;
+  double sE = wave_sum(cs);
+  sED = wave_sum(sED);
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) {
+    red[wv][0] = sE;
+    red[wv][1] = sED;
+  }
+  __syncthreads();
+  if (threadIdx.x < 2) {
+    const int k = threadIdx.x;
+    a.scalpart[((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 2 + k] =
+        (red[0][k] + red[1][k]) + (red[2][k] + red[3][k]);
+  }
+}
+
+template <typename TS>
+void launch_grad_wide(const GradArgs<TS>& a, const TS* K, hipStream_t s) {
+  if (a.ms) {
+    set_error("gprhip: Cov_se_fat multiscales support dimensions d, D <= 64");
+    throw HipFail{ST_BAD_ARG};
+  }
+  const int nz = (a.d + 31) / 32 + (a.big ? (a.D + 31) / 32 : 0);
+  dim3 grid((a.mp + 255) / 256, (a.rows + GRAD_SLAB - 1) / GRAD_SLAB, nz);
+  hipLaunchKernelGGL((grad_wide_kernel<TS>), grid, dim3(256), 0, s, a, K);
+  GPR_HIP(hipGetLastError());
+}
+template void launch_grad_wide<double>(const GradArgs<double>&, const double*, hipStream_t);
+template void launch_grad_wide<float>(const GradArgs<float>&, const float*, hipStream_t);
+
 // Cov_se_fat `Proj {big; small}` (lib/cov_se_fat.ml:570-596): second term of
 //   -tr(X^T dK) = -[ sum_c z_small,c sum_r x_big,r E_rc  -  sum_r x_big,r p_small,r rowsum(E)_r ]
 __global__ __launch_bounds__(256) void proj_term2_kernel(const double* __restrict__ X,

@@ -1146,6 +1146,55 @@ def test_wide_point_dimensions(d):
     assert evf.grad.shape == reff["grad"].shape and relinf(evf.grad, reff["grad"]) <= TOL_GRAD
 
 
+def test_point_dimensions_above_64():
+    """No dimension limit in the reference (lib/cov_se_fat.ml:215-252 projects arbitrary-width inputs,
+    bin/ocaml_gpr.ml:196-202 reads arbitrary-width samples): a general projection D = 200 -> d = 80 (MFMA projection
+    kernel, chunked dimension loops in the covariance / gradient / trace kernels, 16 000 Proj gradient entries) and
+    cov_se_iso at d = 100, against the oracle; predictions through the same kernels."""
+    rng = np.random.default_rng(17)
+    n, m, D, d = 3000, 150, 200, 80
+    X = np.asfortranarray(rng.normal(size=(D, n)))
+    y = np.sin(X[:5].sum(0)) + 0.1 * rng.normal(size=n)
+    P = np.asfortranarray(rng.normal(size=(D, d)) / np.sqrt(D * d))
+    k = O.SeFatKernel(d, 0.1, P)
+    Z = np.asfortranarray(O.se_fat_project(k, X[:, rng.permutation(n)[:m]]) + 0.01 * rng.normal(size=(d, m)))
+    ref = O.evaluate_fast(k, Z, X, y, 0.1)
+    p = gpr_amd.Problem(gpr_amd.COV_SE_FAT, n, D, d, m, chunk_rows=1024)
+    p.set_inputs(X)
+    p.set_targets(y)
+    ev = p.eval(log_sf2=0.1, sigma2=0.1, inducing=Z, tproj=P)
+    assert ev.grad.shape == ref["grad"].shape == (1 + d * m + D * d,)
+    assert abs(ev.l - ref["l"]) <= TOL_L * abs(ref["l"])
+    assert abs(ev.dl_dsigma2 - ref["dl_dsigma2"]) <= TOL_DS2 * abs(ref["dl_dsigma2"])
+    assert relinf(ev.grad, ref["grad"]) <= TOL_GRAD and relinf(ev.coeffs, ref["coeffs"]) <= TOL_COEFF
+    Xt = np.asfortranarray(rng.normal(size=(D, 77)))
+    mean, var = p.predict(Xt, predictive=False)
+    assert relinf(mean, O.predict_means(k, Z, ref["coeffs"], Xt)) <= 1e-8
+    model = O.evaluate(k, Z, X, y, 0.1, want_grad=False, keep=True)["model"]
+    assert relinf(var, O.predict_variances(k, Z, model, Xt, predictive=False)) <= 1e-8
+    p.close()
+    n, m, d = 2500, 130, 100
+    X, y, Z = synth(23, n, m, d)
+    le = 0.5 * np.log(d)
+    ref = O.evaluate_fast(O.SeIsoKernel(le, -0.2), Z, X, y, 0.05)
+    p = gpr_amd.Problem(gpr_amd.COV_SE_ISO, n, d, d, m)
+    p.set_inputs(X)
+    p.set_targets(y)
+    ev = p.eval(log_ell=le, log_sf2=-0.2, sigma2=0.05, inducing=Z)
+    p.close()
+    assert abs(ev.l - ref["l"]) <= TOL_L * abs(ref["l"])
+    assert relinf(ev.grad, ref["grad"]) <= TOL_GRAD and relinf(ev.coeffs, ref["coeffs"]) <= TOL_COEFF
+    with pytest.raises(gpr_amd.GprHipError, match="multiscales support"):
+        q = gpr_amd.Problem(gpr_amd.COV_SE_FAT, 300, 70, 70, 20)
+        q.set_inputs(X[:70, :300])
+        q.set_targets(y[:300])
+        try:
+            q.eval(log_sf2=0.0, sigma2=0.1, inducing=np.asfortranarray(X[:70, :20]),
+                   log_multiscales_m05=np.zeros((70, 20), order="F"))
+        finally:
+            q.close()
+
+
 def test_fp32_bulk_posterior_paths():
     """Prediction, training-set statistics and covariances on a problem created in the fp32-bulk mode (the n x m
     work of prediction and statistics runs in fp32 there; covariances are always fp64), against the fp64 oracle
