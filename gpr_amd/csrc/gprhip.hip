@@ -147,7 +147,7 @@ struct gprhip_problem {
   }
   int ks_used = 8;
   int64_t slice_rows = 4096;  // training points per split-K slice of the SYRK launches
-  int tile_order = 0;
+  int tile_order = 2;  // block -> tile order of the chunk GEMMs (mfma_gemm.hip tile_of_block): XCD-local 8 x 8 super tiles
   int grad_scalar = 0;  // GPRHIP_GRAD_SCALAR: use the scalar gradient kernel even where the MFMA one applies
   // Cov_se_fat `Proj hypers: rows of the exchange-2 column block beyond d+1, and the D x d second term
   int dbig() const { return kind == GPRHIP_COV_SE_FAT ? D : 0; }
@@ -1248,7 +1248,7 @@ int gprhip_problem_create_ex(int device, int cov_kind, int precision, int64_t n,
     p->f32 = (precision == GPRHIP_F32_BULK);
     p->esz = p->f32 ? 4 : 8;
     p->mp = (int)round_up(m, TILE);
-    int64_t chunk = chunk_rows > 0 ? chunk_rows : 32768;
+    int64_t chunk = chunk_rows > 0 ? chunk_rows : 131072;
     if (const char* e = getenv("GPRHIP_CHUNK_ROWS")) chunk = atoll(e);
     chunk = round_up(std::min<int64_t>(chunk, round_up(n, TILE)), TILE);
     p->chunk = chunk;
