@@ -146,7 +146,7 @@ struct gprhip_problem {
     return (int64_t)(nchunks - 1) * chunk + round_up(rows_of(nchunks - 1), TILE);
   }
   int ks_used = 8;
-  int64_t slice_rows = 4096;  // training points per split-K slice of the SYRK launches
+  int64_t slice_rows = 8192;  // training points per split-K slice of the SYRK launches (4096 in the fp32-bulk mode)
   int tile_order = 2;  // block -> tile order of the chunk GEMMs (mfma_gemm.hip tile_of_block): XCD-local 8 x 8 super tiles
   int grad_scalar = 0;  // GPRHIP_GRAD_SCALAR: use the scalar gradient kernel even where the MFMA one applies
   // Cov_se_fat `Proj hypers: rows of the exchange-2 column block beyond d+1, and the D x d second term
@@ -413,11 +413,12 @@ void upload_hypers(gprhip_problem* p, const gprhip_hypers* h) {
 
 // Split-K factor of the SYRK-shaped accumulations over training points.  Slices are dealt to the
 // 8 XCDs (mfma_gemm.hip), so the factor is a multiple of 8.  Blocks of one slice share their operand
-// rows through the XCD's L2 while they run in step.  Run time is flat in the slice length (measured
-// 4k..125k rows) but the blocks of a long slice drift apart and re-fetch more (rocprofv3 FETCH_SIZE per
-// launch at n=1M, m=2048: 159 GB with 16k-row slices, 86 GB with 4k-row slices, against 16.4 GB of V), so
-// slices are kept near `slice_rows` (4096) rows.  Among nearby factors the one whose (tiles x slices / 8)
-// fills whole residency rounds of an XCD (32 CUs x 2 blocks) is taken.
+// rows through the XCD's L2 while they run in step.  Measured at n=1M, m=2048 (rocprofv3 FETCH_SIZE per launch,
+// against 16.4 GB of V): 60 GB through the fabric for 2k-, 4k- and 8k-row slices alike once every workgroup of the
+// launch runs the same loop (mfma_gemm.hip) -- the re-fetch factor is set by the stagger of workgroup start times
+// against the L2 window, not by the slice length -- and the step is fastest with 8k..16k-row slices (381.6 ms;
+// 385 ms at 4k and at 32k), so slices are kept near `slice_rows`.  Among nearby factors the one whose
+// (tiles x slices / 8) fills whole residency rounds of an XCD (32 CUs x 2 blocks) is taken.
 int pick_kslices(int mp, int64_t rows_p, int max_slices, int64_t slice_rows) {
   const int nt = mp / TILE, tiles = nt * (nt + 1) / 2;
   const int slots = 64;
@@ -1255,6 +1256,7 @@ int gprhip_problem_create_ex(int device, int cov_kind, int precision, int64_t n,
     p->nchunks = (int)((n + chunk - 1) / chunk);
     // partial-sum buffers of the split-K SYRK launches: one m x m slice per `slice_rows` training points,
     // capped at 40 GB
+    if (p->f32) p->slice_rows = 4096;  // fp32 accumulation never runs over more than 4096 rows before the fp64 sum
     if (const char* e = getenv("GPRHIP_SLICE_ROWS")) p->slice_rows = std::max<int64_t>(1024, atoll(e));
     p->kslices = (int)std::max<int64_t>(8, std::min<int64_t>((round_up(n, p->slice_rows) / p->slice_rows + 23) / 8 * 8,
                                                               (40LL << 30) / (p->mp * (int64_t)p->mp * 8) / 8 * 8));
