@@ -5,6 +5,9 @@ The k-loop (engine_asm.inc) owns v88..v255 (fp64 kernels) / v80..v255 (fp32) and
 amdgpu_num_vgpr / amdgpu_num_sgpr.  Two things would silently break that contract and are checked here:
   * any compiler-generated instruction outside the ;;#ASMSTART / ;;#ASMEND blocks that names a register of ours
     (SGPR spills are parked in lanes of VGPRs chosen without regard to the cap);
+  * static LDS: the loop addresses LDS absolutely from byte 0 of the workgroup's allocation, which is only the dynamic
+    segment if the compiler places nothing of its own there (it promotes private arrays to LDS unless told not to:
+    -mllvm -disable-promote-alloca-to-lds; a 1536-byte promoted array once overlaid the first A image);
   * (reported, not fatal) scratch use or register spills in these kernels: slow but safe as long as the rule above holds.
 usage: audit_engine.py listing.s
 """
@@ -43,6 +46,9 @@ for ln in text.split("\n"):
     # (SGPR spill lanes in a VGPR below the cap, or VGPR spills to scratch, are safe -- only slow; they are reported)
     if "v_writelane" in code or "v_readlane" in code or "scratch_" in code:
         notes.add("%s: spill code present (%s ...)" % (kernel, code.split()[0]))
+for m in re.finditer(r"\.amdhsa_group_segment_fixed_size\s+(\d+)", text):
+    if int(m.group(1)) != 0:
+        bad.append("a kernel carries %s bytes of static LDS (compiler-placed): the loop's LDS map starts at byte 0" % m.group(1))
 if bad:
     print("audit_engine: FAILED")
     for b in bad[:40]:

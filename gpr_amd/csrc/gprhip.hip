@@ -147,7 +147,7 @@ struct gprhip_problem {
   }
   int ks_used = 8;
   int64_t slice_rows = 8192;  // training points per split-K slice of the SYRK launches (4096 in the fp32-bulk mode)
-  int tile_order = 2;  // block -> tile order of the chunk GEMMs (mfma_gemm.hip tile_of_block): XCD-local 8 x 8 super tiles
+  int tile_order = 3;  // block -> tile order of the chunk GEMMs (mfma_gemm.hip tile_of_block): paired column tiles, XCD-local groups
   int grad_scalar = 0;  // GPRHIP_GRAD_SCALAR: use the scalar gradient kernel even where the MFMA one applies
   // Cov_se_fat `Proj hypers: rows of the exchange-2 column block beyond d+1, and the D x d second term
   int dbig() const { return kind == GPRHIP_COV_SE_FAT ? D : 0; }

@@ -44,6 +44,7 @@ struct GemmArgsT {
   int tri = TRI_NONE;
   int upper_only = 0;    // compute only tiles with row tile <= column tile
   int order = 0;         // block -> tile order of full grids (see tile_of_block)
+  int ipw = 1;           // items per workgroup (set by launch_gemm: 2 for the paired order 3)
   int nbatch = 1;        // independent problems of identical shape: gridDim.y, pointers advance by the strides
   int64_t batch_a = 0, batch_b = 0, batch_c = 0;
   int kslices = 1;       // split K over the grid; slice z writes C + z*slice_stride

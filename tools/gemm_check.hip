@@ -44,7 +44,16 @@ int check(GemmOp op, int M, int N, int K, int tri, bool scale) {
   hipMemcpy(ds, hs.data(), K * 8, hipMemcpyHostToDevice);
   hipMemset(dC, 0, (int64_t)M * N * 8);
   GemmArgs g; g.A = dA; g.lda = ac; g.B = dB; g.ldb = bc; g.C = dC; g.ldc = N; g.M = M; g.N = N; g.K = K;
+  g.order = getenv("ORD") ? atoi(getenv("ORD")) : 0;
   g.tri = tri; g.scale_k = scale ? ds : nullptr;
+  double *drp = nullptr, *drd = nullptr, *dvec = nullptr;
+  const int nparts = 2 * (N / 128);
+  if (getenv("RP")) {  // row reductions from the epilogue (sum of squares and dot with a vector), as the V / Q' products use them
+    hipMalloc(&drp, (int64_t)nparts * M * 8); hipMalloc(&drd, (int64_t)nparts * M * 8); hipMalloc(&dvec, N * 8);
+    hipMemset(drp, 0xff, (int64_t)nparts * M * 8); hipMemset(drd, 0xff, (int64_t)nparts * M * 8);
+    hipMemcpy(dvec, hs.data(), std::min(N, K) * 8, hipMemcpyHostToDevice);
+    g.rp_sumsq = drp; g.rp_dot = drd; g.rp_vec = dvec;
+  }
   launch_gemm(op, g, 0);
   naive<<<dim3((N + 255) / 256, M), 256>>>(op, dA, ac, dB, bc, dR, N, M, N, K, scale ? ds : nullptr);
   std::vector<double> hC((int64_t)M * N), hR((int64_t)M * N);
@@ -52,6 +61,44 @@ int check(GemmOp op, int M, int N, int K, int tri, bool scale) {
   hipMemcpy(hR.data(), dR, hR.size() * 8, hipMemcpyDeviceToHost);
   double maxerr = 0;
   for (size_t i = 0; i < hC.size(); ++i) maxerr = std::max(maxerr, fabs(hC[i] - hR[i]));
+  if (getenv("WHERE") && maxerr > 1e-10 * K) {  // which tiles are wrong (count of bad elements per column tile; first bad row panels)
+    const int nbn = N / 128, nbm = M / 128;
+    std::vector<int> cnt(nbn, 0), firstbm(nbn, -1), tiles(nbn, 0);
+    for (int bm = 0; bm < nbm; ++bm)
+      for (int bn = 0; bn < nbn; ++bn) {
+        int bad = 0;
+        for (int r = 0; r < 128; ++r)
+          for (int q = 0; q < 128; ++q) {
+            const int64_t ix = (int64_t)(bm * 128 + r) * N + bn * 128 + q;
+            if (fabs(hC[ix] - hR[ix]) > 1e-10 * K) ++bad;
+          }
+        if (bad && firstbm[bn] < 0 && bn < 2) {
+          printf("    tile (%d,%d) bad rows:", bm, bn);
+          for (int r = 0; r < 128; ++r) { int c = 0; for (int q = 0; q < 128; ++q) { const int64_t ix = (int64_t)(bm * 128 + r) * N + bn * 128 + q; if (fabs(hC[ix] - hR[ix]) > 1e-10 * K) ++c; } if (c) printf(" %d(%d)", r, c); }
+          printf("\n    bad cols:");
+          for (int q = 0; q < 128; ++q) { int c = 0; for (int r = 0; r < 128; ++r) { const int64_t ix = (int64_t)(bm * 128 + r) * N + bn * 128 + q; if (fabs(hC[ix] - hR[ix]) > 1e-10 * K) ++c; } if (c) printf(" %d(%d)", q, c); }
+          printf("\n");
+        }
+        if (bad) { cnt[bn] += bad; ++tiles[bn]; if (firstbm[bn] < 0) firstbm[bn] = bm; }
+      }
+    for (int bn = 0; bn < nbn; ++bn) printf("    col tile %d: %d bad tiles, %d bad elements, first bad row panel %d\n", bn, tiles[bn], cnt[bn], firstbm[bn]);
+  }
+  if (drp && N <= K) {
+    std::vector<double> hp((int64_t)nparts * M), hd((int64_t)nparts * M);
+    hipMemcpy(hp.data(), drp, hp.size() * 8, hipMemcpyDeviceToHost);
+    hipMemcpy(hd.data(), drd, hd.size() * 8, hipMemcpyDeviceToHost);
+    double e2 = 0, ed = 0;
+    for (int i = 0; i < M; ++i) {
+      double s2 = 0, sd = 0, r2 = 0, rd = 0;
+      for (int q = 0; q < nparts; ++q) { s2 += hp[(int64_t)q * M + i]; sd += hd[(int64_t)q * M + i]; }
+      for (int j = 0; j < N; ++j) { const double v = hR[(int64_t)i * N + j]; r2 += v * v; rd += v * hs[j]; }
+      e2 = std::max(e2, fabs(s2 - r2) / (1.0 + r2)); ed = std::max(ed, fabs(sd - rd) / (1.0 + fabs(rd)));
+    }
+    printf("  row partials: sumsq err %.3e dot err %.3e %s\n", e2, ed, (e2 < 1e-10 && ed < 1e-10) ? "OK" : "FAIL");
+    printf("  C maxerr %.3e\n", maxerr);
+    if (!(e2 < 1e-10 && ed < 1e-10)) maxerr = 1e300;
+    hipFree(drp); hipFree(drd); hipFree(dvec);
+  }
   printf("check op=%d M=%d N=%d K=%d tri=%d scale=%d maxerr=%.3e %s\n", op, M, N, K, tri, (int)scale, maxerr,
          maxerr < 1e-10 * K ? "OK" : "FAIL");
   hipFree(dA); hipFree(dB); hipFree(dC); hipFree(dR); hipFree(ds);
@@ -124,6 +171,7 @@ int check_f32(GemmOp op, int M, int N, int K, int tri, bool scale, bool epi) {
   hipMemcpy(ds, hs.data(), hs.size() * 8, hipMemcpyHostToDevice); hipMemcpy(dcol, hcol.data(), N * 8, hipMemcpyHostToDevice);
   hipMemset(dC, 0, (int64_t)M * N * 4);
   GemmArgsF g; g.A = dA; g.lda = ac; g.B = dB; g.ldb = bc; g.C = dC; g.ldc = N; g.M = M; g.N = N; g.K = K; g.tri = tri;
+  g.order = getenv("ORD") ? atoi(getenv("ORD")) : 0;
   g.scale_k = scale ? dsf : nullptr;
   if (epi) { g.epi_rows_a = ds; g.epi_rows_b = ds; g.epi_rows_c = ds; g.epi_col = dcol; g.epi_mat = dM; g.epi_ldm = N; }
   launch_gemm(op, g, 0);
@@ -272,6 +320,8 @@ int main() {
     bad += check_f32(OP_NN, 384, 256, 256, TRI_KHI_BN, false, false);
     bad += check_f32(OP_NT, 384, 256, 256, TRI_KLO_BN, false, true);
     bad += check_f32(OP_TN, 128, 128, 32, TRI_NONE, false, false);
+    bad += check_f32(OP_NN, 8192, 512, 512, TRI_KHI_BN, false, false);
+    bad += check_f32(OP_NT, 8192, 512, 512, TRI_KLO_BN, false, true);
     bad += check_syrk_cs<float>(256, 1056, 8);
     bad += check_syrk_cs<float>(384, 4096 + 96, 3);
     printf("f32 checks failed: %d\n", bad);
@@ -291,6 +341,14 @@ int main() {
   bad += check(OP_NT, 256, 256, 256, TRI_KLO_MAX, false);
   bad += check(OP_TN, 128, 128, 16, TRI_NONE, false);
   bad += check(OP_NN, 128, 256, 48, TRI_NONE, false);
+  bad += check(OP_NN, 8192, 512, 512, TRI_KHI_BN, false);   // 64 row panels: the paired order (ORD=3) applies
+  bad += check(OP_NT, 8192, 512, 512, TRI_KLO_BN, false);
+  if (getenv("RP")) {
+    bad += check(OP_NN, 8192, 2048, 2048, TRI_KHI_BN, false);
+    bad += check(OP_NT, 8192, 2048, 2048, TRI_KLO_BN, false);
+    printf("checks failed: %d\n", bad);
+    return bad;
+  }
   bad += check_syrk_cs<double>(256, 1040, 8);
   bad += check_syrk_cs<double>(384, 4096 + 48, 3);
   printf("checks failed: %d\n", bad);
