@@ -70,7 +70,7 @@ struct GemmArgsT {
   double* rp_sumsq = nullptr;
   double* rp_dot = nullptr;
   const double* rp_vec = nullptr;
-  int lab_skip = 0;  // tools/gemm_check.hip only (timing ablation): 1 = no epilogue at all, 2 = epilogue without its stores
+  int lab_skip = 0;  // tools/gemm_check.hip only (timing ablation): 1 = no epilogue at all
 };
 using GemmArgs = GemmArgsT<double>;
 using GemmArgsF = GemmArgsT<float>;
