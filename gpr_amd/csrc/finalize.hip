@@ -8,7 +8,7 @@ namespace gprhip {
 template <typename TS>
 __global__ __launch_bounds__(256) void sum_slices_kernel(const double* __restrict__ base,
                                                          const TS* __restrict__ slices, int nslices,
-                                                         int64_t stride, int mp, int packed,
+                                                         int nslices_diag, int64_t stride, int mp, int packed,
                                                          double* __restrict__ dst) {
   const int c = blockIdx.x * 256 + threadIdx.x;
   const int r = blockIdx.y;
@@ -18,7 +18,8 @@ __global__ __launch_bounds__(256) void sum_slices_kernel(const double* __restric
   double acc = 0.0;
   if (upper) {
     acc = base ? base[off] : 0.0;
-    for (int z = 0; z < nslices; ++z) acc += (double)slices[(int64_t)z * stride + off];
+    const int nz = (r / TILE == c / TILE) ? nslices_diag : nslices;  // diagonal tiles of a SYRK launch: fewer slices
+    for (int z = 0; z < nz; ++z) acc += (double)slices[(int64_t)z * stride + off];
   }
   if (!packed) dst[off] = acc;
   else if (upper) dst[packed_upper_off(r, c)] = acc;
@@ -26,13 +27,13 @@ __global__ __launch_bounds__(256) void sum_slices_kernel(const double* __restric
 
 template <typename TS>
 void launch_sum_slices(const double* base, const TS* slices, int nslices, int64_t stride, int mp,
-                       double* dst, hipStream_t s, int packed) {
+                       double* dst, hipStream_t s, int packed, int nslices_diag) {
   hipLaunchKernelGGL(sum_slices_kernel<TS>, dim3((mp + 255) / 256, mp), dim3(256), 0, s, base, slices,
-                     nslices, stride, mp, packed, dst);
+                     nslices, nslices_diag > 0 ? nslices_diag : nslices, stride, mp, packed, dst);
   GPR_HIP(hipGetLastError());
 }
-template void launch_sum_slices<double>(const double*, const double*, int, int64_t, int, double*, hipStream_t, int);
-template void launch_sum_slices<float>(const double*, const float*, int, int64_t, int, double*, hipStream_t, int);
+template void launch_sum_slices<double>(const double*, const double*, int, int64_t, int, double*, hipStream_t, int, int);
+template void launch_sum_slices<float>(const double*, const float*, int, int64_t, int, double*, hipStream_t, int, int);
 
 // dst[b][r][c] = sum_z slices[z][b][r][c] over a rows x cols rectangle (leading dimension ld, batch stride bs;
 // slices and dst share offsets): combines the split-K partial products of small GEMM launches in a fixed order.

@@ -49,7 +49,7 @@ class Cfg:
     def name(self):
         return "ENGINE_LOOP_%s_%s%s%s" % ("F64" if self.f64 else "F32", self.op.upper(),
                                           {0: "", 1: "_W", 2: "_WS"}[self.var],
-                                          {None: "", "khi": "_KHI", "klo": "_KLO"}[self.diag])
+                                          {None: "", "khi": "_KHI", "klo": "_KLO", "sy": "_SY"}[self.diag])
 
 
 def reg(base, width):
@@ -83,8 +83,8 @@ def gen(c):
                 addr = "%[addrA]" if kk == 0 else AX(kk)
                 off = b * BUFSZ + i * 2048
             else:
-                addr = "%[addrA]"
-                off = b * BUFSZ + (kk * 4608 + i * 128 if c.f64 else kk * 2176 + i * 64)
+                addr = "%[addrA]"   # k-major A (TN): sub-tile i = 16-row block wr + 2i of the tile, like B's columns
+                off = b * BUFSZ + (kk * 4608 + i * 256 if c.f64 else kk * 2176 + i * 128)
             emit("%s %s, %s offset:%d" % (c.rd, A(s, i), addr, off))
         for j in range(4):
             if c.b_x:
@@ -116,8 +116,9 @@ def gen(c):
                 emit("%s %s, %s, %s" % ("v_mul_f64" if c.f64 else "v_mul_f32", A(s, i), A(s, i), W(s)))
             emit("s_nop 1")
         for i in range(4):
-            for j in live:
-                emit("%s %s, %s, %s, %s" % (c.mfma, ACC(i, j), A(s, i), B(s, j), ACC(i, j)))
+            for j in range(4):
+                if j in live or (i, j) in live:
+                    emit("%s %s, %s, %s, %s" % (c.mfma, ACC(i, j), A(s, i), B(s, j), ACC(i, j)))
 
     # ---- LDS-DMA of one stage into buffer b (8 tile instructions per wavefront; weights by wavefronts 0 / 1)
     def dma(b):
@@ -245,6 +246,21 @@ def gen(c):
         stage(0, "2f")
         stage(1, "2f")
         emit("s_branch 1b")
+    elif c.diag == "sy":
+        # diagonal tile of a SYRK-shaped launch (A and B are the same operand, only row block <= column block is
+        # kept): wave (wr, wc) owns 16-row blocks wr + 2i and 16-column blocks wc + 2j, so sub-tile (i, j) lies on or
+        # above the diagonal iff wr + 2i <= wc + 2j -- i <= j for three of the waves, i < j for wave (1, 0).  10 (6) of
+        # the 16 MFMAs of a k-step remain; the strictly-lower sub-tiles keep their zeros.
+        emit("s_cmp_eq_u32 %[wave], 2")
+        emit("s_cbranch_scc1 20f")
+        emit("1:")
+        for b in (0, 1):
+            stage(b, "2f", live=lambda kk: tuple((i, j) for i in range(4) for j in range(4) if i <= j))
+        emit("s_branch 1b")
+        emit("20:")
+        for b in (0, 1):
+            stage(b, "2f", live=lambda kk: tuple((i, j) for i in range(4) for j in range(4) if i < j))
+        emit("s_branch 20b")
     elif c.diag == "khi":
         # plain stages until DSTAGES remain, then the diagonal block (a copy per starting buffer and wave column)
         def to_diag(label):
@@ -292,7 +308,7 @@ def main():
     out = ["// Generated by gen_engine_asm.py -- do not edit.", ""]
     for f64 in (True, False):
         for op, var, diag in (("nn", 0, None), ("nt", 0, None), ("tn", 0, None), ("tn", 1, None), ("tn", 2, None),
-                              ("nn", 0, "khi"), ("nt", 0, "klo")):
+                              ("nn", 0, "khi"), ("nt", 0, "klo"), ("tn", 1, "sy"), ("tn", 2, "sy")):
             c = Cfg(f64, op, var, diag)
             for part, lines in zip(("PRO", "MAIN"), gen(c)):
                 if diag and part == "PRO":

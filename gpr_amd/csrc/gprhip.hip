@@ -428,7 +428,8 @@ int pick_kslices(int mp, int64_t rows_p, int max_slices, int64_t slice_rows) {
   double best_eff = 0.0;
   for (int ks = std::max(8, target - 16); ks <= std::min(max_slices / 8 * 8, target + 16); ks += 8) {
     if ((int64_t)ks * BK * 8 > rows_p && ks > 8) continue;
-    const int items = tiles * (ks / 8);
+    const int ksd = gemm_syrk_diag_slices(ks);  // items of one XCD: off-diagonal tiles per slice + the diagonal tiles' own slices
+    const int items = (tiles - nt) * (ks / 8) + nt * ((ksd + 7) / 8);
     const double eff = (double)items / ((double)((items + slots - 1) / slots) * slots);
     if (eff > best_eff + 1e-9) {
       best_eff = eff;
@@ -541,10 +542,11 @@ void do_pass1(gprhip_problem* p, const gprhip_hypers* h, int want_grad, int64_t 
     GPR_HIP(hipEventRecord(p->timer.k1, s));
     p->timer.k_recorded = true;
   }
-  launch_reduce_rows(p->gemvpart, ks, mp, ar1_c, 1, s);
+  const int ksd = gemm_syrk_diag_slices(ks);  // the diagonal tiles (which also store the column sums) use fewer, longer slices
+  launch_reduce_rows(p->gemvpart, ksd, mp, ar1_c, 1, s);
   tstop(p);
   p->ks_used = ks;
-  launch_sum_slices<TS>(nullptr, slices, ks, mm, mp, ar1, s, 1);
+  launch_sum_slices<TS>(nullptr, slices, ks, mm, mp, ar1, s, 1, ksd);
   p->stage = 1;
   p->have_v = true;  // (revoked by finish() if the factorisation of K_m turns out to have failed)
 }
@@ -684,7 +686,7 @@ void do_pass2(gprhip_problem* p, const double* ar1, double* ar2) {
     wg.kslices = p->ks_used; wg.slice_stride = mm;
     launch_gemm(OP_TN, wg, s);
     tstop(p);
-    launch_sum_slices<TS>(nullptr, slices, p->ks_used, mm, mp, ar2, s, 1);
+    launch_sum_slices<TS>(nullptr, slices, p->ks_used, mm, mp, ar2, s, 1, gemm_syrk_diag_slices(p->ks_used));
   }
   p->stage = 2;
 }

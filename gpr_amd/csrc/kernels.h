@@ -159,10 +159,11 @@ template <typename TS>
 void launch_grad_fused(const GradArgs<TS>& a, hipStream_t s);
 
 // ---- m x m finalisation (finalize.hip)
-// dst (upper tiles) = base + sum_z slices[z]
+// dst (upper tiles) = base + sum_z slices[z]; the diagonal tiles sum the first nslices_diag slices only (0 = nslices;
+// gemm_syrk_diag_slices for the result of a SYRK-shaped engine launch)
 template <typename TS>
 void launch_sum_slices(const double* base, const TS* slices, int nslices, int64_t stride, int mp,
-                       double* dst, hipStream_t s, int packed = 0);
+                       double* dst, hipStream_t s, int packed = 0, int nslices_diag = 0);
 // dst (float) = src (double), n elements: fp32 copies of U^-1 / R~^-1 for the fp32 contractions
 void launch_to_float(const double* src, float* dst, int64_t n, hipStream_t s);
 // W~ = I - B~^-1 - t~ t~^T - G~ as a full symmetric matrix (inputs valid on upper tiles);
