@@ -54,7 +54,8 @@ def cpu_baseline(m, d, seed):
     this host's cores on a bounded row sample of the same workload (its cost is linear in n).  A short run sizes the
     sample for ~15 s; a single-thread figure is measured on a smaller sample."""
     from oracle import fitc_ref as R
-    cores = os.cpu_count() or 1
+    host_cores = os.cpu_count() or 1
+    cores = R.usable_cores()      # affinity mask capped by the cgroup CPU quota: threads beyond it are only throttled
     le = 0.5 * np.log(d)
 
     def run(n_rows, threads):
@@ -79,14 +80,15 @@ def cpu_baseline(m, d, seed):
     n1 = 4096
     dt1, _ = run(n1, 1)
     return {"value": n_cpu / dt, "unit": "training-points/s", "cores": int(out["blas_threads"]), "kind": "port",
-            "host_cores": cores, "omp_threads": int(out["omp_threads"]),
+            "host_cores": host_cores, "usable_cores": cores, "omp_threads": int(out["omp_threads"]),
             "single_thread": {"value": n1 / dt1, "unit": "training-points/s", "rows": n1},
             "seconds": {k: float(v) for k, v in zip(("covariances", "chol_V_QR", "trained_inverses", "U_S_W_X",
                                                      "per_hyper_traces", "total"), out["secs"])},
             "sample": "oracle/fitc_ref.c (reference LAPACK sequence: potrf, trsm, geqrf+orgqr, potri x2, trsm x2, "
                       "syrk x2, per-hyper traces; covariance loops under OpenMP) on n=%d rows of the same m=%d d=%d "
-                      "workload, %.1f s, scipy OpenBLAS, %d BLAS threads on %d host cores"
-                      % (n_cpu, m, d, dt, int(out["blas_threads"]), cores)}
+                      "workload, %.1f s, scipy OpenBLAS, %d BLAS / OpenMP threads = the %d cores this container's CPU "
+                      "quota allows, of %d on the host"
+                      % (n_cpu, m, d, dt, int(out["blas_threads"]), cores, host_cores)}
 
 
 def profile_traffic(n, m):

@@ -419,7 +419,7 @@ void upload_hypers(gprhip_problem* p, const gprhip_hypers* h) {
 // against the L2 window, not by the slice length -- and the step is fastest with 8k..16k-row slices (381.6 ms;
 // 385 ms at 4k and at 32k), so slices are kept near `slice_rows`.  Among nearby factors the one whose
 // (tiles x slices / 8) fills whole residency rounds of an XCD (32 CUs x 2 blocks) is taken.
-int pick_kslices(int mp, int64_t rows_p, int max_slices, int64_t slice_rows) {
+int pick_kslices(int mp, int64_t rows_p, int max_slices, int64_t slice_rows, bool f64) {
   const int nt = mp / TILE, tiles = nt * (nt + 1) / 2;
   const int slots = 64;
   int target = (int)((rows_p / slice_rows + 7) / 8 * 8);
@@ -428,7 +428,7 @@ int pick_kslices(int mp, int64_t rows_p, int max_slices, int64_t slice_rows) {
   double best_eff = 0.0;
   for (int ks = std::max(8, target - 16); ks <= std::min(max_slices / 8 * 8, target + 16); ks += 8) {
     if ((int64_t)ks * BK * 8 > rows_p && ks > 8) continue;
-    const int ksd = gemm_syrk_diag_slices(ks);  // items of one XCD: off-diagonal tiles per slice + the diagonal tiles' own slices
+    const int ksd = gemm_syrk_diag_slices(ks, f64, true);  // items of one XCD: off-diagonal tiles per slice + the diagonal tiles' own slices
     const int items = (tiles - nt) * (ks / 8) + nt * ((ksd + 7) / 8);
     const double eff = (double)items / ((double)((items + slots - 1) / slots) * slots);
     if (eff > best_eff + 1e-9) {
@@ -522,7 +522,7 @@ void do_pass1(gprhip_problem* p, const gprhip_hypers* h, int want_grad, int64_t 
   // one SYRK-shaped launch over all rows of the shard (V is resident): B~_part = V^T diag(is) V
   // (R~^T R~ replaces the stacked QR's R, lib/fitc_gp.ml:170-182), and c~ = V^T (is .* y)
   const int64_t ktot = p->rows_total_padded();
-  const int ks = pick_kslices(mp, ktot, p->kslices, p->slice_rows);
+  const int ks = pick_kslices(mp, ktot, p->kslices, p->slice_rows, !p->f32);
   tstart(p, "p1_syrk_B");
   GemmArgsT<TS> b;
   b.A = Vstore; b.lda = mp; b.B = Vstore; b.ldb = mp; b.C = slices; b.ldc = mp;
@@ -542,7 +542,7 @@ void do_pass1(gprhip_problem* p, const gprhip_hypers* h, int want_grad, int64_t 
     GPR_HIP(hipEventRecord(p->timer.k1, s));
     p->timer.k_recorded = true;
   }
-  const int ksd = gemm_syrk_diag_slices(ks);  // the diagonal tiles (which also store the column sums) use fewer, longer slices
+  const int ksd = gemm_syrk_diag_slices(ks, !p->f32, true);  // the diagonal tiles (which also store the column sums) use fewer, longer slices
   launch_reduce_rows(p->gemvpart, ksd, mp, ar1_c, 1, s);
   tstop(p);
   p->ks_used = ks;
@@ -686,7 +686,7 @@ void do_pass2(gprhip_problem* p, const double* ar1, double* ar2) {
     wg.kslices = p->ks_used; wg.slice_stride = mm;
     launch_gemm(OP_TN, wg, s);
     tstop(p);
-    launch_sum_slices<TS>(nullptr, slices, p->ks_used, mm, mp, ar2, s, 1, gemm_syrk_diag_slices(p->ks_used));
+    launch_sum_slices<TS>(nullptr, slices, p->ks_used, mm, mp, ar2, s, 1, gemm_syrk_diag_slices(p->ks_used, !p->f32, false));
   }
   p->stage = 2;
 }

@@ -86,7 +86,7 @@ void launch_gemm(GemmOp op, const GemmArgsF& g, hipStream_t stream);
 
 // A weighted upper_only TN launch with A == B (SYRK-shaped) split `kslices` ways (a multiple of 8) gives its diagonal
 // tiles fewer, longer k-slices: their partial products (and the column sums) occupy slice buffers 0 .. this - 1 only.
-int gemm_syrk_diag_slices(int kslices);
+int gemm_syrk_diag_slices(int kslices, bool f64, bool col_sums);
 
 // Partial row sums the fused row reductions emit per 128-column tile (= wave columns of the engine geometry).
 int gemm_row_parts_per_tile();
