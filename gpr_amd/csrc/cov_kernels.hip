@@ -6,6 +6,7 @@
 // contraction), then exp(log_sf2 + inv_ell2_05 * r2).  Only the last-ulp behaviour of
 // exp() can differ from the CPU.
 #include "kernels.h"
+#include "exp_fast.h"
 
 namespace gprhip {
 
@@ -20,6 +21,7 @@ __global__ __launch_bounds__(256) void cov_cross_kernel(CovParams cp, const doub
                                                         int rows, int rows_p,
                                                         const double* __restrict__ Z, int m, int mp,
                                                         int d, TS* __restrict__ K) {
+  const ExpK ek = exp_consts();
   __shared__ double xs[32][DT];
   const int j = blockIdx.x * 256 + threadIdx.x;
   const int r0 = blockIdx.y * 32;
@@ -41,7 +43,7 @@ __global__ __launch_bounds__(256) void cov_cross_kernel(CovParams cp, const doub
       const double diff = xs[i][k] - z[k];
       acc = acc + diff * diff;
     }
-    const double val = (r0 + i < rows && live_col) ? exp(cp.log_sf2 + cp.inv_ell2_05 * acc) : 0.0;
+    const double val = (r0 + i < rows && live_col) ? exp_fast(cp.log_sf2 + cp.inv_ell2_05 * acc, ek) : 0.0;
     K[(int64_t)(r0 + i) * mp + j] = (TS)val;
   }
 }
@@ -53,6 +55,7 @@ __global__ __launch_bounds__(256) void cov_cross_ms_kernel(CovParams cp, const d
                                                            int rows, int rows_p,
                                                            const double* __restrict__ Z, int m, int mp,
                                                            int d, TS* __restrict__ K) {
+  const ExpK ek = exp_consts();
   __shared__ double xs[32][DT];
   const int j = blockIdx.x * 256 + threadIdx.x;
   const int r0 = blockIdx.y * 32;
@@ -79,7 +82,7 @@ __global__ __launch_bounds__(256) void cov_cross_ms_kernel(CovParams cp, const d
       const double diff = xs[i][k] - z[k];
       acc = (acc + diff * (diff / sc[k])) + lsc[k];
     }
-    const double val = (r0 + i < rows && live_col) ? exp(cp.log_sf2 + cp.inv_ell2_05 * acc) : 0.0;
+    const double val = (r0 + i < rows && live_col) ? exp_fast(cp.log_sf2 + cp.inv_ell2_05 * acc, ek) : 0.0;
     K[(int64_t)(r0 + i) * mp + j] = (TS)val;
   }
 }
@@ -90,6 +93,7 @@ __global__ __launch_bounds__(256) void cov_upper_ms_kernel(CovParams cp, const d
                                                            const double* __restrict__ het,
                                                            double* __restrict__ km,
                                                            double* __restrict__ kj) {
+  const ExpK ek = exp_consts();
   const int c = blockIdx.x * 256 + threadIdx.x;
   if (c >= mp) return;
   const int r0 = blockIdx.y * 32;
@@ -109,7 +113,7 @@ __global__ __launch_bounds__(256) void cov_upper_ms_kernel(CovParams cp, const d
 #pragma unroll
         for (int k = 0; k < DT; ++k)
           if (k < d) acc = acc + log(msc[k] + msc[k] - 1.0);   // lib/cov_se_fat.ml:128-131
-        val = exp(cp.log_sf2 + cp.inv_ell2_05 * acc);
+        val = exp_fast(cp.log_sf2 + cp.inv_ell2_05 * acc, ek);
         valj = (het ? val + het[c] : val) + jitter;
       } else {
         const double* x = Z + (int64_t)r * d;
@@ -122,7 +126,7 @@ __global__ __launch_bounds__(256) void cov_upper_ms_kernel(CovParams cp, const d
             acc = (acc + diff * (diff / scale)) + log(scale);
           }
         }
-        val = exp(cp.log_sf2 + cp.inv_ell2_05 * acc);
+        val = exp_fast(cp.log_sf2 + cp.inv_ell2_05 * acc, ek);
         valj = val;
       }
     } else if (r == c) {
@@ -139,6 +143,7 @@ __global__ __launch_bounds__(256) void cov_upper_kernel(CovParams cp, const doub
                                                         const double* __restrict__ het,
                                                         double* __restrict__ km,
                                                         double* __restrict__ kj) {
+  const ExpK ek = exp_consts();
   const int c = blockIdx.x * 256 + threadIdx.x;
   if (c >= mp) return;
   const int r0 = blockIdx.y * 32;
@@ -163,7 +168,7 @@ __global__ __launch_bounds__(256) void cov_upper_kernel(CovParams cp, const doub
             acc = acc + diff * diff;
           }
         }
-        val = exp(cp.log_sf2 + cp.inv_ell2_05 * acc);
+        val = exp_fast(cp.log_sf2 + cp.inv_ell2_05 * acc, ek);
         valj = val;
       }
     } else if (r == c) {
@@ -182,6 +187,7 @@ __global__ __launch_bounds__(256) void cov_cross_wide_kernel(CovParams cp, const
                                                              int rows, int rows_p,
                                                              const double* __restrict__ Z, int m, int mp,
                                                              int d, TS* __restrict__ K) {
+  const ExpK ek = exp_consts();
   __shared__ double xs[32][64];
   const int j = blockIdx.x * 256 + threadIdx.x;
   const int r0 = blockIdx.y * 32;
@@ -212,7 +218,7 @@ __global__ __launch_bounds__(256) void cov_cross_wide_kernel(CovParams cp, const
 #pragma unroll
   for (int i = 0; i < 32; ++i) {
     if (i < nr) {
-      const double val = (r0 + i < rows && live_col) ? exp(cp.log_sf2 + cp.inv_ell2_05 * acc[i]) : 0.0;
+      const double val = (r0 + i < rows && live_col) ? exp_fast(cp.log_sf2 + cp.inv_ell2_05 * acc[i], ek) : 0.0;
       K[(int64_t)(r0 + i) * mp + j] = (TS)val;
     }
   }
@@ -222,6 +228,7 @@ __global__ __launch_bounds__(256) void cov_upper_wide_kernel(CovParams cp, const
                                                              int mp, int d, double jitter,
                                                              const double* __restrict__ het,
                                                              double* __restrict__ km, double* __restrict__ kj) {
+  const ExpK ek = exp_consts();
   __shared__ double xs[32][64];
   const int c = blockIdx.x * 256 + threadIdx.x;
   const int r0 = blockIdx.y * 32;
@@ -257,7 +264,7 @@ __global__ __launch_bounds__(256) void cov_upper_wide_kernel(CovParams cp, const
           val = cp.sf2;
           valj = (het ? cp.sf2 + het[c] : cp.sf2) + jitter;
         } else {
-          val = exp(cp.log_sf2 + cp.inv_ell2_05 * acc[i]);
+          val = exp_fast(cp.log_sf2 + cp.inv_ell2_05 * acc[i], ek);
           valj = val;
         }
       } else if (r == c) {

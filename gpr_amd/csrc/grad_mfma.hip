@@ -14,6 +14,7 @@
 // l15), which is exactly four B operands (k = lq) of the next MFMAs: E never leaves the registers.
 // Workgroup: 4 wavefronts x 32 columns, one slab of 256 rows, rows staged through LDS 32 at a time.
 #include "kernels.h"
+#include "exp_fast.h"
 
 namespace gprhip {
 
@@ -38,9 +39,15 @@ template <int KS4, int DT, int BT, typename TS>
 __global__ __launch_bounds__(256, (DT + BT <= 4 && KS4 <= 8) ? 2 : 1) void grad_mfma_kernel(GradArgs<TS> a) {
   constexpr int DP = DT * 16, LDP = DP + 1;
   constexpr int BP = BT > 0 ? BT * 16 : 1, LDB = BP + 1;
-  __shared__ double ps[G_RC * LDP];
+  // Up to 16 point dimensions without projection hypers (the Cov_se_iso shapes): the staged points are double-buffered
+  // -- chunk c+1 is fetched into registers while chunk c is consumed, one barrier per chunk -- and the X values of
+  // the next row tile are loaded while the current one is computed.  The wider instantiations have no registers to
+  // spare for that and keep one staging buffer.
+  constexpr bool PF = (DT == 1 && BT == 0);
+  constexpr int NBUF = PF ? 2 : 1;
+  __shared__ double ps[NBUF * G_RC * LDP];
   __shared__ double bs[BT > 0 ? G_RC * LDB : 1];
-  __shared__ double pn[G_RC];
+  __shared__ double pn[NBUF * G_RC];
   __shared__ double red[4][2];
   __shared__ double sh[DP];  // the expansion offset, zero-padded
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -48,6 +55,7 @@ __global__ __launch_bounds__(256, (DT + BT <= 4 && KS4 <= 8) ? 2 : 1) void grad_
   __syncthreads();
   const int l15 = lane & 15, lq = lane >> 4;
   const int cb = blockIdx.x * 128 + wv * 32;
+  const ExpK ek = exp_consts();
 
   double zf[2][KS4], zn[2];
   bool live_c[2];
@@ -80,71 +88,130 @@ __global__ __launch_bounds__(256, (DT + BT <= 4 && KS4 <= 8) ? 2 : 1) void grad_
 
   const int r0 = blockIdx.y * G_SLAB;
   const int r1 = min(a.rows, r0 + G_SLAB);
-  for (int rb = r0; rb < r1; rb += G_RC) {
-    __syncthreads();
-    for (int idx = tid; idx < G_RC * DP; idx += 256) {
-      const int r = idx / DP, k = idx % DP;
-      ps[r * LDP + k] =
-          (k < a.d && rb + r < r1) ? a.pts[(int64_t)(rb + r) * a.d + k] - sh[k] : 0.0;
-    }
-    if (BT > 0) {
-      for (int idx = tid; idx < G_RC * BP; idx += 256) {
-        const int r = idx / BP, k = idx % BP;
-        bs[r * LDB + k] = (k < a.D && rb + r < r1) ? a.big[(int64_t)(rb + r) * a.D + k] : 0.0;
-      }
-    }
-    __syncthreads();
-    if (tid < G_RC) {
-      double s2 = 0.0;
-      for (int k = 0; k < DP; ++k) s2 += ps[tid * LDP + k] * ps[tid * LDP + k];
-      pn[tid] = s2;
-    }
-    __syncthreads();
-#pragma unroll 1  // one row tile's worth of registers: two wavefronts per SIMD stay resident
-    for (int rt = 0; rt < G_RC / 16; ++rt) {
-      if (rb + rt * 16 >= r1) break;
-      double xv[2][4];
+
+  // X values of one 16-row tile (rows first .. first+15) for this wave's 32 columns
+  auto load_x = [&](int first, double (&xv)[2][4]) {
 #pragma unroll
-      for (int jt = 0; jt < 2; ++jt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int row = rb + rt * 16 + lq + 4 * r;
-          xv[jt][r] = (row < r1) ? (double)a.X[(int64_t)row * a.mp + cb + jt * 16 + l15] : 0.0;
-        }
-      double ev[2][4];
-#pragma unroll
-      for (int jt = 0; jt < 2; ++jt) {
-        gd4 s4 = (gd4){0, 0, 0, 0};
-#pragma unroll
-        for (int s = 0; s < KS4; ++s) s4 = mfma4(ps[(rt * 16 + l15) * LDP + 4 * s + lq], zf[jt][s], s4);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int lr = rt * 16 + lq + 4 * r;
-          const double dist = fmax(pn[lr] + zn[jt] - 2.0 * s4[r], 0.0);
-          const double e = (live_c[jt] && rb + lr < r1) ? xv[jt][r] * exp(a.log_sf2 + a.inv_ell2_05 * dist) : 0.0;
-          ev[jt][r] = e;
-          cs[jt] += e;
-          sE += e;
-          sED += e * dist;
-        }
-      }
+    for (int jt = 0; jt < 2; ++jt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int prow = (rt * 16 + 4 * r + lq);
+        const int row = first + lq + 4 * r;
+        xv[jt][r] = (row < r1) ? (double)a.X[(int64_t)row * a.mp + cb + jt * 16 + l15] : 0.0;
+      }
+  };
+  // one 16-row tile: rows rb + 16 rt ... of the chunk staged at psb / bsb / pnb
+  auto tile = [&](const double* psb, const double* bsb, const double* pnb, int rb, int rt, const double (&xv)[2][4]) {
+    double ev[2][4];
 #pragma unroll
-        for (int t = 0; t < DT; ++t) {
-          const double ap = ps[prow * LDP + t * 16 + l15];
-          g[t][0] = mfma4(ap, ev[0][r], g[t][0]);
-          g[t][1] = mfma4(ap, ev[1][r], g[t][1]);
-        }
-        if (BT > 0) {
+    for (int jt = 0; jt < 2; ++jt) {
+      gd4 s4 = (gd4){0, 0, 0, 0};
 #pragma unroll
-          for (int t = 0; t < (BT > 0 ? BT : 1); ++t) {
-            const double ab = bs[prow * LDB + t * 16 + l15];
-            gb[t][0] = mfma4(ab, ev[0][r], gb[t][0]);
-            gb[t][1] = mfma4(ab, ev[1][r], gb[t][1]);
-          }
+      for (int s = 0; s < KS4; ++s) s4 = mfma4(psb[(rt * 16 + l15) * LDP + 4 * s + lq], zf[jt][s], s4);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int lr = rt * 16 + lq + 4 * r;
+        const double dist = fmax(pnb[lr] + zn[jt] - 2.0 * s4[r], 0.0);
+        const double kv = exp_fast(a.log_sf2 + a.inv_ell2_05 * dist, ek);
+        const double e = (live_c[jt] && rb + lr < r1) ? xv[jt][r] * kv : 0.0;
+        ev[jt][r] = e;
+        cs[jt] += e;
+        sE += e;
+        sED += e * dist;
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int prow = (rt * 16 + 4 * r + lq);
+#pragma unroll
+      for (int t = 0; t < DT; ++t) {
+        const double ap = psb[prow * LDP + t * 16 + l15];
+        g[t][0] = mfma4(ap, ev[0][r], g[t][0]);
+        g[t][1] = mfma4(ap, ev[1][r], g[t][1]);
+      }
+      if (BT > 0) {
+#pragma unroll
+        for (int t = 0; t < (BT > 0 ? BT : 1); ++t) {
+          const double ab = bsb[prow * LDB + t * 16 + l15];
+          gb[t][0] = mfma4(ab, ev[0][r], gb[t][0]);
+          gb[t][1] = mfma4(ab, ev[1][r], gb[t][1]);
         }
+      }
+    }
+  };
+
+  if constexpr (PF) {
+    // thread -> (row tid/16 + 16 j, dimension tid%16) of a chunk: the 16 lanes of a row also reduce its squared norm
+    constexpr int NPV = G_RC / 16;
+    const int sr = tid >> 4, sk = tid & 15;
+    double pv[NPV];
+    auto fetch_pts = [&](int rb) {
+#pragma unroll
+      for (int j = 0; j < NPV; ++j) {
+        const int row = rb + sr + 16 * j;
+        pv[j] = (sk < a.d && row < r1) ? a.pts[(int64_t)row * a.d + sk] - sh[sk] : 0.0;
+      }
+    };
+    auto store_pts = [&](int buf) {
+#pragma unroll
+      for (int j = 0; j < NPV; ++j) {
+        const int r = sr + 16 * j;
+        ps[buf * G_RC * LDP + r * LDP + sk] = pv[j];
+        double s2 = pv[j] * pv[j];
+        s2 += __shfl_xor(s2, 1);
+        s2 += __shfl_xor(s2, 2);
+        s2 += __shfl_xor(s2, 4);
+        s2 += __shfl_xor(s2, 8);
+        if (sk == 0) pn[buf * G_RC + r] = s2;
+      }
+    };
+    double xv[2][4], xn[2][4];
+    fetch_pts(r0);
+    load_x(r0, xv);
+    store_pts(0);
+    __syncthreads();
+    int buf = 0;
+    for (int rb = r0; rb < r1; rb += G_RC, buf ^= 1) {
+      const bool more = rb + G_RC < r1;
+      if (more) fetch_pts(rb + G_RC);
+#pragma unroll 1
+      for (int rt = 0; rt < G_RC / 16; ++rt) {
+        if (rb + rt * 16 >= r1) break;
+        load_x(rb + rt * 16 + 16, xn);  // rows beyond the slab load nothing
+        tile(ps + buf * G_RC * LDP, bs, pn + buf * G_RC, rb, rt, xv);
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) xv[jt][r] = xn[jt][r];
+      }
+      if (more) store_pts(buf ^ 1);
+      __syncthreads();
+    }
+  } else {
+    for (int rb = r0; rb < r1; rb += G_RC) {
+      __syncthreads();
+      for (int idx = tid; idx < G_RC * DP; idx += 256) {
+        const int r = idx / DP, k = idx % DP;
+        ps[r * LDP + k] = (k < a.d && rb + r < r1) ? a.pts[(int64_t)(rb + r) * a.d + k] - sh[k] : 0.0;
+      }
+      if (BT > 0) {
+        for (int idx = tid; idx < G_RC * BP; idx += 256) {
+          const int r = idx / BP, k = idx % BP;
+          bs[r * LDB + k] = (k < a.D && rb + r < r1) ? a.big[(int64_t)(rb + r) * a.D + k] : 0.0;
+        }
+      }
+      __syncthreads();
+      if (tid < G_RC) {
+        double s2 = 0.0;
+        for (int k = 0; k < DP; ++k) s2 += ps[tid * LDP + k] * ps[tid * LDP + k];
+        pn[tid] = s2;
+      }
+      __syncthreads();
+#pragma unroll 1  // one row tile's worth of registers: two wavefronts per SIMD stay resident
+      for (int rt = 0; rt < G_RC / 16; ++rt) {
+        if (rb + rt * 16 >= r1) break;
+        double xv[2][4];
+        load_x(rb + rt * 16, xv);
+        tile(ps, bs, pn, rb, rt, xv);
       }
     }
   }

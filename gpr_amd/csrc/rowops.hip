@@ -2,6 +2,7 @@
 // Wavefront reductions give diag(Q_nn)-type quantities; every cross-block sum goes through
 // a partial buffer that is reduced in a fixed order (bit-reproducible run to run).
 #include "kernels.h"
+#include "exp_fast.h"
 
 namespace gprhip {
 
@@ -240,6 +241,7 @@ int grad_slab_rows() { return GRAD_SLAB; }
 
 template <int DT, int DBT, typename TS>
 __global__ __launch_bounds__(256) void grad_fused_kernel(GradArgs<TS> a) {
+  const ExpK ek = exp_consts();
   __shared__ double red[4][2];
   __shared__ double xs[32][DT];                  // the 32 points being streamed, zero-padded to DT
   __shared__ double xbs[32][DBT > 0 ? DBT : 1];  // their original inputs (Cov_se_fat with tproj)
@@ -280,7 +282,7 @@ __global__ __launch_bounds__(256) void grad_fused_kernel(GradArgs<TS> a) {
         const double df = xs[i][k] - z[k];
         dist += df * df;
       }
-      const double e = live ? xv * exp(a.log_sf2 + a.inv_ell2_05 * dist) : 0.0;
+      const double e = live ? xv * exp_fast(a.log_sf2 + a.inv_ell2_05 * dist, ek) : 0.0;
 #pragma unroll
       for (int k = 0; k < DT; ++k) gx[k] += xs[i][k] * e;
 #pragma unroll
@@ -323,6 +325,7 @@ __global__ __launch_bounds__(256) void grad_fused_kernel(GradArgs<TS> a) {
 // multiscales, :585-595), reduced across wavefronts by launch_reduce_rowes.
 template <int DT, int DBT, typename TS>
 __global__ __launch_bounds__(256) void grad_fused_ms_kernel(GradArgs<TS> a) {
+  const ExpK ek = exp_consts();
   __shared__ double red[4];
   __shared__ double xs[32][DT];
   __shared__ double xbs[32][DBT > 0 ? DBT : 1];
@@ -371,7 +374,7 @@ __global__ __launch_bounds__(256) void grad_fused_ms_kernel(GradArgs<TS> a) {
         const double df = xs[i][k] - z[k];
         dist += df * df * isc[k];
       }
-      const double e = live ? xv * exp(a.log_sf2 + a.inv_ell2_05 * dist) : 0.0;
+      const double e = live ? xv * exp_fast(a.log_sf2 + a.inv_ell2_05 * dist, ek) : 0.0;
 #pragma unroll
       for (int k = 0; k < DT; ++k) {
         gx[k] += xs[i][k] * e;

@@ -16,6 +16,8 @@ from oracle import fitc_oracle as O
 from tests.staged_double import StagedDouble
 from tests.util import relinf, synth
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
 
 def test_iso_hyper_enumeration_matches_reference_order():
     k = cov_se_iso.Kernel.create(cov_se_iso.Params(0.3, -0.2))
@@ -187,3 +189,15 @@ def test_model_file_text_standardisation_and_roundtrip(tmp_path):
     assert np.array_equal(back.co_variance_coeffs[1], 2 * u)
     assert model_file.format_predictions([1.0, 2.5]) == "1.000000\n2.500000\n"
     assert model_file.format_predictions([1.0], [0.25]) == "1.000000,0.250000\n"
+
+
+def test_exp_fast_within_one_ulp_of_libm(tmp_path):
+    """gpr_amd/csrc/exp_fast.h (the exponential of the covariance and gradient kernels) compiled for the host: the
+    same IEEE fma sequence the device executes, against libm over the argument range the kernels produce."""
+    import subprocess
+    exe = tmp_path / "exp_check"
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-ffp-contract=off",
+                           os.path.join(ROOT, "tests", "cpp", "exp_check.cpp"), "-o", str(exe)])
+    out = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "special cases bad=0" in out.stdout
