@@ -300,19 +300,37 @@ void timestamps(GemmOp op, int M, int N, int K, int tri, const char* path) {
   int64_t ar = M, ac = K, br = op == OP_NT ? N : K, bc = op == OP_NT ? K : N;
   double *dA, *dB, *dC;
   hipMalloc(&dA, ar * ac * 8); hipMalloc(&dB, br * bc * 8); hipMalloc(&dC, (int64_t)M * N * 8);
-  hipMemset(dA, 0, ar * ac * 8); hipMemset(dB, 0, br * bc * 8);
+  {  // realistic operand values: the chip's clock under fp64 MFMA load depends on the data
+    std::vector<double> h(std::max(ar * ac, br * bc));
+    for (size_t i = 0; i < h.size(); ++i) h[i] = (double)((i * 2654435761u) & 0xffff) / 65536.0 - 0.5;
+    hipMemcpy(dB, h.data(), br * bc * 8, hipMemcpyHostToDevice);
+    const int data = getenv("DATA") ? atoi(getenv("DATA")) : 0;
+    if (data == 1)       // covariance-like A: exp(-1/2 chi^2_8)-distributed values in (0, 1]
+      for (size_t i = 0; i < (size_t)(ar * ac); ++i) {
+        double c2 = 0;
+        for (int k = 0; k < 8; ++k) { const double g = (double)(((i * 8 + k) * 2246822519u) & 0xffff) / 65536.0 - 0.5; c2 += 12.0 * g * g; }
+        h[i] = exp(-0.5 * c2);
+      }
+    else if (data == 2)  // full-mantissa random values of mixed magnitude
+      for (size_t i = 0; i < (size_t)(ar * ac); ++i) h[i] = ((double)rand() / RAND_MAX - 0.5) * exp(10.0 * ((double)rand() / RAND_MAX - 0.5));
+    hipMemcpy(dA, h.data(), ar * ac * 8, hipMemcpyHostToDevice);
+  }
   const int nwg = (M / 128) * (N / 128);
-  unsigned long long* dts; hipMalloc(&dts, (size_t)nwg * 64); hipMemset(dts, 0, (size_t)nwg * 64);
+  unsigned long long* dts; hipMalloc(&dts, (size_t)nwg * 128); hipMemset(dts, 0, (size_t)nwg * 128);
   GemmArgs g; g.A = dA; g.lda = ac; g.B = dB; g.ldb = bc; g.C = dC; g.ldc = N; g.M = M; g.N = N; g.K = K;
   g.tri = tri; g.order = getenv("ORD") ? atoi(getenv("ORD")) : 3;
   for (int i = 0; i < 2; ++i) launch_gemm(op, g, 0);
   g.lab_ts = dts;
   launch_gemm(op, g, 0);
   hipDeviceSynchronize();
-  std::vector<unsigned long long> h((size_t)nwg * 8);
+  std::vector<unsigned long long> h((size_t)nwg * 16);
   hipMemcpy(h.data(), dts, h.size() * 8, hipMemcpyDeviceToHost);
   FILE* f = fopen(path, "wb"); fwrite(h.data(), 8, h.size(), f); fclose(f);
-  printf("timestamps: %d workgroup records -> %s\n", nwg, path);
+  {
+    unsigned long long lo = ~0ull, hi = 0;
+    for (int w = 0; w < nwg; ++w) if (h[(size_t)w * 16 + 10]) { lo = std::min(lo, h[(size_t)w * 16 + 10]); for (int q = 0; q < 6; ++q) hi = std::max(hi, h[(size_t)w * 16 + q]); }
+    printf("timestamps: %d workgroup records -> %s; first start to last end %.1f us\n", nwg, path, (hi - lo) / 100.0);
+  }
   hipFree(dA); hipFree(dB); hipFree(dC); hipFree(dts);
 }
 
