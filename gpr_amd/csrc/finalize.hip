@@ -5,30 +5,56 @@ namespace gprhip {
 
 // dst = base + sum_z slices[z] on upper tiles (row tile <= column tile); dst is the mp x mp square (0 elsewhere) or,
 // packed, the upper tiles alone (packed_upper_off: the layout of the exchange buffers).
+// Each thread owns 16 bytes of a row (2 doubles / 4 floats: one vector load per slice), four slices in flight.
 template <typename TS>
 __global__ __launch_bounds__(256) void sum_slices_kernel(const double* __restrict__ base,
                                                          const TS* __restrict__ slices, int nslices,
                                                          int nslices_diag, int64_t stride, int mp, int packed,
                                                          double* __restrict__ dst) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
+  constexpr int V = 16 / (int)sizeof(TS);
+  typedef TS vec_t __attribute__((ext_vector_type(V)));
+  const int c = (blockIdx.x * 256 + threadIdx.x) * V;  // mp is a multiple of 128: a vector never straddles a tile
   const int r = blockIdx.y;
   if (c >= mp) return;
   const int64_t off = (int64_t)r * mp + c;
   const bool upper = r / TILE <= c / TILE;
-  double acc = 0.0;
+  double acc[V];
+#pragma unroll
+  for (int v = 0; v < V; ++v) acc[v] = 0.0;
   if (upper) {
-    acc = base ? base[off] : 0.0;
+    if (base) {
+#pragma unroll
+      for (int v = 0; v < V; ++v) acc[v] = base[off + v];
+    }
     const int nz = (r / TILE == c / TILE) ? nslices_diag : nslices;  // diagonal tiles of a SYRK launch: fewer slices
-    for (int z = 0; z < nz; ++z) acc += (double)slices[(int64_t)z * stride + off];
+    const TS* sp = slices + off;
+    int z = 0;
+    for (; z + 4 <= nz; z += 4) {
+      const vec_t a0 = *reinterpret_cast<const vec_t*>(sp + (int64_t)z * stride);
+      const vec_t a1 = *reinterpret_cast<const vec_t*>(sp + (int64_t)(z + 1) * stride);
+      const vec_t a2 = *reinterpret_cast<const vec_t*>(sp + (int64_t)(z + 2) * stride);
+      const vec_t a3 = *reinterpret_cast<const vec_t*>(sp + (int64_t)(z + 3) * stride);
+#pragma unroll
+      for (int v = 0; v < V; ++v) acc[v] = (((acc[v] + (double)a0[v]) + (double)a1[v]) + (double)a2[v]) + (double)a3[v];
+    }
+    for (; z < nz; ++z) {
+      const vec_t a0 = *reinterpret_cast<const vec_t*>(sp + (int64_t)z * stride);
+#pragma unroll
+      for (int v = 0; v < V; ++v) acc[v] += (double)a0[v];
+    }
   }
-  if (!packed) dst[off] = acc;
-  else if (upper) dst[packed_upper_off(r, c)] = acc;
+#pragma unroll
+  for (int v = 0; v < V; ++v) {
+    if (!packed) dst[off + v] = acc[v];
+    else if (upper) dst[packed_upper_off(r, c + v)] = acc[v];
+  }
 }
 
 template <typename TS>
 void launch_sum_slices(const double* base, const TS* slices, int nslices, int64_t stride, int mp,
                        double* dst, hipStream_t s, int packed, int nslices_diag) {
-  hipLaunchKernelGGL(sum_slices_kernel<TS>, dim3((mp + 255) / 256, mp), dim3(256), 0, s, base, slices,
+  constexpr int V = 16 / (int)sizeof(TS);
+  hipLaunchKernelGGL(sum_slices_kernel<TS>, dim3((mp / V + 255) / 256, mp), dim3(256), 0, s, base, slices,
                      nslices, nslices_diag > 0 ? nslices_diag : nslices, stride, mp, packed, dst);
   GPR_HIP(hipGetLastError());
 }

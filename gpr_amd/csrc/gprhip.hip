@@ -640,6 +640,7 @@ void do_pass2(gprhip_problem* p, const double* ar1, double* ar2) {
       ga.big = proj ? p->X + base * p->D : nullptr; ga.D = proj ? p->D : 0;
       ga.ms = p->cp.ms; ga.rowes = nullptr; ga.shift = p->zshift;
       ga.col_rows = p->d + 1 + ga.D + (ga.ms ? p->d : 0);  // rows this launch produces (tightly packed)
+      ga.slab = grad_slab_rows((int)p->col_rows());
       const int nslots = 4 * ((mp + 255) / 256);
       if (ga.ms && proj) {
         if (!p->rowes) {
@@ -661,7 +662,7 @@ void do_pass2(gprhip_problem* p, const double* ar1, double* ar2) {
         launch_grad_fused(ga, s);
         nbx = (mp + 255) / 256;
       }
-      const int nslabs = (int)((rows + grad_slab_rows() - 1) / grad_slab_rows());
+      const int nslabs = (int)((rows + ga.slab - 1) / ga.slab);
       launch_reduce_rows(p->colpart, nslabs, ga.col_rows * mp, ar2_col, 1, s);
       if (proj) {
         if (ga.ms) {
@@ -1306,7 +1307,8 @@ int gprhip_problem_create_ex(int device, int cov_kind, int precision, int64_t n,
     p->slices = p->alloc<char>(p->slices_bytes);
     p->rowpart = p->alloc<double>((int64_t)pass1_row_blocks((int)chunk) * 4);
     p->gemvpart = p->alloc<double>((int64_t)p->kslices * mp);  // c~ partials, one row per k-slice
-    const int64_t nslab = (chunk + grad_slab_rows() - 1) / grad_slab_rows();
+    const int64_t gslab = grad_slab_rows((int)p->col_rows());
+    const int64_t nslab = (chunk + gslab - 1) / gslab;
     p->colpart = p->alloc<double>(nslab * p->col_rows() * mp);
     p->scalpart = p->alloc<double>(nslab * (mp / TILE) * 2);
     p->zshift = p->alloc<double>(64);

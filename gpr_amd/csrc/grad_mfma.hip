@@ -12,7 +12,7 @@
 //   G += P^T E, Gb += X_big^T E  (the "inducing-gradient GEMM")
 // A 16x16 tile of E comes out of the elementwise step in the accumulator layout (lane holds rows lq + 4r of column
 // l15), which is exactly four B operands (k = lq) of the next MFMAs: E never leaves the registers.
-// Workgroup: 4 wavefronts x 32 columns, one slab of 256 rows, rows staged through LDS 32 at a time.
+// Workgroup: 4 wavefronts x 32 columns, one slab of a.slab rows, rows staged through LDS 32 at a time.
 #include "kernels.h"
 #include "exp_fast.h"
 
@@ -30,7 +30,6 @@ __device__ __forceinline__ double wsum(double v) {
   return v;
 }
 
-constexpr int G_SLAB = 256;  // must equal grad_slab_rows()
 constexpr int G_RC = 64;     // rows per staged chunk
 
 // KS4 = ceil(d / 4) k-steps of the distance product, DT = ceil(d / 16) tiles of point dimensions,
@@ -86,8 +85,8 @@ __global__ __launch_bounds__(256, (DT + BT <= 4 && KS4 <= 8) ? 2 : 1) void grad_
     for (int jt = 0; jt < 2; ++jt) gb[t][jt] = (gd4){0, 0, 0, 0};
   double cs[2] = {0.0, 0.0}, sE = 0.0, sED = 0.0;
 
-  const int r0 = blockIdx.y * G_SLAB;
-  const int r1 = min(a.rows, r0 + G_SLAB);
+  const int r0 = blockIdx.y * a.slab;
+  const int r1 = min(a.rows, r0 + a.slab);
 
   // X values of one 16-row tile (rows first .. first+15) for this wave's 32 columns
   auto load_x = [&](int first, double (&xv)[2][4]) {
@@ -273,7 +272,7 @@ int grad_mfma_col_blocks(const GradArgs<TS>& a) {
 
 template <typename TS>
 void launch_grad_mfma(const GradArgs<TS>& a, hipStream_t s) {
-  dim3 grid(a.mp / 128, (a.rows + G_SLAB - 1) / G_SLAB);
+  dim3 grid(a.mp / 128, (a.rows + a.slab - 1) / a.slab);
   if (a.d <= 4) dispatch_big<1, 1, TS>(a, grid, s);
   else if (a.d <= 8) dispatch_big<2, 1, TS>(a, grid, s);
   else if (a.d <= 16) dispatch_big<4, 1, TS>(a, grid, s);

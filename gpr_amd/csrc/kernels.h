@@ -134,6 +134,7 @@ struct GradArgs {
   double* colpart;       // out [nslabs][col_rows][mp]: row 0 = column sums of E, rows 1..d = sum_r p_kr E_rc,
                          //     rows d+1..d+D = sum_r x_big,r E_rc, then (multiscales) d rows sum_r p_kr^2 E_rc
   int col_rows;          // rows of one slab of colpart
+  int slab;              // training points per slab (grad_slab_rows)
   double* scalpart;      // out [nslabs][nbx][2]: sum E, sum E*sqr_diff
   const double* shift;   // [d] common offset (centroid of the inducing points) the MFMA kernel subtracts from points
                          //     and inducing points before it expands |p - z|^2, or null
@@ -146,7 +147,7 @@ void launch_proj_term2(const double* X, const double* P, const double* es, int e
                        double* part, hipStream_t s);
 // es[row][k] = sum_slot rowes[row][slot][k]
 void launch_reduce_rowes(const double* rowes, int rows, int nslots, int d, double* es, hipStream_t s);
-int grad_slab_rows();
+int grad_slab_rows(int col_rows);  // rows per slab of colpart / scalpart for a problem with that many accumulator rows
 // d > 64 or D > 64: E = X .* K with K of the chunk given in memory (see rowops.hip)
 template <typename TS>
 void launch_grad_wide(const GradArgs<TS>& a, const TS* K, hipStream_t s);

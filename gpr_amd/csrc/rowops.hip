@@ -236,8 +236,9 @@ void launch_reduce_rows(const double* partial, int nslabs, int width, double* ou
 //   `Dense      (Log_ell)       : tr(X^T (K.*D)) ell^-2 = ell^-2 sum E.*D      lib/cov_se_iso.ml:303-314
 //   `Sparse_cols (Inducing c,k) : scale * sum_r (x_kr - z_kc) E_rc             lib/cov_se_iso.ml:315-327
 // Thread <-> inducing column; rows stream through; per-thread accumulators in registers.
-constexpr int GRAD_SLAB = 256;
-int grad_slab_rows() { return GRAD_SLAB; }
+// Rows per slab of the gradient kernels' column partials: 256, or 1024 when a slab carries 32 or more accumulator rows
+// (wide points / projection hypers: the partials are then the kernels' main memory traffic).
+int grad_slab_rows(int col_rows) { return col_rows >= 32 ? 1024 : 256; }
 
 template <int DT, int DBT, typename TS>
 __global__ __launch_bounds__(256) void grad_fused_kernel(GradArgs<TS> a) {
@@ -258,8 +259,8 @@ __global__ __launch_bounds__(256) void grad_fused_kernel(GradArgs<TS> a) {
 #pragma unroll
   for (int k = 0; k < DBT; ++k) gb[k] = 0.0;
   double cs = 0.0, sE = 0.0, sED = 0.0;
-  const int r0 = blockIdx.y * GRAD_SLAB;
-  const int r1 = min(a.rows, r0 + GRAD_SLAB);
+  const int r0 = blockIdx.y * a.slab;
+  const int r1 = min(a.rows, r0 + a.slab);
   for (int rb = r0; rb < r1; rb += 32) {
     __syncthreads();
     for (int idx = threadIdx.x; idx < 32 * DT; idx += 256) {
@@ -350,8 +351,8 @@ __global__ __launch_bounds__(256) void grad_fused_ms_kernel(GradArgs<TS> a) {
 #pragma unroll
   for (int k = 0; k < DBT; ++k) gb[k] = 0.0;
   double cs = 0.0, sE = 0.0;
-  const int r0 = blockIdx.y * GRAD_SLAB;
-  const int r1 = min(a.rows, r0 + GRAD_SLAB);
+  const int r0 = blockIdx.y * a.slab;
+  const int r1 = min(a.rows, r0 + a.slab);
   for (int rb = r0; rb < r1; rb += 32) {
     __syncthreads();
     for (int idx = threadIdx.x; idx < 32 * DT; idx += 256) {
@@ -461,8 +462,8 @@ __global__ __launch_bounds__(256) void grad_wide_kernel(GradArgs<TS> a, const TS
 #pragma unroll
   for (int k = 0; k < 32; ++k) gx[k] = 0.0;
   double cs = 0.0, sED = 0.0;
-  const int r0 = blockIdx.y * GRAD_SLAB;
-  const int r1 = min(a.rows, r0 + GRAD_SLAB);
+  const int r0 = blockIdx.y * a.slab;
+  const int r1 = min(a.rows, r0 + a.slab);
   for (int rb = r0; rb < r1; rb += 32) {
     __syncthreads();
     for (int idx = threadIdx.x; idx < 32 * 32; idx += 256) {
@@ -511,7 +512,7 @@ void launch_grad_wide(const GradArgs<TS>& a, const TS* K, hipStream_t s) {
     throw HipFail{ST_BAD_ARG};
   }
   const int nz = (a.d + 31) / 32 + (a.big ? (a.D + 31) / 32 : 0);
-  dim3 grid((a.mp + 255) / 256, (a.rows + GRAD_SLAB - 1) / GRAD_SLAB, nz);
+  dim3 grid((a.mp + 255) / 256, (a.rows + a.slab - 1) / a.slab, nz);
   hipLaunchKernelGGL((grad_wide_kernel<TS>), grid, dim3(256), 0, s, a, K);
   GPR_HIP(hipGetLastError());
 }
@@ -520,25 +521,59 @@ template void launch_grad_wide<float>(const GradArgs<float>&, const float*, hipS
 
 // Cov_se_fat `Proj {big; small}` (lib/cov_se_fat.ml:570-596): second term of
 //   -tr(X^T dK) = -[ sum_c z_small,c sum_r x_big,r E_rc  -  sum_r x_big,r p_small,r rowsum(E)_r ]
+// One workgroup per slab of 256 rows; the slab's rows pass through LDS `rs` at a time (x_big as is, p_small already
+// multiplied by its weight), thread t accumulates outputs t, t + 256, ... (eight at a time).
 __global__ __launch_bounds__(256) void proj_term2_kernel(const double* __restrict__ X,
                                                          const double* __restrict__ P,
                                                          const double* __restrict__ es, int es_ld, int rows,
-                                                         int D, int d, double* __restrict__ part) {
-  const int r0 = blockIdx.y * 256, r1 = min(rows, r0 + 256);
-  for (int idx = blockIdx.x * 256 + threadIdx.x; idx < D * d; idx += gridDim.x * 256) {
-    const int big = idx / d, small = idx % d;
-    double acc = 0.0;
-    const int eo = es_ld > 1 ? small : 0;
-    for (int r = r0; r < r1; ++r)
-      acc += X[(int64_t)r * D + big] * P[(int64_t)r * d + small] * es[(int64_t)r * es_ld + eo];
-    part[(int64_t)blockIdx.y * D * d + idx] = acc;
+                                                         int D, int d, int rs, double* __restrict__ part) {
+  extern __shared__ __attribute__((aligned(16))) double proj_lds[];
+  double* const xs = proj_lds;                 // [rs][D]
+  double* const pw = proj_lds + (size_t)rs * D;  // [rs][d]
+  const int tid = threadIdx.x;
+  const int r0 = blockIdx.x * 256, r1 = min(rows, r0 + 256);
+  const int nout = D * d;
+  for (int o0 = 0; o0 < nout; o0 += 256 * 8) {
+    double acc[8];
+    int big[8], small[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int idx = min(o0 + q * 256 + tid, nout - 1);
+      acc[q] = 0.0;
+      big[q] = idx / d;
+      small[q] = idx % d;
+    }
+    for (int rb = r0; rb < r1; rb += rs) {
+      const int nr = min(rs, r1 - rb);
+      __syncthreads();
+      for (int i = tid; i < nr * D; i += 256) xs[i] = X[(int64_t)rb * D + i];
+      for (int i = tid; i < nr * d; i += 256) {
+        const int r = i / d, k = i % d;
+        pw[i] = P[(int64_t)rb * d + i] * es[(int64_t)(rb + r) * es_ld + (es_ld > 1 ? k : 0)];
+      }
+      __syncthreads();
+      for (int r = 0; r < nr; ++r) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) acc[q] += xs[r * D + big[q]] * pw[r * d + small[q]];
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int idx = o0 + q * 256 + tid;
+      if (idx < nout) part[(int64_t)blockIdx.x * nout + idx] = acc[q];
+    }
   }
 }
 
 void launch_proj_term2(const double* X, const double* P, const double* es, int es_ld, int rows, int D, int d,
                        double* part, hipStream_t s) {
-  dim3 grid((D * d + 255) / 256, (rows + 255) / 256);
-  hipLaunchKernelGGL(proj_term2_kernel, grid, dim3(256), 0, s, X, P, es, es_ld, rows, D, d, part);
+  int rs = (int)std::min<int64_t>(64, (48 * 1024) / ((int64_t)(D + d) * 8));
+  if (rs < 1) {
+    set_error("gprhip: Cov_se_fat projection gradient: D + d too large for the staging buffer");
+    throw HipFail{ST_BAD_ARG};
+  }
+  hipLaunchKernelGGL(proj_term2_kernel, dim3((rows + 255) / 256), dim3(256), (size_t)rs * (D + d) * 8, s, X, P, es, es_ld,
+                     rows, D, d, rs, part);
   GPR_HIP(hipGetLastError());
 }
 
@@ -566,7 +601,7 @@ static void grad_dispatch_big(const GradArgs<TS>& a, dim3 grid, hipStream_t s) {
 
 template <typename TS>
 void launch_grad_fused(const GradArgs<TS>& a, hipStream_t s) {
-  dim3 grid((a.mp + 255) / 256, (a.rows + GRAD_SLAB - 1) / GRAD_SLAB);
+  dim3 grid((a.mp + 255) / 256, (a.rows + a.slab - 1) / a.slab);
   if (a.d <= 4) grad_dispatch_big<4, TS>(a, grid, s);
   else if (a.d <= 8) grad_dispatch_big<8, TS>(a, grid, s);
   else if (a.d <= 16) grad_dispatch_big<16, TS>(a, grid, s);

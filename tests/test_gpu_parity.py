@@ -822,6 +822,8 @@ def _run_mirror_check(tmp_path, g, Xt, variational):
             f.write(np.asfortranarray(a, dtype=np.float64).tobytes(order="F"))
     out = subprocess.run([exe, str(path)], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr[-2000:]
+    if out.stderr:
+        print(out.stderr[-2000:])  # shown by pytest when an assertion on the parsed results fails
     res = {}
     for line in out.stdout.splitlines():
         key, *vals = line.split()
