@@ -1,4 +1,6 @@
 #!/bin/bash
+# Whole-evaluation and per-stage times at the row counts one GPU holds when n=1M is split over 8 / 4 GPUs
+# (profiles/rNN_shard_sizes.txt).  usage (GPU box, repo root): bash tools/shard_sizes.sh
 set -u
 root=$(pwd)
 for n in 125000 250000; do
