@@ -595,6 +595,7 @@ void do_pass2(gprhip_problem* p, const double* ar1, double* ar2) {
     tstart(p, "inverses");
     triu_xxt(p, p->rinv, p->binv);  // B~^-1 (upper tiles)
     tstop(p);
+    bool derive_inducing = false;
     for (int c = 0; c < p->nchunks; ++c) {
       const int64_t rows = p->rows_of(c);
       const int rows_p = (int)round_up(rows, TILE);
@@ -657,8 +658,10 @@ void do_pass2(gprhip_problem* p, const double* ar1, double* ar2) {
         cov_chunk<TS>(p, c, bufB);
         launch_grad_wide(ga, static_cast<const TS*>(bufB), s);
         nbx = (mp + 255) / 256;
-      } else if (nbx > 0) launch_grad_mfma(ga, s);
-      else {
+      } else if (nbx > 0) {
+        launch_grad_mfma(ga, s);
+        derive_inducing = proj;  // that kernel accumulates only the projection-gradient sums (grad_mfma.hip)
+      } else {
         launch_grad_fused(ga, s);
         nbx = (mp + 255) / 256;
       }
@@ -678,6 +681,7 @@ void do_pass2(gprhip_problem* p, const double* ar1, double* ar2) {
       launch_reduce_rows(p->scalpart, nslabs * nbx, 2, ar2_tail + A2_SUME, 1, s);
       tstop(p);
     }
+    if (derive_inducing) launch_proj_inducing_grad(ar2_col, mp, p->d, p->D, p->tproj, s);
     // G~_part = V^T diag(v) V over all rows (the two dsyrk of lib/fitc_gp.ml:1198-1203, whitened, in one)
     const int64_t ktot = p->rows_total_padded();
     tstart(p, "p2_syrk_W");

@@ -9,7 +9,9 @@
 //   S = P Z^T  (the "distance GEMM" of SURVEY 8(d)):  |p_r - z_c|^2 = |p_r|^2 + |z_c|^2 - 2 S_rc
 //     (both sides are first shifted by the centroid of the inducing points, so the expansion loses digits only
 //      relative to the spread of the data, not to a common offset; sum_r p_kr E_rc is corrected by shift_k * sum_r E_rc)
-//   G += P^T E, Gb += X_big^T E  (the "inducing-gradient GEMM")
+//   G += P^T E, Gb += X_big^T E  (the "inducing-gradient GEMM"); with projection hypers only Gb is accumulated --
+//     P = X_big tproj, so G = tproj^T Gb follows from the reduced sums (launch_proj_inducing_grad, once per pass)
+//     and a third of the kernel's MFMAs goes away
 // A 16x16 tile of E comes out of the elementwise step in the accumulator layout (lane holds rows lq + 4r of column
 // l15), which is exactly four B operands (k = lq) of the next MFMAs: E never leaves the registers.
 // Workgroup: 4 wavefronts x 32 columns, one slab of a.slab rows, rows staged through LDS 32 at a time.
@@ -121,11 +123,13 @@ __global__ __launch_bounds__(256, (DT + BT <= 4 && KS4 <= 8) ? 2 : 1) void grad_
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int prow = (rt * 16 + 4 * r + lq);
+      if (BT == 0) {
 #pragma unroll
-      for (int t = 0; t < DT; ++t) {
-        const double ap = psb[prow * LDP + t * 16 + l15];
-        g[t][0] = mfma4(ap, ev[0][r], g[t][0]);
-        g[t][1] = mfma4(ap, ev[1][r], g[t][1]);
+        for (int t = 0; t < DT; ++t) {
+          const double ap = psb[prow * LDP + t * 16 + l15];
+          g[t][0] = mfma4(ap, ev[0][r], g[t][0]);
+          g[t][1] = mfma4(ap, ev[1][r], g[t][1]);
+        }
       }
       if (BT > 0) {
 #pragma unroll
@@ -228,7 +232,7 @@ __global__ __launch_bounds__(256, (DT + BT <= 4 && KS4 <= 8) ? 2 : 1) void grad_
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int dim = t * 16 + lq + 4 * r;
-        if (dim < a.d) cp[(int64_t)(1 + dim) * a.mp + col] = g[t][jt][r] + sh[dim] * c;
+        if (dim < a.d) cp[(int64_t)(1 + dim) * a.mp + col] = (BT == 0) ? g[t][jt][r] + sh[dim] * c : 0.0;
       }
     if (BT > 0) {
 #pragma unroll
@@ -278,6 +282,20 @@ void launch_grad_mfma(const GradArgs<TS>& a, hipStream_t s) {
   else if (a.d <= 16) dispatch_big<4, 1, TS>(a, grid, s);
   else if (a.d <= 32) dispatch_big<8, 2, TS>(a, grid, s);
   else dispatch_big<16, 4, TS>(a, grid, s);
+  GPR_HIP(hipGetLastError());
+}
+
+// rows 1..d of the reduced column accumulators from rows d+1..d+D:  sum_r p_kr E_rc = sum_b tproj(b, k) sum_r x_br E_rc
+__global__ __launch_bounds__(256) void proj_inducing_grad_kernel(double* __restrict__ acc, int mp, int d, int D,
+                                                                 const double* __restrict__ tproj) {
+  const int c = blockIdx.x * 256 + threadIdx.x, k = blockIdx.y;
+  if (c >= mp) return;
+  double s = 0.0;
+  for (int b = 0; b < D; ++b) s += tproj[(int64_t)k * D + b] * acc[(int64_t)(d + 1 + b) * mp + c];
+  acc[(int64_t)(1 + k) * mp + c] += s;
+}
+void launch_proj_inducing_grad(double* acc, int mp, int d, int D, const double* tproj, hipStream_t s) {
+  hipLaunchKernelGGL(proj_inducing_grad_kernel, dim3((mp + 255) / 256, d), dim3(256), 0, s, acc, mp, d, D, tproj);
   GPR_HIP(hipGetLastError());
 }
 

@@ -154,6 +154,9 @@ void launch_grad_wide(const GradArgs<TS>& a, const TS* K, hipStream_t s);
 // the same pass on the matrix cores (grad_mfma.hip): column blocks of 128, or 0 if the launch is not eligible
 template <typename TS>
 int grad_mfma_col_blocks(const GradArgs<TS>& a);
+// with projection hypers the matrix-core kernel leaves rows 1..d of the column accumulators zero: after the slabs of
+// all chunks are reduced, acc[1 + k] += sum_b tproj(b, k) acc[d + 1 + b]   (acc: [col_rows][mp])
+void launch_proj_inducing_grad(double* acc, int mp, int d, int D, const double* tproj, hipStream_t s);
 template <typename TS>
 void launch_grad_mfma(const GradArgs<TS>& a, hipStream_t s);
 template <typename TS>
