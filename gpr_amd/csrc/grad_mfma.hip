@@ -40,14 +40,14 @@ template <int KS4, int DT, int BT, typename TS>
 __global__ __launch_bounds__(256, (DT + BT <= 4 && KS4 <= 8) ? 2 : 1) void grad_mfma_kernel(GradArgs<TS> a) {
   constexpr int DP = DT * 16, LDP = DP + 1;
   constexpr int BP = BT > 0 ? BT * 16 : 1, LDB = BP + 1;
-  // Up to 16 point dimensions without projection hypers (the Cov_se_iso shapes): the staged points are double-buffered
-  // -- chunk c+1 is fetched into registers while chunk c is consumed, one barrier per chunk -- and the X values of
-  // the next row tile are loaded while the current one is computed.  The wider instantiations have no registers to
-  // spare for that and keep one staging buffer.
-  constexpr bool PF = (DT == 1 && BT == 0);
+  // Up to 32 point dimensions and 32 input dimensions: the staged points are double-buffered -- chunk c+1 is fetched
+  // into registers while chunk c is consumed, one barrier per chunk -- and the X values of the next row tile are
+  // loaded while the current one is computed.  The wider instantiations have no registers (and no LDS) to spare for
+  // that and keep one staging buffer.
+  constexpr bool PF = (DT <= 2 && BT <= 2);
   constexpr int NBUF = PF ? 2 : 1;
   __shared__ double ps[NBUF * G_RC * LDP];
-  __shared__ double bs[BT > 0 ? G_RC * LDB : 1];
+  __shared__ double bs[BT > 0 ? NBUF * G_RC * LDB : 1];
   __shared__ double pn[NBUF * G_RC];
   __shared__ double red[4][2];
   __shared__ double sh[DP];  // the expansion offset, zero-padded
@@ -143,28 +143,43 @@ __global__ __launch_bounds__(256, (DT + BT <= 4 && KS4 <= 8) ? 2 : 1) void grad_
   };
 
   if constexpr (PF) {
-    // thread -> (row tid/16 + 16 j, dimension tid%16) of a chunk: the 16 lanes of a row also reduce its squared norm
-    constexpr int NPV = G_RC / 16;
-    const int sr = tid >> 4, sk = tid & 15;
-    double pv[NPV];
+    // thread -> (row tid/DP + (256/DP) j, dimension tid%DP) of a chunk: the DP lanes of a row also reduce its squared
+    // norm; the original inputs (projection hypers) are staged the same way with BP lanes per row
+    constexpr int RPP = 256 / DP, NPV = G_RC / RPP;
+    constexpr int RPB = 256 / BP, NBV = BT > 0 ? G_RC / RPB : 1;
+    const int sr = tid / DP, sk = tid % DP;
+    const int br_ = tid / BP, bk = tid % BP;
+    double pv[NPV], bv[NBV];
     auto fetch_pts = [&](int rb) {
 #pragma unroll
       for (int j = 0; j < NPV; ++j) {
-        const int row = rb + sr + 16 * j;
+        const int row = rb + sr + RPP * j;
         pv[j] = (sk < a.d && row < r1) ? a.pts[(int64_t)row * a.d + sk] - sh[sk] : 0.0;
+      }
+      if constexpr (BT > 0) {
+#pragma unroll
+        for (int j = 0; j < NBV; ++j) {
+          const int row = rb + br_ + RPB * j;
+          bv[j] = (bk < a.D && row < r1) ? a.big[(int64_t)row * a.D + bk] : 0.0;
+        }
       }
     };
     auto store_pts = [&](int buf) {
 #pragma unroll
       for (int j = 0; j < NPV; ++j) {
-        const int r = sr + 16 * j;
+        const int r = sr + RPP * j;
         ps[buf * G_RC * LDP + r * LDP + sk] = pv[j];
         double s2 = pv[j] * pv[j];
         s2 += __shfl_xor(s2, 1);
         s2 += __shfl_xor(s2, 2);
         s2 += __shfl_xor(s2, 4);
         s2 += __shfl_xor(s2, 8);
+        if constexpr (DP == 32) s2 += __shfl_xor(s2, 16);
         if (sk == 0) pn[buf * G_RC + r] = s2;
+      }
+      if constexpr (BT > 0) {
+#pragma unroll
+        for (int j = 0; j < NBV; ++j) bs[buf * G_RC * LDB + (br_ + RPB * j) * LDB + bk] = bv[j];
       }
     };
     double xv[2][4], xn[2][4];
@@ -180,7 +195,7 @@ __global__ __launch_bounds__(256, (DT + BT <= 4 && KS4 <= 8) ? 2 : 1) void grad_
       for (int rt = 0; rt < G_RC / 16; ++rt) {
         if (rb + rt * 16 >= r1) break;
         load_x(rb + rt * 16 + 16, xn);  // rows beyond the slab load nothing
-        tile(ps + buf * G_RC * LDP, bs, pn + buf * G_RC, rb, rt, xv);
+        tile(ps + buf * G_RC * LDP, bs + (BT > 0 ? buf * G_RC * LDB : 0), pn + buf * G_RC, rb, rt, xv);
 #pragma unroll
         for (int jt = 0; jt < 2; ++jt)
 #pragma unroll
