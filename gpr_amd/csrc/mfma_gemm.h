@@ -45,7 +45,6 @@ struct GemmArgsT {
   int upper_only = 0;    // compute only tiles with row tile <= column tile
   int order = 0;         // block -> tile order of full grids (see tile_of_block)
   int ipw = 1;           // items per workgroup (set by launch_gemm: 2 for the paired order 3)
-  int stagger = 0;       // set by launch_gemm: paired launch whose first round is staggered (gemm_body)
   int syrk = 0;          // set by launch_gemm: weighted TN launch with A == B and upper_only (diagonal tiles skip their lower sub-tiles)
   int dslices = 0;       // set by launch_gemm: k-slices of the diagonal tiles of such a launch (gemm_syrk_diag_slices), 0 = as kslices
   int nbatch = 1;        // independent problems of identical shape: gridDim.y, pointers advance by the strides
@@ -75,7 +74,6 @@ struct GemmArgsT {
   const double* rp_vec = nullptr;
   int lab_skip = 0;  // tools/gemm_check.hip only (timing ablation): 1 = no epilogue at all
   unsigned long long* lab_ts = nullptr;  // tools/gemm_check.hip only: 8 words per workgroup (phase time stamps, HW_ID, XCC_ID)
-  int lab_phase = 0, lab_delay = 0;  // tools/gemm_check.hip only: workgroups < 512 with bit lab_phase set sleep lab_delay x 3.4 us first
 };
 using GemmArgs = GemmArgsT<double>;
 using GemmArgsF = GemmArgsT<float>;

@@ -121,7 +121,6 @@ void timeit(GemmOp op, int M, int N, int K, int tri, int upper, int kslices, con
   double* dS = nullptr; if (scale) { hipMalloc(&dS, (int64_t)K * 8); hipMemcpy(dS, h.data(), (int64_t)K * 8, hipMemcpyHostToDevice); }
   GemmArgs g; g.scale_k = dS; g.A = dA; g.lda = ac; g.B = dB; g.ldb = bc; g.C = dC; g.ldc = N; g.M = M; g.N = N; g.K = K;
   g.tri = tri; g.upper_only = upper; g.kslices = kslices; g.order = getenv("ORD") ? atoi(getenv("ORD")) : 0; g.slice_stride = (int64_t)M * N; g.lab_skip = getenv("SKIP") ? atoi(getenv("SKIP")) : 0;
-  g.lab_phase = getenv("PHASE") ? atoi(getenv("PHASE")) : 0; g.lab_delay = getenv("DELAY") ? atoi(getenv("DELAY")) : 0;
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   for (int i = 0; i < 2; ++i) launch_gemm(op, g, 0);
   hipEventRecord(e0, 0);
@@ -393,7 +392,7 @@ int main() {
   bad += check(OP_NN, 128, 256, 48, TRI_NONE, false);
   bad += check(OP_NN, 8192, 512, 512, TRI_KHI_BN, false);   // 64 row panels: the paired order (ORD=3) applies
   bad += check(OP_NT, 8192, 512, 512, TRI_KLO_BN, false);
-  bad += check(OP_NN, 32768, 1024, 1024, TRI_KHI_BN, false);  // 1024 pairs: the staggered first round applies (ORD=3)
+  bad += check(OP_NN, 32768, 1024, 1024, TRI_KHI_BN, false);  // 1024 pairs (ORD=3): several residency rounds
   bad += check(OP_NT, 32768, 1024, 1024, TRI_KLO_BN, false);
   if (getenv("RP")) {
     bad += check(OP_NN, 8192, 2048, 2048, TRI_KHI_BN, false);
