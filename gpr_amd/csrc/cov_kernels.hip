@@ -342,11 +342,95 @@ void launch_cov_upper(const CovParams& cp, const double* Z, int m, int mp, int d
   GPR_HIP(hipGetLastError());
 }
 
+// fp32-bulk mode, 16..64 point dimensions: the distance through the matrix cores.  K is rounded to fp32 on store in
+// that mode, so the rounding sequence of the reference's direct differences is not preserved anyway, and above 16
+// dimensions the scalar kernel is bound by its 3 d fp64 instructions per element:
+//   |p - z|^2 = |p|^2 + |z|^2 - 2 S,  S = P Z^T as v_mfma_f64_16x16x4_f64 tiles, both sides shifted by the centroid of
+//   the inducing points first (the expansion then loses digits only relative to the spread of the data).
+// Workgroup: 4 wavefronts x 32 columns, a slab of 256 rows staged through LDS 64 rows at a time (as grad_mfma.hip).
+typedef double cd4 __attribute__((ext_vector_type(4)));
+template <int KS4, typename TS>
+__global__ __launch_bounds__(256) void cov_cross_mfma_kernel(CovParams cp, const double* __restrict__ pts, int rows,
+                                                             int rows_p, const double* __restrict__ Z, int m, int mp,
+                                                             int d, const double* __restrict__ shift,
+                                                             TS* __restrict__ K) {
+  constexpr int DP = KS4 * 4, LDP = DP + 1, RC = 64, SLAB = 256;
+  const ExpK ek = exp_consts();
+  __shared__ double ps[RC * LDP];
+  __shared__ double pn[RC];
+  __shared__ double sh[DP];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  if (tid < DP) sh[tid] = tid < d ? shift[tid] : 0.0;
+  __syncthreads();
+  const int l15 = lane & 15, lq = lane >> 4;
+  const int cb = blockIdx.x * 128 + wv * 32;
+  double zf[2][KS4], zn[2];
+  bool live_c[2];
+#pragma unroll
+  for (int jt = 0; jt < 2; ++jt) {
+    const int col = cb + jt * 16 + l15;
+    live_c[jt] = col < m;
+    double s2 = 0.0;
+#pragma unroll
+    for (int s = 0; s < KS4; ++s) {
+      const int k = 4 * s + lq;
+      const double z = (live_c[jt] && k < d) ? Z[(int64_t)col * d + k] - sh[k] : 0.0;
+      zf[jt][s] = z;
+      s2 = __builtin_fma(z, z, s2);
+    }
+    s2 += __shfl_xor(s2, 16);
+    s2 += __shfl_xor(s2, 32);
+    zn[jt] = s2;
+  }
+  const int r0 = blockIdx.y * SLAB, r1 = min(rows_p, r0 + SLAB);
+  for (int rb = r0; rb < r1; rb += RC) {
+    __syncthreads();
+    for (int idx = tid; idx < RC * DP; idx += 256) {
+      const int r = idx / DP, k = idx % DP;
+      ps[r * LDP + k] = (k < d && rb + r < rows) ? pts[(int64_t)(rb + r) * d + k] - sh[k] : 0.0;
+    }
+    __syncthreads();
+    if (tid < RC) {
+      double s2 = 0.0;
+      for (int k = 0; k < DP; ++k) s2 = __builtin_fma(ps[tid * LDP + k], ps[tid * LDP + k], s2);
+      pn[tid] = s2;
+    }
+    __syncthreads();
+    for (int rt = 0; rt < RC / 16; ++rt) {
+      if (rb + rt * 16 >= r1) break;
+#pragma unroll
+      for (int jt = 0; jt < 2; ++jt) {
+        cd4 s4 = (cd4){0, 0, 0, 0};
+#pragma unroll
+        for (int s = 0; s < KS4; ++s)
+          s4 = __builtin_amdgcn_mfma_f64_16x16x4f64(ps[(rt * 16 + l15) * LDP + 4 * s + lq], zf[jt][s], s4, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int lr = rt * 16 + lq + 4 * r, row = rb + lr;
+          const double dist = fmax(__builtin_fma(-2.0, s4[r], pn[lr] + zn[jt]), 0.0);
+          const double kv = exp_fast(__builtin_fma(cp.inv_ell2_05, dist, cp.log_sf2), ek);
+          if (row < r1) K[(int64_t)row * mp + cb + jt * 16 + l15] = (TS)((row < rows && live_c[jt]) ? kv : 0.0);
+        }
+      }
+    }
+  }
+}
+
 template <typename TS>
 void launch_cov_cross(const CovParams& cp, const double* pts, int rows, int rows_p, const double* Z,
-                      int m, int mp, int d, TS* K, hipStream_t s) {
-  dim3 grid(mp / 256 + (mp % 256 ? 1 : 0), (rows_p + 31) / 32);
+                      int m, int mp, int d, TS* K, hipStream_t s, const double* shift) {
   no_wide_multiscales(cp, d);
+  if constexpr (sizeof(TS) == 4) {
+    if (shift && !cp.ms && d >= 16 && d <= 64 && mp % 128 == 0) {
+      dim3 g2(mp / 128, (rows_p + 255) / 256);
+      if (d <= 16) hipLaunchKernelGGL((cov_cross_mfma_kernel<4, TS>), g2, dim3(256), 0, s, cp, pts, rows, rows_p, Z, m, mp, d, shift, K);
+      else if (d <= 32) hipLaunchKernelGGL((cov_cross_mfma_kernel<8, TS>), g2, dim3(256), 0, s, cp, pts, rows, rows_p, Z, m, mp, d, shift, K);
+      else hipLaunchKernelGGL((cov_cross_mfma_kernel<16, TS>), g2, dim3(256), 0, s, cp, pts, rows, rows_p, Z, m, mp, d, shift, K);
+      GPR_HIP(hipGetLastError());
+      return;
+    }
+  }
+  dim3 grid(mp / 256 + (mp % 256 ? 1 : 0), (rows_p + 31) / 32);
   dispatch_dt(d, [&](auto dt) {
     constexpr int DT = decltype(dt)::value;
     if constexpr (DT == 0)
@@ -359,9 +443,9 @@ void launch_cov_cross(const CovParams& cp, const double* pts, int rows, int rows
   GPR_HIP(hipGetLastError());
 }
 template void launch_cov_cross<double>(const CovParams&, const double*, int, int, const double*, int, int, int,
-                                       double*, hipStream_t);
+                                       double*, hipStream_t, const double*);
 template void launch_cov_cross<float>(const CovParams&, const double*, int, int, const double*, int, int, int,
-                                      float*, hipStream_t);
+                                      float*, hipStream_t, const double*);
 
 void launch_project(const double* X, int64_t n, int D, int d, const double* tproj, double* P,
                     hipStream_t s) {

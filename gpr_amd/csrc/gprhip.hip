@@ -444,7 +444,7 @@ void cov_chunk(gprhip_problem* p, int c, TS* K) {
   const int64_t rows = p->rows_of(c);
   const int64_t rows_p = round_up(rows, TILE);
   const double* pts = p->pts() + (int64_t)c * p->chunk * p->d;
-  launch_cov_cross<TS>(p->cp, pts, (int)rows, (int)rows_p, p->Z, p->m, p->mp, p->d, K, p->stream);
+  launch_cov_cross<TS>(p->cp, pts, (int)rows, (int)rows_p, p->Z, p->m, p->mp, p->d, K, p->stream, p->zshift);
 }
 
 template <typename TS>

@@ -29,9 +29,11 @@ void launch_cov_upper(const CovParams& cp, const double* Z, int m, int mp, int d
 // rows in [rows, rows_p) and columns in [m, mp) are written as 0.
 // TS = storage type of the n x m matrices (double, or float for the fp32-bulk mode: distances and
 // exp are still evaluated in fp64, only the stored value is rounded).
+// shift (optional, [d]: centroid of the inducing points): lets the fp32-bulk mode with 16..64 point dimensions take
+// the matrix-core distance kernel (cov_cross_mfma_kernel); fp64 storage always runs the direct-difference kernels.
 template <typename TS>
 void launch_cov_cross(const CovParams& cp, const double* pts, int rows, int rows_p, const double* Z,
-                      int m, int mp, int d, TS* K, hipStream_t s);
+                      int m, int mp, int d, TS* K, hipStream_t s, const double* shift = nullptr);
 
 // Cov_se_fat.Eval.Inputs.project (lib/cov_se_fat.ml:215-218): P[n][d] = X[n][D] * tproj[D][d]
 // (tproj given as the reference's Fortran D x d matrix, i.e. element (big,small) at tproj[small*D+big]).
