@@ -87,6 +87,9 @@ struct gprhip_problem {
   int nchunks = 0;
   int kslices = 0;   // upper bound on the split-K factor (set at creation from the memory budget)
   hipStream_t stream = nullptr;
+  // second stream: the covariance of the first row chunk runs beside the K_m factorisation (do_pass1)
+  hipStream_t stream2 = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   std::vector<void*> allocs;
 
   double *X = nullptr, *y = nullptr, *P = nullptr;
@@ -440,11 +443,11 @@ int pick_kslices(int mp, int64_t rows_p, int max_slices, int64_t slice_rows, boo
 }
 
 template <typename TS>
-void cov_chunk(gprhip_problem* p, int c, TS* K) {
+void cov_chunk(gprhip_problem* p, int c, TS* K, hipStream_t s = nullptr) {
   const int64_t rows = p->rows_of(c);
   const int64_t rows_p = round_up(rows, TILE);
   const double* pts = p->pts() + (int64_t)c * p->chunk * p->d;
-  launch_cov_cross<TS>(p->cp, pts, (int)rows, (int)rows_p, p->Z, p->m, p->mp, p->d, K, p->stream, p->zshift);
+  launch_cov_cross<TS>(p->cp, pts, (int)rows, (int)rows_p, p->Z, p->m, p->mp, p->d, K, s ? s : p->stream, p->zshift);
 }
 
 template <typename TS>
@@ -481,6 +484,16 @@ void do_pass1(gprhip_problem* p, const gprhip_hypers* h, int want_grad, int64_t 
     throw HipFail{ST_STATE};
   }
   p->have_v = false;
+  // K_nm of the first chunk does not depend on U: it is built on the second stream while the (latency-bound, few-CU)
+  // factorisation and inversion of K_m run -- 0.4 ms of every evaluation, which is what a chunk's builder takes.
+  // (Not under the per-stage timer, whose events sit on the main stream.)
+  const bool cov0_ahead = !reuse && !p->timer.on;
+  if (cov0_ahead) {
+    GPR_HIP(hipEventRecord(p->ev_fork, s));  // hypers, inducing points and projections are enqueued on s
+    GPR_HIP(hipStreamWaitEvent(p->stream2, p->ev_fork, 0));
+    cov_chunk<TS>(p, 0, bufA, p->stream2);
+    GPR_HIP(hipEventRecord(p->ev_join, p->stream2));
+  }
   tstart(p, "km_chol");
   GPR_HIP(hipMemsetAsync(p->info, 0, 2 * sizeof(int), s));
   GPR_HIP(hipMemsetAsync(p->scal, 0, NSCAL * sizeof(double), s));
@@ -499,7 +512,8 @@ void do_pass1(gprhip_problem* p, const gprhip_hypers* h, int want_grad, int64_t 
     TS* V = Vstore + base * mp;
     if (!reuse) {
       tstart(p, "p1_cov");
-      cov_chunk<TS>(p, c, bufA);
+      if (c == 0 && cov0_ahead) GPR_HIP(hipStreamWaitEvent(s, p->ev_join, 0));
+      else cov_chunk<TS>(p, c, bufA);
       tstop(p);
       tstart(p, "p1_trmm_V");
       GemmArgsT<TS> g;  // V = K U^-1   (dtrsm `R, lib/fitc_gp.ml:226-227)
@@ -1275,6 +1289,9 @@ int gprhip_problem_create_ex(int device, int cov_kind, int precision, int64_t n,
     if (const char* e = getenv("GPRHIP_TILE_ORDER")) p->tile_order = atoi(e);
     if (const char* e = getenv("GPRHIP_GRAD_SCALAR")) p->grad_scalar = atoi(e);
     GPR_HIP(hipStreamCreate(&p->stream));
+    GPR_HIP(hipStreamCreate(&p->stream2));
+    GPR_HIP(hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming));
+    GPR_HIP(hipEventCreateWithFlags(&p->ev_join, hipEventDisableTiming));
     const int mp = p->mp;
     const int64_t mm = (int64_t)mp * mp;
     const int64_t npad = (int64_t)p->nchunks * chunk;
@@ -1332,6 +1349,12 @@ void gprhip_problem_destroy(gprhip_problem* p) {
     hipStreamSynchronize(p->stream);
     hipStreamDestroy(p->stream);
   }
+  if (p->stream2) {
+    hipStreamSynchronize(p->stream2);
+    hipStreamDestroy(p->stream2);
+  }
+  if (p->ev_fork) hipEventDestroy(p->ev_fork);
+  if (p->ev_join) hipEventDestroy(p->ev_join);
   if (p->timer.k0) {
     hipEventDestroy(p->timer.k0);
     hipEventDestroy(p->timer.k1);
