@@ -1315,3 +1315,34 @@ def test_random_shapes_fp32_bulk_against_oracle(seed):
     # the fp64 path itself is at 6e-9 and the fp32 operands give 1.7e-2 (measured, seeds 2, 3, 7); the stated 5e-3
     # holds from 8 dimensions on, where the inducing points are spread out
     assert relinf(ev.coeffs, ref["coeffs"]) <= (TOL32_COEFF if d >= 8 else 5e-2)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("env", [{}, {"F32": "1"}], ids=["fp64", "fp32"])
+def test_engine_harness(env):
+    """tools/gemm_check.hip (built by `make -C gpr_amd/csrc tools`, i.e. by __graft_entry__.build()): every operand
+    layout, triangular k-range, weighted / column-sum / diagonal-tile variant and fused epilogue of the MFMA engine
+    against a naive kernel, in the paired XCD-local tile order the library launches with."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "build", "gemm_check")
+    assert os.path.exists(exe), "build/gemm_check not built (make -C gpr_amd/csrc tools)"
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=600,
+                         env=dict(os.environ, ORD="3", **env))
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("check ")]
+    assert len(lines) >= 10 and all(ln.rstrip().endswith("OK") for ln in lines), out.stdout[-3000:]
+    assert ("f32 checks failed: 0" if env else "checks failed: 0") in out.stdout
+
+
+@pytest.mark.gpu
+def test_diagonal_block_harness():
+    """tools/potrf_check.hip: the LDS-resident 128 x 128 Cholesky + inverse kernel against its definition."""
+    import re
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "build", "potrf_check")
+    assert os.path.exists(exe), "build/potrf_check not built (make -C gpr_amd/csrc tools)"
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    m = re.search(r"max \|U\^T U - A\| = (\S+)\s+max \|U Dinv - I\| = (\S+)", out.stdout)
+    assert m, out.stdout[-2000:]
+    assert float(m.group(1)) < 1e-12 and float(m.group(2)) < 1e-13
