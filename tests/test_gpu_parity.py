@@ -1317,6 +1317,18 @@ def test_random_shapes_fp32_bulk_against_oracle(seed):
     assert relinf(ev.coeffs, ref["coeffs"]) <= (TOL32_COEFF if d >= 8 else 5e-2)
 
 
+def _harness(name):
+    """build/<name>, built by __graft_entry__.build(); built on the spot (hipcc is on the GPU box) if the snapshot
+    came without it."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "build", name)
+    if not os.path.exists(exe):
+        subprocess.run(["make", "-C", os.path.join(root, "gpr_amd", "csrc"), "tools"], capture_output=True, timeout=900)
+    assert os.path.exists(exe), "build/%s not built (make -C gpr_amd/csrc tools)" % name
+    return exe
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("env", [{}, {"F32": "1"}], ids=["fp64", "fp32"])
 def test_engine_harness(env):
@@ -1324,9 +1336,7 @@ def test_engine_harness(env):
     layout, triangular k-range, weighted / column-sum / diagonal-tile variant and fused epilogue of the MFMA engine
     against a naive kernel, in the paired XCD-local tile order the library launches with."""
     import subprocess
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    exe = os.path.join(root, "build", "gemm_check")
-    assert os.path.exists(exe), "build/gemm_check not built (make -C gpr_amd/csrc tools)"
+    exe = _harness("gemm_check")
     out = subprocess.run([exe], capture_output=True, text=True, timeout=600,
                          env=dict(os.environ, ORD="3", **env))
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("check ")]
@@ -1339,9 +1349,7 @@ def test_diagonal_block_harness():
     """tools/potrf_check.hip: the LDS-resident 128 x 128 Cholesky + inverse kernel against its definition."""
     import re
     import subprocess
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    exe = os.path.join(root, "build", "potrf_check")
-    assert os.path.exists(exe), "build/potrf_check not built (make -C gpr_amd/csrc tools)"
+    exe = _harness("potrf_check")
     out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     m = re.search(r"max \|U\^T U - A\| = (\S+)\s+max \|U Dinv - I\| = (\S+)", out.stdout)
     assert m, out.stdout[-2000:]
