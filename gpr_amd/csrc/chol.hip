@@ -50,6 +50,8 @@ __global__ __launch_bounds__(PT) void potrf_diag_kernel(double* __restrict__ A, 
   int& bad = *reinterpret_cast<int*>(rdiag + NB);              // keep all LDS in the one dynamic array
   const int tid = threadIdx.x;
   const int lane = tid & 63, wid = tid >> 6;
+  j += blockIdx.x;  // a launch over several blocks handles block j + blockIdx.x (inverse-only pass over all blocks)
+  dinv += (int64_t)blockIdx.x * NB * NB;
   double* Ab = A + (int64_t)j * NB * mp + (int64_t)j * NB;
   for (int idx = tid; idx < NB * NB / 2; idx += PT) {
     const int r = idx / (NB / 2), c2 = (idx % (NB / 2)) * 2;
@@ -160,7 +162,7 @@ __global__ __launch_bounds__(PT) void potrf_diag_kernel(double* __restrict__ A, 
   __syncthreads();
 
   // ---------------- invert in place (upper)
-  if (!(flags & 2)) {
+  if (!(flags & 2) || (flags & 32)) {
     // all eight diagonal micro-block inverses: wave w handles blocks w (8 waves)
     {
       const int b = wid, j0 = b * MB, cc = lane & 15;
@@ -183,6 +185,16 @@ __global__ __launch_bounds__(PT) void potrf_diag_kernel(double* __restrict__ A, 
       }
     }
     __syncthreads();
+    if (flags & 32) {
+      // factor-only step of the blocked factorisation (potrf_upper_blocked): the panel solve works by substitution
+      // with the eight 16 x 16 micro inverses, stored as [8][16][16] at the head of this block's dinv slot; the
+      // full block inverse is formed later, off the critical path, by the inverse-only pass (flags = 1)
+      for (int idx = tid; idx < 8 * MB * MB; idx += PT)
+        dinv[idx] = dblk(T, idx >> 8)[((idx >> 4) & 15) * LDT + (idx & 15)];
+      return;
+    }
+  }
+  if (!(flags & 2)) {
     // block column b of the inverse, in place (LAPACK dtrtri order): wavefront ri < b owns the 16x16 tile (ri, b):
     //   T1 = sum_{kt=ri}^{b-1} X(ri,kt) U(kt,b)   (X = the already inverted leading block; 4 MFMAs per kt)
     //   X(ri,b) = -T1 D_b                           (T1 re-laid out as an A operand through the wave's LDS scratch)
@@ -224,6 +236,7 @@ __global__ __launch_bounds__(PT) void potrf_diag_kernel(double* __restrict__ A, 
       __syncthreads();
     }
   }
+  if (flags & 2) return;
   for (int idx = tid; idx < NB * NB / 2; idx += PT) {
     const int r = idx / (NB / 2), c2 = (idx % (NB / 2)) * 2;
     double2 v;
@@ -231,6 +244,106 @@ __global__ __launch_bounds__(PT) void potrf_diag_kernel(double* __restrict__ A, 
     v.y = (c2 + 1 >= r) ? T[r * LDT + c2 + 1] : 0.0;
     *reinterpret_cast<double2*>(dinv + (int64_t)r * NB + c2) = v;
   }
+}
+
+// ---- blocked factorisation without the engine: panel solve and trailing update of one 128-row step
+//
+// A step of the right-looking factorisation is a latency chain (diagonal block -> panel -> trailing blocks -> next
+// diagonal block) of k = 128 products.  On the contraction engine such a launch costs 23-28 us whatever its size
+// (workgroup entry, first-stage latency, 128 x 128 tiles on 4 wavefronts: 14 us of MFMAs alone), and the panel needed
+// the full inverse of the diagonal block first (16 us + its store).  These two kernels are built for k = 128 instead:
+// operands go from L2 straight into MFMA fragment registers, the tiles are small enough that every step spreads over
+// the whole chip, and the panel is solved by substitution with the 16 x 16 micro inverses only.
+
+// Panel: X = U_jj^-T A[j, c] in place for the column tiles c > j.  A workgroup takes 64 columns, a wavefront 16 of
+// them -- columns are independent, so no barrier after the staging of U_jj.  With 16-row blocks b = 0..7:
+//   X_b = D_b^T T_b,   T_b' -= U_bb'^T X_b  (b' > b),   D_b = inv(U_bb) from the factor kernel.
+// An accumulator tile holds rows lq + 4r in register r: used as the B operand of the next MFMA it supplies the k index
+// in that order, and the A operand (read from LDS) is indexed to match.
+constexpr int PANEL_LDS = (36 + 8) * MB * MB * 8;
+__global__ __launch_bounds__(256) void potrf_panel_kernel(double* __restrict__ A, int mp, int j,
+                                                          const double* __restrict__ dmicro) {
+  extern __shared__ __attribute__((aligned(16))) double L[];  // [36][16][16] blocks (i <= b) of U_jj, then [8][16][16] D_b
+  double* Dm = L + 36 * MB * MB;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int l15 = lane & 15, lq = lane >> 4;
+  const double* Ujj = A + (int64_t)j * NB * mp + (int64_t)j * NB;
+  {
+    const int k = tid >> 4, m = tid & 15;
+    int blk = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int b = i; b < 8; ++b, ++blk) L[blk * 256 + tid] = Ujj[(int64_t)(16 * i + k) * mp + 16 * b + m];
+#pragma unroll
+    for (int b = 0; b < 8; ++b) Dm[b * 256 + tid] = dmicro[b * 256 + tid];
+  }
+  const int c0 = (j + 1) * NB + blockIdx.x * 64 + wid * 16;
+  double* Ap = A + (int64_t)j * NB * mp + c0 + l15;
+  pd4 T[8];
+#pragma unroll
+  for (int b = 0; b < 8; ++b)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) T[b][r] = Ap[(int64_t)(16 * b + lq + 4 * r) * mp];
+  __syncthreads();
+  const int fo = lq * 16 + l15;  // fragment element of k-step r: [(lq + 4r)][l15] -> fo + 64 r
+  int blk = 0;
+#pragma unroll
+  for (int b = 0; b < 8; ++b) {
+    pd4 x = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) x = mfma_f64(Dm[b * 256 + fo + 64 * r], T[b][r], x);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Ap[(int64_t)(16 * b + lq + 4 * r) * mp] = x[r];
+    ++blk;  // block (b, b) itself
+#pragma unroll
+    for (int b2 = b + 1; b2 < 8; ++b2, ++blk)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) T[b2] = mfma_f64(-L[blk * 256 + fo + 64 * r], x[r], T[b2]);
+  }
+}
+
+// Trailing update: A[r, c] -= X_r^T X_c over the upper 64 x 64 sub-tiles of the blocks behind step j (X = block row j,
+// 128 deep).  One workgroup per sub-tile, a 32 x 32 quarter per wavefront; the fragments of both operands are rows of
+// X, read from L2 as they are (16 consecutive doubles per k).
+__global__ __launch_bounds__(256) void potrf_update_kernel(double* __restrict__ A, int mp, int j) {
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int l15 = lane & 15, lq = lane >> 4;
+  int si = 0, rem = blockIdx.x;  // sub-tile (si <= sj) of the trailing part, in 64-blocks
+  const int ns = (mp / NB - 1 - j) * 2;
+  while (rem >= ns - si) {
+    rem -= ns - si;
+    ++si;
+  }
+  const int sj = si + rem;
+  const int64_t base = (int64_t)(j + 1) * NB;
+  const int64_t r0 = base + si * 64 + (wid >> 1) * 32, c0 = base + sj * 64 + (wid & 1) * 32;
+  const double* X = A + (int64_t)j * NB * mp;
+  const double* Xa = X + (int64_t)lq * mp + r0 + l15;
+  const double* Xb = X + (int64_t)lq * mp + c0 + l15;
+  double* Cp = A + (r0 + lq) * mp + c0 + l15;
+  pd4 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[i][jj][r] = Cp[(int64_t)(16 * i + 4 * r) * mp + 16 * jj];
+#pragma unroll 8
+  for (int ks = 0; ks < NB / 4; ++ks) {
+    const int64_t o = (int64_t)(4 * ks) * mp;
+    const double a0 = -Xa[o], a1 = -Xa[o + 16], b0 = Xb[o], b1 = Xb[o + 16];
+    acc[0][0] = mfma_f64(a0, b0, acc[0][0]);
+    acc[0][1] = mfma_f64(a0, b1, acc[0][1]);
+    acc[1][0] = mfma_f64(a1, b0, acc[1][0]);
+    acc[1][1] = mfma_f64(a1, b1, acc[1][1]);
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) Cp[(int64_t)(16 * i + 4 * r) * mp + 16 * jj] = acc[i][jj][r];
 }
 
 __global__ void zero_strict_lower_kernel(double* __restrict__ A, int mp) {
@@ -304,6 +417,37 @@ void launch_potrf_diag_flags(double* A, int mp, int j, double* dinv, int* info, 
     attr = true;
   }
   hipLaunchKernelGGL(potrf_diag_kernel, dim3(1), dim3(PT), POTRF_LDS, s, A, mp, j, dinv, info, flags);
+  GPR_HIP(hipGetLastError());
+}
+
+// Blocked upper Cholesky A = U^T U in place (dpotrf `U; lib/fitc_gp.ml:56) with inv(U_jj) of every diagonal block in
+// dinv: per step a factor-only diagonal kernel, the substitution panel and the small-tile trailing update; the block
+// inverses (which nothing on the chain needs any more) are formed by one launch over all blocks at the end.
+void potrf_upper_blocked(hipStream_t s, double* A, int mp, double* dinv, int* info) {
+  static bool attr = false;
+  if (!attr) {
+    GPR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&potrf_diag_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, POTRF_LDS));
+    GPR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&potrf_panel_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, PANEL_LDS));
+    attr = true;
+  }
+  const int nb = mp / NB;
+  if (nb == 1) {  // a single block: factor and inverse in one launch
+    hipLaunchKernelGGL(potrf_diag_kernel, dim3(1), dim3(PT), POTRF_LDS, s, A, mp, 0, dinv, info, 0);
+    GPR_HIP(hipGetLastError());
+    return;
+  }
+  for (int j = 0; j < nb; ++j) {
+    double* dj = dinv + (int64_t)j * NB * NB;
+    hipLaunchKernelGGL(potrf_diag_kernel, dim3(1), dim3(PT), POTRF_LDS, s, A, mp, j, dj, info, 2 + 32);
+    if (j + 1 < nb) {
+      const int rest = nb - 1 - j, ns = 2 * rest;
+      hipLaunchKernelGGL(potrf_panel_kernel, dim3(2 * rest), dim3(256), PANEL_LDS, s, A, mp, j, dj);
+      hipLaunchKernelGGL(potrf_update_kernel, dim3(ns * (ns + 1) / 2), dim3(256), 0, s, A, mp, j);
+    }
+  }
+  hipLaunchKernelGGL(potrf_diag_kernel, dim3(nb), dim3(PT), POTRF_LDS, s, A, mp, 0, dinv, info, 1);
   GPR_HIP(hipGetLastError());
 }
 

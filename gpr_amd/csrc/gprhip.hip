@@ -222,6 +222,17 @@ void tcollect(gprhip_problem* p) {
 // Blocked upper Cholesky A = U^T U in place (dpotrf `U; lib/fitc_gp.ml:56) -- diagonal blocks in
 // LDS, panel solve and trailing update on the MFMA engine.  dinv receives inv(U_jj) per block.
 void potrf_upper_n(hipStream_t s, double* A, int mp, double* dinv, int* info) {
+  // default: the engine-free step kernels of chol.hip (potrf_upper_blocked); GPRHIP_POTRF_ENGINE=1 (read once) keeps the
+  // round-2 sequence below for A/B timing -- diagonal block with its full inverse, panel and trailing update as engine
+  // launches
+  static const bool engine_steps = [] {
+    const char* e = getenv("GPRHIP_POTRF_ENGINE");
+    return e && atoi(e) != 0;
+  }();
+  if (!engine_steps) {
+    potrf_upper_blocked(s, A, mp, dinv, info);
+    return;
+  }
   const int nb = mp / TILE;
   for (int j = 0; j < nb; ++j) {
     double* dj = dinv + (int64_t)j * TILE * TILE;

@@ -47,6 +47,10 @@ void launch_project(const double* X, int64_t n, int D, int d, const double* tpro
 void launch_potrf_diag(double* A, int mp, int j, double* dinv, int* info, hipStream_t s);
 // flags bit0: the block already holds an upper factor -- skip the factorisation, only write inv(U_jj) to dinv
 void launch_potrf_diag_flags(double* A, int mp, int j, double* dinv, int* info, int flags, hipStream_t s);
+// Whole blocked factorisation A = U^T U (upper, in place; the strict lower parts of the diagonal blocks are zeroed, the
+// tiles below the diagonal untouched) + inv(U_jj) of every diagonal block in dinv [mp/128][128][128], without the
+// contraction engine: factor-only diagonal kernel, substitution panel, small-tile trailing update per 128-row step.
+void potrf_upper_blocked(hipStream_t s, double* A, int mp, double* dinv, int* info);
 void launch_zero_strict_lower(double* A, int mp, hipStream_t s);
 void launch_copy_block(const double* src, int64_t lds, double* dst, int64_t ldd, int rows, int cols,
                        hipStream_t s);

@@ -1354,3 +1354,10 @@ def test_diagonal_block_harness():
     m = re.search(r"max \|U\^T U - A\| = (\S+)\s+max \|U Dinv - I\| = (\S+)", out.stdout)
     assert m, out.stdout[-2000:]
     assert float(m.group(1)) < 1e-12 and float(m.group(2)) < 1e-13
+    # the whole blocked factorisation (factor-only diagonal kernel, substitution panel, small-tile trailing update,
+    # block inverses in one launch) at 1 .. 32 block rows; the strict lower triangle is poisoned with 1e300
+    rows = re.findall(r"blocked potrf m=(\d+): \S+ us  info=(-?\d+)  max \|U\^T U - A\| / max\|A\| = (\S+)  "
+                      r"max \|U_jj Dinv_j - I\| = (\S+)", out.stdout)
+    assert [int(r[0]) for r in rows] == [128, 384, 1024, 2048, 4096], out.stdout[-2000:]
+    for _, info, ea, ed in rows:
+        assert int(info) == 0 and float(ea) < 1e-13 and float(ed) < 1e-10

@@ -33,5 +33,59 @@ int main() {
   for (int i = 0; i < n; ++i) for (int j = i; j < n; ++j) { double s = 0; for (int k = 0; k <= i; ++k) s += U[k*n+i]*U[k*n+j]; e1m = std::max(e1m, fabs(s - A[i*n+j])); }
   for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) { double s = 0; for (int k = 0; k < n; ++k) s += U[i*n+k]*D[k*n+j]; e2m = std::max(e2m, fabs(s - (i==j))); }
   printf("max |U^T U - A| = %.2e   max |U Dinv - I| = %.2e\n", e1m, e2m);
+
+  // the whole blocked factorisation (potrf_upper_blocked: factor-only diagonal kernel, substitution panel, small-tile
+  // trailing update, block inverses at the end) against its definition, and its time
+  for (int m : {128, 384, 1024, 2048, 4096}) {
+    const int nb = m / 128;
+    std::vector<double> B((size_t)m * 64), S((size_t)m * m);
+    for (auto& v : B) v = (double)rand() / RAND_MAX - 0.5;
+    for (int i = 0; i < m; ++i)
+      for (int j = i; j < m; ++j) {
+        double s = 0;
+        for (int k = 0; k < 64; ++k) s += B[(size_t)i * 64 + k] * B[(size_t)j * 64 + k];
+        S[(size_t)i * m + j] = s + (i == j ? 1e-2 * (1 + i % 7) : 0.0);
+        if (j > i) S[(size_t)j * m + i] = 1e300;  // the strict lower triangle must never be read
+      }
+    double *dS, *dV; int* dJ;
+    hipMalloc(&dS, (size_t)m * m * 8); hipMalloc(&dV, (size_t)nb * 128 * 128 * 8); hipMalloc(&dJ, 8); hipMemset(dJ, 0, 8);
+    float best = 1e9;
+    for (int rep = 0; rep < 4; ++rep) {
+      hipMemcpy(dS, S.data(), (size_t)m * m * 8, hipMemcpyHostToDevice);
+      hipEventRecord(e0, 0);
+      potrf_upper_blocked(0, dS, m, dV, dJ);
+      hipEventRecord(e1, 0); hipEventSynchronize(e1);
+      float ms; hipEventElapsedTime(&ms, e0, e1); best = std::min(best, ms);
+    }
+    int hinfo = -1;
+    hipMemcpy(&hinfo, dJ, 4, hipMemcpyDeviceToHost);
+    std::vector<double> Um((size_t)m * m), Dv((size_t)nb * 128 * 128);
+    hipMemcpy(Um.data(), dS, (size_t)m * m * 8, hipMemcpyDeviceToHost);
+    hipMemcpy(Dv.data(), dV, Dv.size() * 8, hipMemcpyDeviceToHost);
+    double ea = 0, ed = 0, amax = 0;
+    if (m <= 2048) {
+      // U^T U against A on the upper triangle: rows of U^T U from the transposed factor (contiguous inner loops)
+      std::vector<double> Ut((size_t)m * m, 0.0);
+      for (int k = 0; k < m; ++k) for (int j = k; j < m; ++j) Ut[(size_t)j * m + k] = Um[(size_t)k * m + j];
+      for (int i = 0; i < m; ++i)
+        for (int j = i; j < m; ++j) {
+          double s = 0;
+          const double *a = &Ut[(size_t)i * m], *b = &Ut[(size_t)j * m];
+          for (int k = 0; k <= i; ++k) s += a[k] * b[k];
+          ea = std::max(ea, fabs(s - S[(size_t)i * m + j]));
+          amax = std::max(amax, fabs(S[(size_t)i * m + j]));
+        }
+    }
+    for (int jb = 0; jb < nb; ++jb)
+      for (int i = 0; i < 128; ++i)
+        for (int j = 0; j < 128; ++j) {
+          double s = 0;
+          for (int k = i; k < 128; ++k) s += Um[(size_t)(jb * 128 + i) * m + jb * 128 + k] * Dv[(size_t)jb * 16384 + k * 128 + j];
+          ed = std::max(ed, fabs(s - (i == j)));
+        }
+    printf("blocked potrf m=%d: %.1f us  info=%d  max |U^T U - A| / max|A| = %.2e  max |U_jj Dinv_j - I| = %.2e\n", m,
+           best * 1e3, hinfo, amax > 0 ? ea / amax : 0.0, ed);
+    hipFree(dS); hipFree(dV); hipFree(dJ);
+  }
   return 0;
 }
