@@ -102,12 +102,15 @@ def profile_traffic(n, m):
     rows = [r for r in json.load(open(path)) if "gemm_f64_tn_w" in r["kernel"] and r["avg_ms"] > 5.0]
     if not rows:
         return None
-    try:
-        rev = subprocess.check_output(["git", "-C", ROOT, "log", "-1", "--format=%h", "--", path], text=True).strip()
+    try:  # (no .git on the GPU box: the file's own hash identifies it there)
+        rev = subprocess.check_output(["git", "-C", ROOT, "log", "-1", "--format=%h", "--", path], text=True,
+                                      stderr=subprocess.DEVNULL).strip()
     except Exception:
         rev = None
+    import hashlib
     algo = float(n) * m * 8
-    out = {"from_profile": os.path.relpath(path, ROOT), "profile_commit": rev or None, "launches": []}
+    out = {"from_profile": os.path.relpath(path, ROOT), "profile_commit": rev or None,
+           "profile_sha256_16": hashlib.sha256(open(path, "rb").read()).hexdigest()[:16], "launches": []}
     for r in rows:
         b = r["hbm_fetch_bytes_per_launch"] + r["hbm_write_bytes_per_launch"]
         out["launches"].append({"kernel": r["kernel"], "avg_ms": r["avg_ms"], "fetch_bytes": r["hbm_fetch_bytes_per_launch"],

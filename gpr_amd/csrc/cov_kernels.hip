@@ -95,18 +95,18 @@ __global__ __launch_bounds__(256) void cov_upper_ms_kernel(CovParams cp, const d
                                                            int m, int mp, int d, double jitter,
                                                            const double* __restrict__ het,
                                                            double* __restrict__ km,
-                                                           double* __restrict__ kj) {
+                                                           double* __restrict__ kj, int rb) {
   const ExpK ek = exp_consts();
   const int c = blockIdx.x * 256 + threadIdx.x;
   if (c >= mp) return;
-  const int r0 = blockIdx.y * 32;
+  const int r0 = blockIdx.y * rb;
   double z[DT], msc[DT];
 #pragma unroll
   for (int k = 0; k < DT; ++k) {
     z[k] = (k < d && c < m) ? Z[(int64_t)c * d + k] : 0.0;
     msc[k] = (k < d && c < m) ? cp.ms[(int64_t)c * d + k] : 1.0;
   }
-  for (int i = 0; i < 32; ++i) {
+  for (int i = 0; i < rb; ++i) {
     const int r = r0 + i;
     if (r >= mp) break;
     double val = 0.0, valj = 0.0;
@@ -145,15 +145,15 @@ __global__ __launch_bounds__(256) void cov_upper_kernel(CovParams cp, const doub
                                                         int m, int mp, int d, double jitter,
                                                         const double* __restrict__ het,
                                                         double* __restrict__ km,
-                                                        double* __restrict__ kj) {
+                                                        double* __restrict__ kj, int rb) {
   const ExpK ek = exp_consts();
   const int c = blockIdx.x * 256 + threadIdx.x;
   if (c >= mp) return;
-  const int r0 = blockIdx.y * 32;
+  const int r0 = blockIdx.y * rb;
   double z[DT];
 #pragma unroll
   for (int k = 0; k < DT; ++k) z[k] = (k < d && c < m) ? Z[(int64_t)c * d + k] : 0.0;
-  for (int i = 0; i < 32; ++i) {
+  for (int i = 0; i < rb; ++i) {
     const int r = r0 + i;
     if (r >= mp) break;
     double val = 0.0, valj = 0.0;
@@ -329,15 +329,19 @@ static void no_wide_multiscales(const CovParams& cp, int d) {
 void launch_cov_upper(const CovParams& cp, const double* Z, int m, int mp, int d, double jitter,
                       const double* het, double* km, double* kj, hipStream_t s) {
   dim3 grid(mp / 256 + (mp % 256 ? 1 : 0), (mp + 31) / 32);
+  // the m x m covariance sits on the latency chain in front of the factorisation: 8 rows per thread instead of 32 puts
+  // four times as many workgroups on the chip (m = 2048: 48 -> 17 us)
+  const int rb = 8;
+  dim3 grid8(grid.x, (mp + rb - 1) / rb);
   no_wide_multiscales(cp, d);
   dispatch_dt(d, [&](auto dt) {
     constexpr int DT = decltype(dt)::value;
     if constexpr (DT == 0)
       hipLaunchKernelGGL(cov_upper_wide_kernel, grid, dim3(256), 0, s, cp, Z, m, mp, d, jitter, het, km, kj);
     else if (cp.ms)
-      hipLaunchKernelGGL((cov_upper_ms_kernel<DT>), grid, dim3(256), 0, s, cp, Z, m, mp, d, jitter, het, km, kj);
+      hipLaunchKernelGGL((cov_upper_ms_kernel<DT>), grid8, dim3(256), 0, s, cp, Z, m, mp, d, jitter, het, km, kj, rb);
     else
-      hipLaunchKernelGGL((cov_upper_kernel<DT>), grid, dim3(256), 0, s, cp, Z, m, mp, d, jitter, het, km, kj);
+      hipLaunchKernelGGL((cov_upper_kernel<DT>), grid8, dim3(256), 0, s, cp, Z, m, mp, d, jitter, het, km, kj, rb);
   });
   GPR_HIP(hipGetLastError());
 }

@@ -509,8 +509,8 @@ void do_pass1(gprhip_problem* p, const gprhip_hypers* h, int want_grad, int64_t 
   GPR_HIP(hipMemsetAsync(p->info, 0, 2 * sizeof(int), s));
   GPR_HIP(hipMemsetAsync(p->scal, 0, NSCAL * sizeof(double), s));
   GPR_HIP(hipMemsetAsync(ar1_c, 0, (size_t)(mp + A1_TAIL) * sizeof(double), s));
-  launch_cov_upper(p->cp, p->Z, p->m, mp, p->d, h->jitter, p->has_het() ? p->het : nullptr, p->km, p->kj, s);
-  GPR_HIP(hipMemcpyAsync(p->umat, p->kj, (size_t)mm * sizeof(double), hipMemcpyDeviceToDevice, s));
+  // K_m + (hetero) + jitter goes straight into the factor's buffer (kj is scratch of the finish stage only)
+  launch_cov_upper(p->cp, p->Z, p->m, mp, p->d, h->jitter, p->has_het() ? p->het : nullptr, p->km, p->umat, s);
   potrf_upper(p, p->umat, p->info);  // U = chol(K_m + jitter), lib/fitc_gp.ml:53-57
   trtri_upper(p, p->umat, p->uinv, p->wmat);
   if (p->f32) launch_to_float(p->uinv, p->uinv_f, mm, s);
