@@ -80,6 +80,37 @@ Hyper = Union[str, Inducing_hyper, Proj_hyper, Log_hetero_skedasticity, Log_mult
 LOG_SF2 = "Log_sf2"
 
 
+def create_default_kernel_params(inputs, n_inducing, rng=None) -> Params:
+    """Eval.Inputs.create_default_kernel_params (lib/cov_se_fat.ml:191-213): d = min(big_dim, 10), a random projection
+    scaled by the inverse row means of the inputs, log_hetero_skedasticity -5, log_multiscales_m05 0.  The reference
+    draws from OCaml's global `Random` state; here a numpy Generator (or seed) supplies the uniform(-1, 1) numbers, in
+    the reference's order: tproj row by row, then log_sf2."""
+    rng = rng if isinstance(rng, np.random.Generator) else np.random.default_rng(rng)
+    x = np.asarray(inputs, dtype=np.float64)
+    big_dim, n_inputs = x.shape
+    d = min(big_dim, 10)
+    factor = float(n_inputs) / float(big_dim)
+    tproj = np.empty((big_dim, d), order="F")
+    for r in range(big_dim):
+        mean_factor = factor / float(np.sum(x[r, :]))
+        tproj[r, :] = mean_factor * (rng.uniform(0.0, 2.0, size=d) - 1.0)
+    log_sf2 = float(rng.uniform(0.0, 2.0) - 1.0)
+    return Params.create(d, log_sf2, tproj=tproj, log_hetero_skedasticity=np.full(n_inducing, -5.0),
+                         log_multiscales_m05=np.zeros((d, n_inducing), order="F"))
+
+
+def project(kernel: Kernel, inputs):
+    """Eval.Inputs.project (lib/cov_se_fat.ml:215-218): tproj^T inputs, or the inputs themselves without a projection."""
+    x = np.asfortranarray(inputs, dtype=np.float64)
+    tp = kernel.params.tproj
+    return x if tp is None else np.asfortranarray(tp.T @ x)
+
+
+def create_inducing(kernel: Kernel, inputs):
+    """Eval.Inputs.create_inducing = project (lib/cov_se_fat.ml:220): inducing points live in the projected space."""
+    return project(kernel, inputs)
+
+
 def kernel_space_dim(kernel: Kernel, inputs) -> int:
     return kernel.params.d
 

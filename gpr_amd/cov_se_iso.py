@@ -57,6 +57,11 @@ def create_default_kernel_params(_inputs=None, n_inducing=None) -> Params:
     return Params(log_ell=0.0, log_sf2=0.0)
 
 
+def create_inducing(_kernel, inputs):
+    """Eval.Inputs.create_inducing (lib/cov_se_iso.ml:120): chosen inputs are the inducing points."""
+    return np.asfortranarray(inputs, dtype=np.float64)
+
+
 def kernel_space_dim(kernel, inputs) -> int:
     return inputs.shape[0]
 

@@ -23,7 +23,8 @@ Beyond the hot path: posterior means and variances at new input
 (`Eval.Covariances`: FITC_covariances in `FITC`/`Variational_FITC`, FIC_covariances in `FIC`/
 `Variational_FIC`, lib/fitc_gp.ml:565-627 -- the only place the two families differ) and the samplers
 (`Eval.Sampler`, `Eval.Cov_sampler`; the standard normal draws come from a numpy Generator instead of
-GSL's ziggurat).  Not provided: `Covariances.calc_model_inputs` (O(n^2) over the training set).  The
+GSL's ziggurat).  `Inducing.choose_n_first_inputs` / `choose_n_random_inputs`, `Inputs.create_default_kernel` and the
+`calc_model_inputs` variants (n x n host matrices: small n only) complete Sigs.Eval.  The
 optimiser drivers live in gpr_amd/optim.py: an L-BFGS driver over the reference's multim_f/multim_dcommon callbacks
 (GSL itself is not available) and step-for-step mirrors of Optim.SGD / Optim.SMD.
 """
@@ -169,7 +170,9 @@ _default_rng = np.random.default_rng()
 
 
 def _rng(rng):
-    return _default_rng if rng is None else rng
+    if rng is None:
+        return _default_rng
+    return rng if isinstance(rng, np.random.Generator) else np.random.default_rng(rng)
 
 
 def _make_variant(spec, variational, functor, cov_kind="FITC"):
@@ -207,15 +210,46 @@ def _make_variant(spec, variational, functor, cov_kind="FITC"):
     def model_update_sigma2(model, sigma2):
         return _Model(model.inputs, sigma2, variational)
 
+    def check_n_inducing(n_inducing, inputs):
+        n_inputs = np.asarray(inputs).shape[1]
+        if n_inputs < 1 or n_inducing > n_inputs:  # lib/fitc_gp.ml:45-51
+            raise ValueError("Gpr.Fitc_gp.Make_common.check_n_inducing: violating 1 <= n_inducing (%d) <= n_inputs (%d)"
+                             % (n_inducing, n_inputs))
+
+    def choose(kernel, inputs, indexes):
+        """Inducing.choose (lib/fitc_gp.ml:62-64): Utils.choose_cols, then the spec's create_inducing."""
+        chosen = np.asfortranarray(np.asarray(inputs, dtype=np.float64)[:, indexes])
+        return inducing_calc(kernel, spec.create_inducing(kernel, chosen))
+
+    def choose_n_first_inputs(kernel, inputs, n_inducing):
+        check_n_inducing(n_inducing, inputs)                                            # :66-72
+        return choose(kernel, inputs, np.arange(n_inducing))
+
+    def choose_n_random_inputs(kernel, inputs, n_inducing, rnd_state=None):
+        """lib/fitc_gp.ml:74-92: the first n_inducing steps of a Fisher-Yates shuffle of the input indexes.  The
+        reference draws `Random.State.int rnd_state (n_inputs - i + 1)` at step i; a numpy Generator (or a seed) stands
+        in for OCaml's Random.State, drawing `integers(n_inputs - i + 1)` at the same step."""
+        check_n_inducing(n_inducing, inputs)
+        rng = _rng(rnd_state)
+        n_inputs = np.asarray(inputs).shape[1]
+        indexes = np.arange(n_inputs)
+        for i in range(n_inducing):   # (0-based; the reference's step i+1 draws below n_inputs - i)
+            rnd_index = int(rng.integers(n_inputs - i))
+            indexes[rnd_index], indexes[i] = indexes[i], indexes[rnd_index]
+        return choose(kernel, inputs, indexes[:n_inducing])
+
     def hyper_lookup(hyper_t, hyper):
         idx = spec.HyperModule.index_of(hyper_t.kernel, hyper_t.inducing_points, hyper)
         return float(hyper_t.evaluation.grad[idx])
 
     Eval = SimpleNamespace(
         Inducing=SimpleNamespace(calc=inducing_calc, get_points=lambda i: i.points,
-                                 get_kernel=lambda i: i.kernel),
+                                 get_kernel=lambda i: i.kernel, choose_n_first_inputs=choose_n_first_inputs,
+                                 choose_n_random_inputs=choose_n_random_inputs),
         Inputs=SimpleNamespace(calc=lambda points, inducing, **kw: inputs_calc(inducing, points, **kw),
-                               get_points=lambda i: i.points),
+                               get_points=lambda i: i.points,
+                               create_default_kernel=lambda inputs, n_inducing, **kw: spec.Kernel.create(  # :128-130
+                                   spec.create_default_kernel_params(inputs, n_inducing, **kw))),
         Model=SimpleNamespace(
             calc=model_calc, update_sigma2=model_update_sigma2,
             calc_log_evidence=lambda model: model.evaluation(False).l1,   # lib/fitc_gp.ml:238
@@ -285,7 +319,13 @@ def _make_variant(spec, variational, functor, cov_kind="FITC"):
         # the state (chol_km, r_mat) comes from an evaluation of `cvp` (a model or a trained model)
         return _Variances(_predict(cvp, inputs, False, True, sigma2)[1], sigma2)
 
+    def variances_calc_model_inputs(model):
+        """Variances.calc_model_inputs (lib/fitc_gp.ml:487-496): r_vec + rowsum((K_nm R^-1)^2) at the model's own
+        inputs -- the same numbers Variances.calc gives there, so the prediction path serves it."""
+        return variances_calc(model, model.sigma2, model.inputs)
+
     Eval.Variances = SimpleNamespace(
+        calc_model_inputs=variances_calc_model_inputs,
         calc=variances_calc,                                                                   # :498-518
         get=lambda v, predictive=True: v.variances + v.sigma2 if predictive else v.variances)  # :520-529
 
@@ -358,8 +398,27 @@ def _make_variant(spec, variational, functor, cov_kind="FITC"):
         res[np.diag_indices(res.shape[0])] += c.sigma2                          # :549-559
         return res
 
-    def covariances_calc_model_inputs(_model):
-        raise NotImplementedError("Covariances.calc_model_inputs (O(n^2) over the training set) is not provided")
+    def covariances_calc_model_inputs(model):
+        """FITC_covariances.calc_model_inputs (lib/fitc_gp.ml:569-579): K_n - V V^T + Q_n Q_n^T, and
+        FIC_covariances.calc_model_inputs (:609-614): Q_n Q_n^T + diag(r_vec) -- as written, with the model's own Q
+        factor, whose rows carry sqrt(1/s_i) (Q_n = diag(sqrt is) K_nm R^-1, :176-182).  Assembled on the host from
+        what the device gives at the model's own inputs: C_fitc = K_n - V V^T + Q' Q'^T (`calc`), Q' Q'^T off the
+        diagonal from the FIC form, its diagonal from the variances, r_vec from the model state.
+        An n x n host matrix, as in the reference: for small n only."""
+        prob = _problem_of(model, model.inputs, model.sigma2)
+        pts = model.inputs.points
+        r_vec = prob.debug_fetch("r")
+        qq = prob.covariances(pts, kind="FIC", predictive=False)
+        var = prob.predict(pts, predictive=False, want_variances=True)[1]
+        qq[np.diag_indices(qq.shape[0])] = var - r_vec                  # |Q'_i|^2 = variance_i - r_i (:487-496)
+        sq = np.sqrt(1.0 / (r_vec + model.sigma2))
+        qnqn = qq * sq[:, None] * sq[None, :]
+        if cov_kind == "FIC":
+            cov = qnqn
+            cov[np.diag_indices(cov.shape[0])] += r_vec
+        else:
+            cov = prob.covariances(pts, kind="FITC", predictive=False) + (qnqn - qq)
+        return _Covariances(pts, cov, model.sigma2, prob)
 
     Eval.Covariances = SimpleNamespace(
         calc=covariances_calc, get=covariances_get, calc_model_inputs=covariances_calc_model_inputs,

@@ -696,6 +696,30 @@ def fic_covariances(k, inducing_points, model, test_inputs):
     return np.triu(cov)
 
 
+def variances_model_inputs(model):
+    """Variances.calc_model_inputs lib/fitc_gp.ml:487-496: r_vec + rowsum((K_nm r_mat^-1)^2)."""
+    tmp = _F(blas.dtrsm(1.0, model["r_mat"], model["knm"], side=1, lower=0, trans_a=0))
+    return model["r_vec"] + np.einsum("ij,ij->i", tmp, tmp)
+
+
+def fitc_covariances_model_inputs(k, model, inputs):
+    """FITC_covariances.calc_model_inputs lib/fitc_gp.ml:569-579: calc_upper - syrk v_mat + syrk ~n q_mat, where
+    q_mat is the model's Q factor, i.e. its first n rows are diag(sqrt is) K_nm R^-1 (:176-182) -- as written."""
+    n = model["n"]
+    cov = np.triu(np.nan_to_num(spec_inputs_calc_upper(k, inputs), nan=0.0))
+    cov = _syrk_upper(-1.0, model["v_mat"], 1.0, _F(cov))
+    cov = _syrk_upper(1.0, _F(model["q_mat"][:n, :]), 1.0, cov)
+    return np.triu(cov)
+
+
+def fic_covariances_model_inputs(model):
+    """FIC_covariances.calc_model_inputs lib/fitc_gp.ml:609-614 -> calc_common :601-607 with the model's q_mat, r_vec."""
+    n = model["n"]
+    cov = _syrk_upper(1.0, _F(model["q_mat"][:n, :]), 0.0, np.zeros((n, n), order="F"))
+    cov[np.diag_indices(n)] += model["r_vec"]
+    return np.triu(cov)
+
+
 def covariances_get(cov, sigma2, predictive=True):
     """Common_covariances.get_common lib/fitc_gp.ml:549-559."""
     if not predictive:

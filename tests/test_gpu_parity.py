@@ -609,6 +609,55 @@ def test_stats_covariances_and_samplers():
     GP.close()
 
 
+def test_calc_model_inputs_family_and_inducing_choice():
+    """Sigs.Eval members either side of the path: Variances.calc_model_inputs (lib/fitc_gp.ml:487-496),
+    FITC_/FIC_covariances.calc_model_inputs (:569-579, :609-614; as written, with the model's sqrt(1/s)-scaled Q factor)
+    against the oracle, for a standard and a variational model, and a model built on Inducing.choose_n_first_inputs /
+    choose_n_random_inputs evaluated against the oracle on the same chosen points."""
+    n, m, d = 700, 70, 3
+    X, y, _ = synth(41, n, m, d)
+    s2 = 0.15
+    kernel = cov_se_iso.Kernel.create(cov_se_iso.Params(0.3, -0.1))
+    k = O.SeIsoKernel(0.3, -0.1)
+    GP = fitc_gp.Make_deriv(cov_se_iso)
+    for F, fic, variational in ((GP.FITC, False, False), (GP.FIC, True, False), (GP.Variational_FITC, False, True)):
+        E = F.Eval
+        inducing = E.Inducing.choose_n_random_inputs(kernel, X, n_inducing=m, rnd_state=5)
+        Z = E.Inducing.get_points(inducing)
+        assert Z.shape == (d, m) and len({tuple(c) for c in Z.T}) == m
+        assert all(any(np.array_equal(c, x) for x in X.T) for c in Z.T[:5])
+        model = E.Model.calc(E.Inputs.calc(X, inducing), sigma2=s2)
+        ref = O.evaluate(k, Z, X, y, s2, want_grad=False, keep=True, variational=variational)
+        trained = E.Trained.calc(model, targets=y)
+        assert abs(E.Trained.calc_log_evidence(trained) - ref["l"]) <= 1e-9 * abs(ref["l"])
+        var_ref = O.variances_model_inputs(ref["model"])
+        v = E.Variances.calc_model_inputs(model)
+        assert relinf(E.Variances.get(v, predictive=False), var_ref) <= 1e-8
+        assert relinf(E.Variances.get(v), var_ref + s2) <= 1e-8
+        cref = O.fic_covariances_model_inputs(ref["model"]) if fic else O.fitc_covariances_model_inputs(k, ref["model"], X)
+        c = E.Covariances.calc_model_inputs(model)
+        got = E.Covariances.get(c, predictive=False)
+        assert np.max(np.abs(np.triu(got) - cref)) <= 1e-8 * np.max(np.abs(cref))
+        assert np.allclose(np.diag(E.Covariances.get(c)), np.diag(cref) + s2, rtol=0, atol=1e-8)
+    first = GP.FITC.Eval.Inducing.choose_n_first_inputs(kernel, X, n_inducing=m)
+    assert np.array_equal(GP.FITC.Eval.Inducing.get_points(first), X[:, :m])
+    GP.close()
+    # Cov_se_fat: the chosen inputs are projected into the kernel's space (create_inducing = project, lib/cov_se_fat.ml:220)
+    D, dd = 5, 2
+    rng = np.random.default_rng(3)
+    Xb = np.asfortranarray(rng.normal(size=(D, 300)) + 2.0)
+    fk = cov_se_fat.Kernel.create(cov_se_fat.Params.create(dd, 0.1, tproj=rng.normal(size=(D, dd)) / np.sqrt(D)))
+    GPf = fitc_gp.Make_deriv(cov_se_fat)
+    ind = GPf.FITC.Eval.Inducing.choose_n_first_inputs(fk, Xb, n_inducing=20)
+    Zf = GPf.FITC.Eval.Inducing.get_points(ind)
+    assert Zf.shape == (dd, 20) and np.allclose(Zf, fk.params.tproj.T @ Xb[:, :20], rtol=0, atol=1e-15)
+    yb = np.sin(Xb.sum(0))
+    tr = GPf.FITC.Eval.Trained.calc(GPf.FITC.Eval.Model.calc(GPf.FITC.Eval.Inputs.calc(Xb, ind), sigma2=0.1), targets=yb)
+    reff = O.evaluate(O.SeFatKernel(dd, 0.1, fk.params.tproj, None, None), Zf, Xb, yb, 0.1, want_grad=False)
+    assert abs(GPf.FITC.Eval.Trained.calc_log_evidence(tr) - reff["l"]) <= 1e-9 * abs(reff["l"])
+    GPf.close()
+
+
 @pytest.mark.parametrize("name", posterior_golden_names())
 def test_golden_posterior(name):
     """Committed posterior fixtures (tests/golden/make_golden.py save_posterior): prediction, both covariance

@@ -201,3 +201,43 @@ def test_exp_fast_within_one_ulp_of_libm(tmp_path):
     out = subprocess.run([str(exe)], capture_output=True, text=True)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "special cases bad=0" in out.stdout
+
+
+def test_inducing_choice_and_default_kernels_follow_the_reference():
+    """Inducing.choose_n_first_inputs / choose_n_random_inputs (lib/fitc_gp.ml:45-92: partial Fisher-Yates over the
+    input indexes, check_n_inducing), Inputs.create_default_kernel (:128-130) with the two specs' default parameters
+    (lib/cov_se_iso.ml:122-123, lib/cov_se_fat.ml:191-213) -- host logic only, no device."""
+    from gpr_amd import fitc_gp
+    rng = np.random.default_rng(0)
+    X = np.asfortranarray(rng.normal(size=(4, 50)) + 3.0)
+    GP = fitc_gp.Make_deriv(cov_se_iso)
+    E = GP.FITC.Eval
+    k = E.Inputs.create_default_kernel(X, n_inducing=7)
+    assert k.get_params().log_ell == 0.0 and k.get_params().log_sf2 == 0.0
+    ind = E.Inducing.choose_n_first_inputs(k, X, n_inducing=7)
+    assert np.array_equal(E.Inducing.get_points(ind), X[:, :7])
+    # the same partial shuffle, restated: step i swaps position i with a draw below n - i
+    g = np.random.default_rng(11)
+    idx = list(range(50))
+    for i in range(9):
+        j = int(g.integers(50 - i))
+        idx[j], idx[i] = idx[i], idx[j]
+    ind = E.Inducing.choose_n_random_inputs(k, X, n_inducing=9, rnd_state=11)
+    assert np.array_equal(E.Inducing.get_points(ind), X[:, idx[:9]])
+    assert len(set(idx[:9])) == 9
+    with pytest.raises(ValueError, match=r"check_n_inducing: violating 1 <= n_inducing \(51\) <= n_inputs \(50\)"):
+        E.Inducing.choose_n_random_inputs(k, X, n_inducing=51)
+    with pytest.raises(ValueError, match="check_n_inducing"):
+        E.Inducing.choose_n_first_inputs(k, X[:, :0], n_inducing=0)
+    # Cov_se_fat defaults: d = min(big_dim, 10), tproj rows scaled by n / (big_dim * row sum), hetero -5, multiscales 0
+    GPf = fitc_gp.Make_deriv(cov_se_fat)
+    Xb = np.asfortranarray(rng.uniform(0.5, 1.5, size=(12, 40)))
+    kf = GPf.FITC.Eval.Inputs.create_default_kernel(Xb, n_inducing=6, rng=4)
+    pf = kf.get_params()
+    assert pf.d == 10 and pf.tproj.shape == (12, 10) and -1.0 <= pf.log_sf2 < 1.0
+    bound = (40.0 / 12.0) / Xb.sum(1)
+    assert np.all(np.abs(pf.tproj) <= bound[:, None] * (1 + 1e-15))
+    assert np.array_equal(pf.log_hetero_skedasticity, np.full(6, -5.0)) and pf.log_multiscales_m05.shape == (10, 6)
+    assert not np.any(pf.log_multiscales_m05)
+    indf = GPf.FITC.Eval.Inducing.choose_n_first_inputs(kf, Xb, n_inducing=6)
+    assert np.allclose(GPf.FITC.Eval.Inducing.get_points(indf), pf.tproj.T @ Xb[:, :6], rtol=0, atol=1e-14)

@@ -339,3 +339,34 @@ def test_ill_conditioned_fixtures(name):
         assert abs(out["l1"] - float(g["mp_l1"])) <= 1e-10 * abs(float(g["mp_l1"]))
         assert abs(out["l2"] - float(g["mp_l2"])) <= 1e-10 * abs(float(g["mp_l2"]))
         assert relinf(out["coeffs"], g["mp_coeffs"]) <= 1e-9
+
+
+def test_calc_model_inputs_restatements_against_dense_formulas():
+    """Variances.calc_model_inputs / FITC_ / FIC_covariances.calc_model_inputs (lib/fitc_gp.ml:487-496, :569-579,
+    :609-614) from dense textbook expressions: variances equal Variances.calc at the training inputs; the covariance
+    forms carry the model's Q factor, Q_n = diag(sqrt(1/s)) K_nm R^-1 with R^T R = B = K_m + K_mn S^-1 K_nm."""
+    rng = np.random.default_rng(12)
+    n, m, d = 60, 9, 2
+    X = np.asfortranarray(rng.normal(size=(d, n)))
+    Z = np.asfortranarray(X[:, :m] + 0.05 * rng.normal(size=(d, m)))
+    y = rng.normal(size=n)
+    k = O.SeIsoKernel(0.2, 0.3)
+    s2 = 0.3
+    ref = O.evaluate(k, Z, X, y, s2, want_grad=False, keep=True)
+    mod = ref["model"]
+    var = O.variances_model_inputs(mod)
+    assert np.allclose(var, O.predict_variances(k, Z, mod, X, predictive=False), rtol=1e-10, atol=1e-12)
+    knm, _ = O.spec_calc_shared_cross(k, X, Z)
+    km = np.triu(mod["inducing"]["km"]) + np.triu(mod["inducing"]["km"], 1).T + 1e-6 * np.eye(m)
+    qn = knm @ np.linalg.inv(km)
+    r = k.sf2 - np.einsum("ij,ij->i", qn, knm)
+    s = r + s2
+    B = km + knm.T @ (knm / s[:, None])
+    dq = (knm / np.sqrt(s)[:, None])
+    qq = dq @ np.linalg.solve(B, dq.T)
+    kn = np.exp(k.log_sf2 - 0.5 * np.exp(-2 * k.log_ell) * ((X.T[:, None, :] - X.T[None, :, :]) ** 2).sum(-1))
+    fitc = kn - qn @ knm.T + qq
+    got = O.fitc_covariances_model_inputs(k, mod, X)
+    assert np.max(np.abs(got - np.triu(fitc))) <= 1e-9
+    fic = qq + np.diag(r)
+    assert np.max(np.abs(O.fic_covariances_model_inputs(mod) - np.triu(fic))) <= 1e-9
