@@ -107,8 +107,14 @@ struct gprhip_problem {
   bool have_model = false;
   bool have_factors = false;  // U^-1 / R~^-1 valid (false after a means-only gprhip_load_predictor)
   bool have_v = false;        // Vstore / r hold V = K_nm U^-1 of the current kernel and inducing points (reuse_v)
+  bool have_k = false;        // Kstore holds K_nm of the current kernel and inducing points for every chunk
+  int k_resident = 1;         // GPRHIP_K_RESIDENT=0 (read at creation): never keep K_nm (ablation)
   // n x m storage: double, or float in the fp32-bulk mode (element size `esz`)
   void *bufA = nullptr, *bufB = nullptr, *Vstore = nullptr;
+  // Cov_se_fat with projection hypers: K_nm of all rows, kept from pass 1 for the gradient kernel of pass 2 (which then
+  // reads E = X .* K instead of recomputing distances and exp) when the device has room for a second n x m matrix
+  void* Kstore = nullptr;
+  bool kstore_tried = false;
   float *uinv_f = nullptr, *rinv_f = nullptr;  // fp32 copies of U^-1 / R~^-1 (fp32-bulk mode)
   float *is_f = nullptr, *yis_f = nullptr, *v_f = nullptr;  // fp32 copies of the SYRK row weights (fp32-bulk mode)
   int f32 = 0;
@@ -488,6 +494,23 @@ void do_pass1(gprhip_problem* p, const gprhip_hypers* h, int want_grad, int64_t 
   TS* const Vstore = static_cast<TS*>(p->Vstore);
   TS* const bufA = static_cast<TS*>(p->bufA);
   TS* const slices = static_cast<TS*>(p->slices);
+  // K resident (see Kstore): decided at the first gradient evaluation that can use it, kept for the problem's life
+  if (!p->Kstore && !p->kstore_tried && want_grad && p->k_resident && p->kind == GPRHIP_COV_SE_FAT && h->tproj &&
+      !h->log_multiscales_m05 && p->d <= 64 && p->D <= 64 && !p->grad_scalar) {
+    p->kstore_tried = true;
+    size_t free_b = 0, total_b = 0;
+    const size_t need = (size_t)p->nchunks * p->chunk * mp * sizeof(TS);
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b > need + (size_t(4) << 30)) {
+      void* ptr = nullptr;
+      if (hipMalloc(&ptr, need) == hipSuccess) {
+        p->allocs.push_back(ptr);
+        p->Kstore = ptr;
+      } else {
+        (void)hipGetLastError();  // no room after all: the gradient kernel recomputes K
+      }
+    }
+  }
+  TS* const Kstore = static_cast<TS*>(p->Kstore);
 
   const bool reuse = h->reuse_v != 0;
   if (reuse && !p->have_v) {
@@ -495,6 +518,7 @@ void do_pass1(gprhip_problem* p, const gprhip_hypers* h, int want_grad, int64_t 
     throw HipFail{ST_STATE};
   }
   p->have_v = false;
+  if (!reuse) p->have_k = false;
   // K_nm of the first chunk does not depend on U: it is built on the second stream while the (latency-bound, few-CU)
   // factorisation and inversion of K_m run -- 0.4 ms of every evaluation, which is what a chunk's builder takes.
   // (Not under the per-stage timer, whose events sit on the main stream.)
@@ -502,7 +526,7 @@ void do_pass1(gprhip_problem* p, const gprhip_hypers* h, int want_grad, int64_t 
   if (cov0_ahead) {
     GPR_HIP(hipEventRecord(p->ev_fork, s));  // hypers, inducing points and projections are enqueued on s
     GPR_HIP(hipStreamWaitEvent(p->stream2, p->ev_fork, 0));
-    cov_chunk<TS>(p, 0, bufA, p->stream2);
+    cov_chunk<TS>(p, 0, Kstore ? Kstore : bufA, p->stream2);
     GPR_HIP(hipEventRecord(p->ev_join, p->stream2));
   }
   tstart(p, "km_chol");
@@ -521,14 +545,15 @@ void do_pass1(gprhip_problem* p, const gprhip_hypers* h, int want_grad, int64_t 
     const int rows_p = (int)round_up(rows, TILE);
     const int64_t base = (int64_t)c * p->chunk;
     TS* V = Vstore + base * mp;
+    TS* const Kc = Kstore ? Kstore + base * mp : bufA;  // this chunk's K_nm: kept, or in the chunk buffer
     if (!reuse) {
       tstart(p, "p1_cov");
       if (c == 0 && cov0_ahead) GPR_HIP(hipStreamWaitEvent(s, p->ev_join, 0));
-      else cov_chunk<TS>(p, c, bufA);
+      else cov_chunk<TS>(p, c, Kc);
       tstop(p);
       tstart(p, "p1_trmm_V");
       GemmArgsT<TS> g;  // V = K U^-1   (dtrsm `R, lib/fitc_gp.ml:226-227)
-      g.A = bufA; g.lda = mp; g.B = inv_u<TS>(p); g.ldb = mp; g.C = V; g.ldc = mp;
+      g.A = Kc; g.lda = mp; g.B = inv_u<TS>(p); g.ldb = mp; g.C = V; g.ldc = mp;
       g.M = rows_p; g.N = mp; g.K = mp; g.tri = TRI_KHI_BN; g.order = p->tile_order;
       g.rp_sumsq = p->rp1;  // r = k_diag - rowsum(V.^2) comes out of the epilogue (Mat.syrk_diag, :222-223)
       launch_gemm(OP_NN, g, s);
@@ -574,6 +599,7 @@ void do_pass1(gprhip_problem* p, const gprhip_hypers* h, int want_grad, int64_t 
   launch_sum_slices<TS>(nullptr, slices, ks, mm, mp, ar1, s, 1, ksd);
   p->stage = 1;
   p->have_v = true;  // (revoked by finish() if the factorisation of K_m turns out to have failed)
+  if (!reuse) p->have_k = Kstore != nullptr;
 }
 
 template <typename TS>
@@ -665,6 +691,7 @@ void do_pass2(gprhip_problem* p, const double* ar1, double* ar2) {
       ga.colpart = p->colpart; ga.scalpart = p->scalpart;
       ga.big = proj ? p->X + base * p->D : nullptr; ga.D = proj ? p->D : 0;
       ga.ms = p->cp.ms; ga.rowes = nullptr; ga.shift = p->zshift;
+      ga.K = (p->Kstore && p->have_k && proj && !ga.ms) ? static_cast<const TS*>(p->Kstore) + base * mp : nullptr;
       ga.col_rows = p->d + 1 + ga.D + (ga.ms ? p->d : 0);  // rows this launch produces (tightly packed)
       ga.slab = grad_slab_rows((int)p->col_rows());
       const int nslots = 4 * ((mp + 255) / 256);
@@ -781,7 +808,7 @@ void do_finish(gprhip_problem* p, const double* ar2, gprhip_result* res, double*
   p->stage = 0;
   if (p->timer.on || p->timer.kernel) tcollect(p);
   if (hinfo[0] != 0 || hinfo[1] != 0) {
-    p->have_v = false;  // V came out of a failed factor
+    p->have_v = p->have_k = false;  // V came out of a failed factor
     char buf[160];
     snprintf(buf, sizeof buf,
              "Lacaml.D.potrf: leading minor of order %d of %s is not positive definite",
@@ -1180,7 +1207,7 @@ void do_load_predictor(gprhip_problem* p, const gprhip_hypers* h, const double* 
   hipStream_t s = p->stream;
   const int mp = p->mp, m = p->m;
   const int64_t mm = (int64_t)mp * mp;
-  p->have_model = p->have_factors = p->have_v = false;
+  p->have_model = p->have_factors = p->have_v = p->have_k = false;
   upload_hypers(p, h);
   std::vector<double> t(mp, 0.0);
   if (coeffs) std::memcpy(t.data(), coeffs, (size_t)m * sizeof(double));
@@ -1299,6 +1326,7 @@ int gprhip_problem_create_ex(int device, int cov_kind, int precision, int64_t n,
     }
     if (const char* e = getenv("GPRHIP_TILE_ORDER")) p->tile_order = atoi(e);
     if (const char* e = getenv("GPRHIP_GRAD_SCALAR")) p->grad_scalar = atoi(e);
+    if (const char* e = getenv("GPRHIP_K_RESIDENT")) p->k_resident = atoi(e);
     GPR_HIP(hipStreamCreate(&p->stream));
     GPR_HIP(hipStreamCreate(&p->stream2));
     GPR_HIP(hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming));

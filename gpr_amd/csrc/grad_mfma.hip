@@ -15,6 +15,10 @@
 // A 16x16 tile of E comes out of the elementwise step in the accumulator layout (lane holds rows lq + 4r of column
 // l15), which is exactly four B operands (k = lq) of the next MFMAs: E never leaves the registers.
 // Workgroup: 4 wavefronts x 32 columns, one slab of a.slab rows, rows staged through LDS 32 at a time.
+// KR ("K resident", Cov_se_fat with projection hypers): K_nm of pass 1 is still in memory (gprhip.hip keeps it when the
+// device has room), so E = X .* K is read -- no distance product, no exp: the kernel is left with the X_big^T E
+// MFMAs and 2 x 4 (fp32-bulk) or 2 x 8 bytes per element of HBM traffic (C3: 24 -> 9 ms per evaluation).  Cov_se_fat
+// has no length-scale hyper, so the sum E .* D of the iso kernel is not needed there.
 #include "kernels.h"
 #include "exp_fast.h"
 
@@ -36,7 +40,7 @@ constexpr int G_RC = 64;     // rows per staged chunk
 
 // KS4 = ceil(d / 4) k-steps of the distance product, DT = ceil(d / 16) tiles of point dimensions,
 // BT = ceil(D / 16) tiles of original input dimensions (0: no projection hypers)
-template <int KS4, int DT, int BT, typename TS>
+template <int KS4, int DT, int BT, typename TS, bool KR = false>
 __global__ __launch_bounds__(256, (DT + BT <= 4 && KS4 <= 8) ? 2 : 1) void grad_mfma_kernel(GradArgs<TS> a) {
   constexpr int DP = DT * 16, LDP = DP + 1;
   constexpr int BP = BT > 0 ? BT * 16 : 1, LDB = BP + 1;
@@ -65,15 +69,17 @@ __global__ __launch_bounds__(256, (DT + BT <= 4 && KS4 <= 8) ? 2 : 1) void grad_
     const int col = cb + jt * 16 + l15;
     live_c[jt] = col < a.m;
     double s2 = 0.0;
+    if constexpr (!KR) {
 #pragma unroll
-    for (int s = 0; s < KS4; ++s) {
-      const int k = 4 * s + lq;
-      const double z = (live_c[jt] && k < a.d) ? a.Z[(int64_t)col * a.d + k] - sh[k] : 0.0;
-      zf[jt][s] = z;
-      s2 += z * z;
+      for (int s = 0; s < KS4; ++s) {
+        const int k = 4 * s + lq;
+        const double z = (live_c[jt] && k < a.d) ? a.Z[(int64_t)col * a.d + k] - sh[k] : 0.0;
+        zf[jt][s] = z;
+        s2 += z * z;
+      }
+      s2 += __shfl_xor(s2, 16);
+      s2 += __shfl_xor(s2, 32);
     }
-    s2 += __shfl_xor(s2, 16);
-    s2 += __shfl_xor(s2, 32);
     zn[jt] = s2;
   }
   gd4 g[DT][2], gb[BT > 0 ? BT : 1][2];
@@ -91,13 +97,16 @@ __global__ __launch_bounds__(256, (DT + BT <= 4 && KS4 <= 8) ? 2 : 1) void grad_
   const int r1 = min(a.rows, r0 + a.slab);
 
   // X values of one 16-row tile (rows first .. first+15) for this wave's 32 columns
+  // (KR: times the K values of the same elements -- the loaded tile is E itself)
   auto load_x = [&](int first, double (&xv)[2][4]) {
 #pragma unroll
     for (int jt = 0; jt < 2; ++jt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int row = first + lq + 4 * r;
-        xv[jt][r] = (row < r1) ? (double)a.X[(int64_t)row * a.mp + cb + jt * 16 + l15] : 0.0;
+        const int64_t off = (int64_t)row * a.mp + cb + jt * 16 + l15;
+        if constexpr (KR) xv[jt][r] = (row < r1) ? (double)a.X[off] * (double)a.K[off] : 0.0;
+        else xv[jt][r] = (row < r1) ? (double)a.X[off] : 0.0;
       }
   };
   // one 16-row tile: rows rb + 16 rt ... of the chunk staged at psb / bsb / pnb
@@ -105,19 +114,29 @@ __global__ __launch_bounds__(256, (DT + BT <= 4 && KS4 <= 8) ? 2 : 1) void grad_
     double ev[2][4];
 #pragma unroll
     for (int jt = 0; jt < 2; ++jt) {
-      gd4 s4 = (gd4){0, 0, 0, 0};
+      if constexpr (KR) {
 #pragma unroll
-      for (int s = 0; s < KS4; ++s) s4 = mfma4(psb[(rt * 16 + l15) * LDP + 4 * s + lq], zf[jt][s], s4);
+        for (int r = 0; r < 4; ++r) {  // padded rows and columns of X and K are zero
+          const double e = xv[jt][r];
+          ev[jt][r] = e;
+          cs[jt] += e;
+          sE += e;
+        }
+      } else {
+        gd4 s4 = (gd4){0, 0, 0, 0};
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int lr = rt * 16 + lq + 4 * r;
-        const double dist = fmax(pnb[lr] + zn[jt] - 2.0 * s4[r], 0.0);
-        const double kv = exp_fast(a.log_sf2 + a.inv_ell2_05 * dist, ek);
-        const double e = (live_c[jt] && rb + lr < r1) ? xv[jt][r] * kv : 0.0;
-        ev[jt][r] = e;
-        cs[jt] += e;
-        sE += e;
-        sED += e * dist;
+        for (int s = 0; s < KS4; ++s) s4 = mfma4(psb[(rt * 16 + l15) * LDP + 4 * s + lq], zf[jt][s], s4);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int lr = rt * 16 + lq + 4 * r;
+          const double dist = fmax(pnb[lr] + zn[jt] - 2.0 * s4[r], 0.0);
+          const double kv = exp_fast(a.log_sf2 + a.inv_ell2_05 * dist, ek);
+          const double e = (live_c[jt] && rb + lr < r1) ? xv[jt][r] * kv : 0.0;
+          ev[jt][r] = e;
+          cs[jt] += e;
+          sE += e;
+          sED += e * dist;
+        }
       }
     }
 #pragma unroll
@@ -273,6 +292,12 @@ __global__ __launch_bounds__(256, (DT + BT <= 4 && KS4 <= 8) ? 2 : 1) void grad_
 
 template <int KS4, int DT, typename TS>
 void dispatch_big(const GradArgs<TS>& a, dim3 grid, hipStream_t s) {
+  if (a.K && a.big) {  // K resident (projection hypers only: the caller passes K for no other launch)
+    if (a.D <= 16) hipLaunchKernelGGL((grad_mfma_kernel<KS4, DT, 1, TS, true>), grid, dim3(256), 0, s, a);
+    else if (a.D <= 32) hipLaunchKernelGGL((grad_mfma_kernel<KS4, DT, 2, TS, true>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((grad_mfma_kernel<KS4, DT, 4, TS, true>), grid, dim3(256), 0, s, a);
+    return;
+  }
   if (!a.big) hipLaunchKernelGGL((grad_mfma_kernel<KS4, DT, 0, TS>), grid, dim3(256), 0, s, a);
   else if (a.D <= 16) hipLaunchKernelGGL((grad_mfma_kernel<KS4, DT, 1, TS>), grid, dim3(256), 0, s, a);
   else if (a.D <= 32) hipLaunchKernelGGL((grad_mfma_kernel<KS4, DT, 2, TS>), grid, dim3(256), 0, s, a);

@@ -144,6 +144,8 @@ struct GradArgs {
   double* scalpart;      // out [nslabs][nbx][2]: sum E, sum E*sqr_diff
   const double* shift;   // [d] common offset (centroid of the inducing points) the MFMA kernel subtracts from points
                          //     and inducing points before it expands |p - z|^2, or null
+  const TS* K;           // [rows_p][mp] K_nm of the chunk kept from pass 1 (Cov_se_fat, matrix-core kernel), or null:
+                         //     E = X .* K is then read instead of recomputed (no distance product, no exp)
   const double* ms;      // multiscales [mp][d] or null (Cov_se_fat)
   double* rowes;         // multiscales + tproj: out [rows][nslots][d] partial sum_c E_rc / ms_kc, nslots = 4*gridDim.x
 };

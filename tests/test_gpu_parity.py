@@ -1132,6 +1132,29 @@ def test_scalar_and_mfma_gradient_kernels_agree(name, monkeypatch):
     assert a.l == b.l
 
 
+@pytest.mark.parametrize("name", ["fat_proj", "fat_hetero", "fat_proj_var"])
+def test_resident_and_recomputed_covariance_gradient_passes_agree(name, monkeypatch):
+    """Cov_se_fat with projection hypers keeps K_nm of pass 1 on the device when there is room and the gradient kernel
+    reads E = X .* K (grad_mfma.hip, KR) instead of recomputing distances and exp; GPRHIP_K_RESIDENT=0 forces the
+    recomputing kernel.  Both meet the oracle tolerance, agree with each other, and sigma2-only re-evaluations
+    (update_sigma2: V, r and K reused) go through the kept K as well."""
+    g = load_golden(name)
+    if "tproj" not in g:
+        pytest.skip("no projection hypers in this fixture")
+    p = _problem_for(g)
+    a = _eval_golden(p, g)
+    a2 = _eval_golden(p, g, sigma2=2.0 * float(g["sigma2"]), reuse_v=True)
+    p.close()
+    monkeypatch.setenv("GPRHIP_K_RESIDENT", "0")
+    q = _problem_for(g)
+    b = _eval_golden(q, g)
+    b2 = _eval_golden(q, g, sigma2=2.0 * float(g["sigma2"]), reuse_v=True)
+    q.close()
+    assert relinf(a.grad, g["grad"]) <= TOL_GRAD and relinf(b.grad, g["grad"]) <= TOL_GRAD
+    assert relinf(a.grad, b.grad) <= 1e-9 and relinf(a2.grad, b2.grad) <= 1e-9
+    assert a.l == b.l and a2.l == b2.l
+
+
 def test_inputs_with_a_large_common_offset():
     """The matrix-core gradient kernel expands |p - z|^2 around the centroid of the inducing points: data far from
     the origin (offset 1e4 at unit spread) must not cost digits against the oracle's direct differences."""
