@@ -1302,6 +1302,28 @@ def test_random_shapes_against_oracle(seed):
     """Seeded sweep over shapes the fixed cases do not hit: odd point counts (several k-slices and row chunks with
     ragged tails), 1..6 tile rows of inducing points (SYRK diagonal / off-diagonal tile maps and their slice ratios),
     every point-dimension instantiation, both kernels with random option sets, standard and variational."""
+    _random_shape_case(seed)
+
+
+@pytest.mark.gpu
+def test_random_shapes_long_sweep():
+    """The same sweep over a seed range given in GPR_FUZZ_SEEDS="lo:hi" (skipped without it): the long runs whose logs
+    are kept under profiles/ (r03_fuzz.txt: seeds 24..423)."""
+    spec = os.environ.get("GPR_FUZZ_SEEDS")
+    if not spec:
+        pytest.skip("GPR_FUZZ_SEEDS not set")
+    lo, hi = (int(v) for v in spec.split(":"))
+    bad = []
+    for seed in range(lo, hi):
+        try:
+            _random_shape_case(seed)
+        except AssertionError as e:  # keep going: the log should name every failing seed
+            bad.append((seed, str(e)[:200]))
+    print("random-shape sweep: seeds %d..%d, %d cases, %d failures %s" % (lo, hi - 1, hi - lo, len(bad), bad))
+    assert not bad, bad
+
+
+def _random_shape_case(seed):
     rng = np.random.default_rng(1000 + seed)
     iso = seed % 2 == 0   # (the oracle forms one dense n x m derivative matrix per Proj hyper: smaller fat cases)
     n = int(rng.integers(300, 6000 if iso else 3000))
@@ -1313,7 +1335,9 @@ def test_random_shapes_against_oracle(seed):
     sigma2 = float(10.0 ** rng.uniform(-2, 0))
     chunk_rows = int(rng.choice([0, 256, 1024, 4096]))
     if iso:
-        X, y, Z = synth(2000 + seed, n, m, d)
+        X, y, Z = synth(2000 + seed, n, min(m, n), d)
+        if m > n:  # more inducing points than training points: legal, and a shape of its own (k-range shorter than m)
+            Z = np.asfortranarray(np.hstack([Z, rng.normal(size=(d, m - n))]))
         log_ell = 0.5 * np.log(d) + rng.uniform(-0.3, 0.3)
         k = O.SeIsoKernel(log_ell, rng.uniform(-0.5, 0.5))
         p = gpr_amd.Problem(gpr_amd.COV_SE_ISO, n, d, d, m, chunk_rows=chunk_rows)
