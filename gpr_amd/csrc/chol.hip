@@ -306,7 +306,12 @@ __global__ __launch_bounds__(256) void potrf_panel_kernel(double* __restrict__ A
 // Trailing update: A[r, c] -= X_r^T X_c over the upper 64 x 64 sub-tiles of the blocks behind step j (X = block row j,
 // 128 deep).  One workgroup per sub-tile, a 32 x 32 quarter per wavefront; the fragments of both operands are rows of
 // X, read from L2 as they are (16 consecutive doubles per k).
-__global__ __launch_bounds__(256) void potrf_update_kernel(double* __restrict__ A, int mp, int j) {
+// ALL: every operand fragment is requested before the first MFMA (128 fragment registers, one wavefront per SIMD) -- the
+// kernel's time is launch latency plus load round trips, and left alone the scheduler keeps only five k-steps of loads
+// in flight (13 us of stalls for 3.4 us of MFMAs).  Used while a step's sub-tiles fit the chip in one round at that
+// occupancy; bigger steps run the compiler's pipelined order with four workgroups per CU.
+template <bool ALL>
+__device__ __forceinline__ void potrf_update_body(double* __restrict__ A, int mp, int j) {
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int l15 = lane & 15, lq = lane >> 4;
   int si = 0, rem = blockIdx.x;  // sub-tile (si <= sj) of the trailing part, in 64-blocks
@@ -329,14 +334,34 @@ __global__ __launch_bounds__(256) void potrf_update_kernel(double* __restrict__ 
     for (int jj = 0; jj < 2; ++jj)
 #pragma unroll
       for (int r = 0; r < 4; ++r) acc[i][jj][r] = Cp[(int64_t)(16 * i + 4 * r) * mp + 16 * jj];
+  if constexpr (ALL) {
+    double av[NB / 4][2], bv[NB / 4][2];
+#pragma unroll
+    for (int ks = 0; ks < NB / 4; ++ks) {
+      const int64_t o = (int64_t)(4 * ks) * mp;
+      av[ks][0] = Xa[o];
+      av[ks][1] = Xa[o + 16];
+      bv[ks][0] = Xb[o];
+      bv[ks][1] = Xb[o + 16];
+    }
+#pragma unroll
+    for (int ks = 0; ks < NB / 4; ++ks) {
+      const double a0 = -av[ks][0], a1 = -av[ks][1];
+      acc[0][0] = mfma_f64(a0, bv[ks][0], acc[0][0]);
+      acc[0][1] = mfma_f64(a0, bv[ks][1], acc[0][1]);
+      acc[1][0] = mfma_f64(a1, bv[ks][0], acc[1][0]);
+      acc[1][1] = mfma_f64(a1, bv[ks][1], acc[1][1]);
+    }
+  } else {
 #pragma unroll 8
-  for (int ks = 0; ks < NB / 4; ++ks) {
-    const int64_t o = (int64_t)(4 * ks) * mp;
-    const double a0 = -Xa[o], a1 = -Xa[o + 16], b0 = Xb[o], b1 = Xb[o + 16];
-    acc[0][0] = mfma_f64(a0, b0, acc[0][0]);
-    acc[0][1] = mfma_f64(a0, b1, acc[0][1]);
-    acc[1][0] = mfma_f64(a1, b0, acc[1][0]);
-    acc[1][1] = mfma_f64(a1, b1, acc[1][1]);
+    for (int ks = 0; ks < NB / 4; ++ks) {
+      const int64_t o = (int64_t)(4 * ks) * mp;
+      const double a0 = -Xa[o], a1 = -Xa[o + 16], b0 = Xb[o], b1 = Xb[o + 16];
+      acc[0][0] = mfma_f64(a0, b0, acc[0][0]);
+      acc[0][1] = mfma_f64(a0, b1, acc[0][1]);
+      acc[1][0] = mfma_f64(a1, b0, acc[1][0]);
+      acc[1][1] = mfma_f64(a1, b1, acc[1][1]);
+    }
   }
 #pragma unroll
   for (int i = 0; i < 2; ++i)
@@ -344,6 +369,13 @@ __global__ __launch_bounds__(256) void potrf_update_kernel(double* __restrict__ 
     for (int jj = 0; jj < 2; ++jj)
 #pragma unroll
       for (int r = 0; r < 4; ++r) Cp[(int64_t)(16 * i + 4 * r) * mp + 16 * jj] = acc[i][jj][r];
+}
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) void potrf_update_all_kernel(
+    double* __restrict__ A, int mp, int j) {
+  potrf_update_body<true>(A, mp, j);
+}
+__global__ __launch_bounds__(256) void potrf_update_kernel(double* __restrict__ A, int mp, int j) {
+  potrf_update_body<false>(A, mp, j);
 }
 
 __global__ void zero_strict_lower_kernel(double* __restrict__ A, int mp) {
@@ -444,7 +476,9 @@ void potrf_upper_blocked(hipStream_t s, double* A, int mp, double* dinv, int* in
     if (j + 1 < nb) {
       const int rest = nb - 1 - j, ns = 2 * rest;
       hipLaunchKernelGGL(potrf_panel_kernel, dim3(2 * rest), dim3(256), PANEL_LDS, s, A, mp, j, dj);
-      hipLaunchKernelGGL(potrf_update_kernel, dim3(ns * (ns + 1) / 2), dim3(256), 0, s, A, mp, j);
+      const int tiles = ns * (ns + 1) / 2;
+      if (tiles <= 320) hipLaunchKernelGGL(potrf_update_all_kernel, dim3(tiles), dim3(256), 0, s, A, mp, j);
+      else hipLaunchKernelGGL(potrf_update_kernel, dim3(tiles), dim3(256), 0, s, A, mp, j);
     }
   }
   hipLaunchKernelGGL(potrf_diag_kernel, dim3(nb), dim3(PT), POTRF_LDS, s, A, mp, 0, dinv, info, 1);
