@@ -1155,6 +1155,29 @@ def test_resident_and_recomputed_covariance_gradient_passes_agree(name, monkeypa
     assert a.l == b.l and a2.l == b2.l
 
 
+@pytest.mark.parametrize("n,m,d", [(1, 1, 1), (2, 1, 3), (3, 7, 2), (129, 128, 4), (128, 129, 4), (127, 257, 1)])
+def test_degenerate_and_tile_boundary_shapes(n, m, d):
+    """One training point, one inducing point, more inducing than training points, sizes one off the 128-tile: every
+    padded row and column must stay out of the sums (Cov_se_iso evidence + full gradient, standard and variational)."""
+    rng = np.random.default_rng(100 * n + m)
+    X = np.asfortranarray(rng.normal(size=(d, n)))
+    y = np.sin(X.sum(0)) + 0.1 * rng.normal(size=n)
+    Z = np.asfortranarray(rng.normal(size=(d, m)))
+    k = O.SeIsoKernel(0.1, -0.2)
+    for variational in (False, True):
+        ref = O.evaluate(k, Z, X, y, 0.3, variational=variational)
+        p = gpr_amd.Problem(gpr_amd.COV_SE_ISO, n, d, d, m)
+        p.set_inputs(X)
+        p.set_targets(y)
+        ev = p.eval(log_ell=0.1, log_sf2=-0.2, sigma2=0.3, inducing=Z, variational=variational)
+        p.close()
+        assert abs(ev.l - ref["l"]) <= TOL_L * max(1.0, abs(ref["l"]))
+        assert abs(ev.dl_dsigma2 - ref["dl_dsigma2"]) <= TOL_DS2 * max(1.0, abs(ref["dl_dsigma2"]))
+        assert ev.grad.shape == ref["grad"].shape
+        assert np.max(np.abs(ev.grad - ref["grad"])) <= TOL_GRAD * max(1.0, np.max(np.abs(ref["grad"])))
+        assert np.max(np.abs(ev.coeffs - ref["coeffs"])) <= TOL_COEFF * max(1.0, np.max(np.abs(ref["coeffs"])))
+
+
 def test_inputs_with_a_large_common_offset():
     """The matrix-core gradient kernel expands |p - z|^2 around the centroid of the inducing points: data far from
     the origin (offset 1e4 at unit spread) must not cost digits against the oracle's direct differences."""
