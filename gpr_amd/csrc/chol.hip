@@ -2,6 +2,7 @@
 // plus the small m-vector helpers.  The trailing updates and panel solves run on the MFMA
 // engine; these kernels handle the 128 x 128 diagonal blocks in LDS (one workgroup each).
 // Reference call sites: lib/fitc_gp.ml:53-57 (potrf of K_m + jitter), lib/utils.ml:95-113.
+#include <cstdlib>
 #include "kernels.h"
 
 namespace gprhip {
@@ -261,8 +262,12 @@ __global__ __launch_bounds__(PT) void potrf_diag_kernel(double* __restrict__ A, 
 // An accumulator tile holds rows lq + 4r in register r: used as the B operand of the next MFMA it supplies the k index
 // in that order, and the A operand (read from LDS) is indexed to match.
 constexpr int PANEL_LDS = (36 + 8) * MB * MB * 8;
+// With an identity right-hand side Y carried along (potrf_upper_blocked with Yinv), workgroups beyond the panel's own
+// solve block row j of Y the same way: Y[j, c] <- U_jj^-T Y[j, c] for the column blocks c <= j that are non-zero, so that
+// Y ends as U^-T and the separate triangular inversion goes away.
 __global__ __launch_bounds__(256) void potrf_panel_kernel(double* __restrict__ A, int mp, int j,
-                                                          const double* __restrict__ dmicro) {
+                                                          const double* __restrict__ dmicro,
+                                                          double* __restrict__ Y) {
   extern __shared__ __attribute__((aligned(16))) double L[];  // [36][16][16] blocks (i <= b) of U_jj, then [8][16][16] D_b
   double* Dm = L + 36 * MB * MB;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -278,8 +283,10 @@ __global__ __launch_bounds__(256) void potrf_panel_kernel(double* __restrict__ A
 #pragma unroll
     for (int b = 0; b < 8; ++b) Dm[b * 256 + tid] = dmicro[b * 256 + tid];
   }
-  const int c0 = (j + 1) * NB + blockIdx.x * 64 + wid * 16;
-  double* Ap = A + (int64_t)j * NB * mp + c0 + l15;
+  const int na = (mp / NB - 1 - j) * 2;  // 64-column groups of the panel proper
+  const bool rhs = (int)blockIdx.x >= na;
+  const int c0 = rhs ? ((int)blockIdx.x - na) * 64 + wid * 16 : (j + 1) * NB + blockIdx.x * 64 + wid * 16;
+  double* Ap = (rhs ? Y : A) + (int64_t)j * NB * mp + c0 + l15;
   pd4 T[8];
 #pragma unroll
   for (int b = 0; b < 8; ++b)
@@ -310,23 +317,38 @@ __global__ __launch_bounds__(256) void potrf_panel_kernel(double* __restrict__ A
 // kernel's time is launch latency plus load round trips, and left alone the scheduler keeps only five k-steps of loads
 // in flight (13 us of stalls for 3.4 us of MFMAs).  Used while a step's sub-tiles fit the chip in one round at that
 // occupancy; bigger steps run the compiler's pipelined order with four workgroups per CU.
+// Workgroups beyond the symmetric part update the carried right-hand side: Y[r, c] -= X_r^T Y[j, c] for the row blocks
+// r > j and the column blocks c <= j (nsym = number of symmetric sub-tiles; Y may be null).
 template <bool ALL>
-__device__ __forceinline__ void potrf_update_body(double* __restrict__ A, int mp, int j) {
+__device__ __forceinline__ void potrf_update_body(double* __restrict__ A, int mp, int j, double* __restrict__ Y,
+                                                  int nsym) {
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int l15 = lane & 15, lq = lane >> 4;
-  int si = 0, rem = blockIdx.x;  // sub-tile (si <= sj) of the trailing part, in 64-blocks
   const int ns = (mp / NB - 1 - j) * 2;
-  while (rem >= ns - si) {
-    rem -= ns - si;
-    ++si;
-  }
-  const int sj = si + rem;
   const int64_t base = (int64_t)(j + 1) * NB;
-  const int64_t r0 = base + si * 64 + (wid >> 1) * 32, c0 = base + sj * 64 + (wid & 1) * 32;
   const double* X = A + (int64_t)j * NB * mp;
+  int64_t r0, c0;
+  const double* Xb;
+  double* Cp;
+  if ((int)blockIdx.x < nsym) {
+    int si = 0, rem = blockIdx.x;  // sub-tile (si <= sj) of the trailing part, in 64-blocks
+    while (rem >= ns - si) {
+      rem -= ns - si;
+      ++si;
+    }
+    const int sj = si + rem;
+    r0 = base + si * 64 + (wid >> 1) * 32;
+    c0 = base + sj * 64 + (wid & 1) * 32;
+    Xb = X + (int64_t)lq * mp + c0 + l15;
+    Cp = A + (r0 + lq) * mp + c0 + l15;
+  } else {
+    const int t = (int)blockIdx.x - nsym, ncb = 2 * (j + 1);
+    r0 = base + (t / ncb) * 64 + (wid >> 1) * 32;
+    c0 = (int64_t)(t % ncb) * 64 + (wid & 1) * 32;
+    Xb = Y + (int64_t)(j * NB + lq) * mp + c0 + l15;
+    Cp = Y + (r0 + lq) * mp + c0 + l15;
+  }
   const double* Xa = X + (int64_t)lq * mp + r0 + l15;
-  const double* Xb = X + (int64_t)lq * mp + c0 + l15;
-  double* Cp = A + (r0 + lq) * mp + c0 + l15;
   pd4 acc[2][2];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
@@ -371,11 +393,28 @@ __device__ __forceinline__ void potrf_update_body(double* __restrict__ A, int mp
       for (int r = 0; r < 4; ++r) Cp[(int64_t)(16 * i + 4 * r) * mp + 16 * jj] = acc[i][jj][r];
 }
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) void potrf_update_all_kernel(
-    double* __restrict__ A, int mp, int j) {
-  potrf_update_body<true>(A, mp, j);
+    double* __restrict__ A, int mp, int j, double* __restrict__ Y, int nsym) {
+  potrf_update_body<true>(A, mp, j, Y, nsym);
 }
-__global__ __launch_bounds__(256) void potrf_update_kernel(double* __restrict__ A, int mp, int j) {
-  potrf_update_body<false>(A, mp, j);
+__global__ __launch_bounds__(256) void potrf_update_kernel(double* __restrict__ A, int mp, int j,
+                                                           double* __restrict__ Y, int nsym) {
+  potrf_update_body<false>(A, mp, j, Y, nsym);
+}
+
+// Y = identity (the right-hand side carried through the factorisation), and the final X = Y^T
+__global__ void set_identity_kernel(double* __restrict__ Y, int mp) {
+  const int c = blockIdx.x * 256 + threadIdx.x, r = blockIdx.y;
+  if (c < mp) Y[(int64_t)r * mp + c] = (r == c) ? 1.0 : 0.0;
+}
+__global__ __launch_bounds__(256) void transpose_kernel(const double* __restrict__ Y, int mp, double* __restrict__ X) {
+  __shared__ double t[32][33];
+  const int bx = blockIdx.x * 32, by = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+#pragma unroll
+  for (int i = 0; i < 32; i += 8) t[ty + i][tx] = Y[(int64_t)(by + ty + i) * mp + bx + tx];
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 32; i += 8) X[(int64_t)(bx + ty + i) * mp + by + tx] = t[tx][ty + i];
 }
 
 __global__ void zero_strict_lower_kernel(double* __restrict__ A, int mp) {
@@ -455,7 +494,7 @@ void launch_potrf_diag_flags(double* A, int mp, int j, double* dinv, int* info, 
 // Blocked upper Cholesky A = U^T U in place (dpotrf `U; lib/fitc_gp.ml:56) with inv(U_jj) of every diagonal block in
 // dinv: per step a factor-only diagonal kernel, the substitution panel and the small-tile trailing update; the block
 // inverses (which nothing on the chain needs any more) are formed by one launch over all blocks at the end.
-void potrf_upper_blocked(hipStream_t s, double* A, int mp, double* dinv, int* info) {
+void potrf_upper_blocked(hipStream_t s, double* A, int mp, double* dinv, int* info, double* Yscratch, double* Xinv) {
   static bool attr = false;
   if (!attr) {
     GPR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&potrf_diag_kernel),
@@ -464,24 +503,38 @@ void potrf_upper_blocked(hipStream_t s, double* A, int mp, double* dinv, int* in
                                 hipFuncAttributeMaxDynamicSharedMemorySize, PANEL_LDS));
     attr = true;
   }
+  static const int all_tiles = [] {  // largest step (in 64 x 64 sub-tiles) that runs the all-loads-first update kernel
+    const char* e = getenv("GPRHIP_POTRF_ALL_TILES");
+    return e ? atoi(e) : 768;
+  }();
   const int nb = mp / NB;
   if (nb == 1) {  // a single block: factor and inverse in one launch
     hipLaunchKernelGGL(potrf_diag_kernel, dim3(1), dim3(PT), POTRF_LDS, s, A, mp, 0, dinv, info, 0);
+    if (Xinv) launch_scatter_diag_blocks(dinv, mp, Xinv, s);
     GPR_HIP(hipGetLastError());
     return;
   }
+  // With Xinv the inverse of the factor comes out of the same steps: an identity right-hand side Y rides along (panel:
+  // Y[j, :] <- U_jj^-T Y[j, :], update: Y[r, :] -= U[j, r]^T Y[j, :]), Y ends as U^-T and X = Y^T.  The extra tiles run
+  // on compute units the latency-bound steps leave idle; the recursive-doubling inversion (eight engine launches,
+  // 0.29 ms at m = 2048) and the block-inverse launch are not needed then.
+  double* const Y = Xinv ? Yscratch : nullptr;
+  if (Y) hipLaunchKernelGGL(set_identity_kernel, dim3((mp + 255) / 256, mp), dim3(256), 0, s, Y, mp);
   for (int j = 0; j < nb; ++j) {
     double* dj = dinv + (int64_t)j * NB * NB;
     hipLaunchKernelGGL(potrf_diag_kernel, dim3(1), dim3(PT), POTRF_LDS, s, A, mp, j, dj, info, 2 + 32);
-    if (j + 1 < nb) {
-      const int rest = nb - 1 - j, ns = 2 * rest;
-      hipLaunchKernelGGL(potrf_panel_kernel, dim3(2 * rest), dim3(256), PANEL_LDS, s, A, mp, j, dj);
-      const int tiles = ns * (ns + 1) / 2;
-      if (tiles <= 320) hipLaunchKernelGGL(potrf_update_all_kernel, dim3(tiles), dim3(256), 0, s, A, mp, j);
-      else hipLaunchKernelGGL(potrf_update_kernel, dim3(tiles), dim3(256), 0, s, A, mp, j);
+    const int rest = nb - 1 - j, ns = 2 * rest;
+    const int nrhs = Y ? 2 * (j + 1) : 0;  // 64-column groups of the right-hand side that are non-zero in block row j
+    if (rest + nrhs > 0)
+      hipLaunchKernelGGL(potrf_panel_kernel, dim3(2 * rest + nrhs), dim3(256), PANEL_LDS, s, A, mp, j, dj, Y);
+    if (rest > 0) {
+      const int nsym = ns * (ns + 1) / 2, tiles = nsym + ns * nrhs;
+      if (tiles <= all_tiles) hipLaunchKernelGGL(potrf_update_all_kernel, dim3(tiles), dim3(256), 0, s, A, mp, j, Y, nsym);
+      else hipLaunchKernelGGL(potrf_update_kernel, dim3(tiles), dim3(256), 0, s, A, mp, j, Y, nsym);
     }
   }
-  hipLaunchKernelGGL(potrf_diag_kernel, dim3(nb), dim3(PT), POTRF_LDS, s, A, mp, 0, dinv, info, 1);
+  if (Y) hipLaunchKernelGGL(transpose_kernel, dim3(mp / 32, mp / 32), dim3(256), 0, s, Y, mp, Xinv);
+  else hipLaunchKernelGGL(potrf_diag_kernel, dim3(nb), dim3(PT), POTRF_LDS, s, A, mp, 0, dinv, info, 1);
   GPR_HIP(hipGetLastError());
 }
 

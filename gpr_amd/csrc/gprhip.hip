@@ -259,6 +259,10 @@ void potrf_upper_n(hipStream_t s, double* A, int mp, double* dinv, int* info) {
   }
 }
 void potrf_upper(gprhip_problem* p, double* A, int* info) { potrf_upper_n(p->stream, A, p->mp, p->dinv, info); }
+static const bool g_engine_steps = [] {  // GPRHIP_POTRF_ENGINE=1: the round-2 factorisation + recursive-doubling inverse
+  const char* e = getenv("GPRHIP_POTRF_ENGINE");
+  return e && atoi(e) != 0;
+}();
 
 // A non-batched m x m product with few output tiles and a long k-range, split over `ks` k-slices so that the
 // launch fills the chip; partial products go to the split-K scratch and are summed in a fixed order.
@@ -333,6 +337,17 @@ void trtri_upper(gprhip_problem* p, const double* U, double* X, double* tmp) {
     if (nfull > 0) join(0, sz, nfull);
     if (rem > sz) join((int64_t)nfull * pair, rem - sz, 1);
   }
+}
+
+// U = chol(A) in place and X = inv(U): one pass of the step kernels with the identity riding along as right-hand side
+// (chol.hip); `tmp` is an mp x mp scratch
+void potrf_trtri(gprhip_problem* p, double* A, double* X, double* tmp, int* info) {
+  if (g_engine_steps) {
+    potrf_upper(p, A, info);
+    trtri_upper(p, A, X, tmp);
+    return;
+  }
+  potrf_upper_blocked(p->stream, A, p->mp, p->dinv, info, tmp, X);
 }
 
 // C (upper tiles) = X X^T for upper-triangular X: (U^T U)^-1 = U^-1 U^-T   (Utils.ichol, lib/utils.ml:110-113)
@@ -535,8 +550,7 @@ void do_pass1(gprhip_problem* p, const gprhip_hypers* h, int want_grad, int64_t 
   GPR_HIP(hipMemsetAsync(ar1_c, 0, (size_t)(mp + A1_TAIL) * sizeof(double), s));
   // K_m + (hetero) + jitter goes straight into the factor's buffer (kj is scratch of the finish stage only)
   launch_cov_upper(p->cp, p->Z, p->m, mp, p->d, h->jitter, p->has_het() ? p->het : nullptr, p->km, p->umat, s);
-  potrf_upper(p, p->umat, p->info);  // U = chol(K_m + jitter), lib/fitc_gp.ml:53-57
-  trtri_upper(p, p->umat, p->uinv, p->wmat);
+  potrf_trtri(p, p->umat, p->uinv, p->wmat, p->info);  // U = chol(K_m + jitter), lib/fitc_gp.ml:53-57, and U^-1
   if (p->f32) launch_to_float(p->uinv, p->uinv_f, mm, s);
   tstop(p);
 
@@ -623,9 +637,8 @@ void do_pass2(gprhip_problem* p, const double* ar1, double* ar2) {
   // B~ = I + sum of shard parts; R~ = chol(B~): R = R~ U is the reference's r_mat (lib/fitc_gp.ml:181)
   hipLaunchKernelGGL(add_identity_upper_kernel, dim3((mp + 255) / 256, mp), dim3(256), 0, s, ar1, mp,
                      p->bmat);
-  potrf_upper(p, p->bmat, p->info + 1);
+  potrf_trtri(p, p->bmat, p->rinv, p->wmat, p->info + 1);
   launch_logdet(p->bmat, mp, mp, p->scal + SC_LOGDET_B, s);
-  trtri_upper(p, p->bmat, p->rinv, p->wmat);
   if (p->f32) launch_to_float(p->rinv, p->rinv_f, mm, s);
   TS* const Vstore = static_cast<TS*>(p->Vstore);
   TS* const bufA = static_cast<TS*>(p->bufA);

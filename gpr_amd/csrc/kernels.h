@@ -50,7 +50,11 @@ void launch_potrf_diag_flags(double* A, int mp, int j, double* dinv, int* info, 
 // Whole blocked factorisation A = U^T U (upper, in place; the strict lower parts of the diagonal blocks are zeroed, the
 // tiles below the diagonal untouched) + inv(U_jj) of every diagonal block in dinv [mp/128][128][128], without the
 // contraction engine: factor-only diagonal kernel, substitution panel, small-tile trailing update per 128-row step.
-void potrf_upper_blocked(hipStream_t s, double* A, int mp, double* dinv, int* info);
+// With Xinv != null the inverse of the factor, inv(U) (upper, zeros below), is produced by the same steps (an identity
+// right-hand side in the mp x mp scratch Yscratch rides along) and dinv only serves as scratch; with Xinv == null dinv
+// receives the block inverses as before.
+void potrf_upper_blocked(hipStream_t s, double* A, int mp, double* dinv, int* info, double* Yscratch = nullptr,
+                         double* Xinv = nullptr);
 void launch_zero_strict_lower(double* A, int mp, hipStream_t s);
 void launch_copy_block(const double* src, int64_t lds, double* dst, int64_t ldd, int rows, int cols,
                        hipStream_t s);

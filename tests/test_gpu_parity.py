@@ -1480,3 +1480,9 @@ def test_diagonal_block_harness():
     assert [int(r[0]) for r in rows] == [128, 384, 1024, 2048, 4096], out.stdout[-2000:]
     for _, info, ea, ed in rows:
         assert int(info) == 0 and float(ea) < 1e-13 and float(ed) < 1e-10
+    # ... and with the identity carried along as right-hand side: the same factor, U X = I, X upper triangular
+    inv = re.findall(r"blocked potrf\+inverse m=(\d+): \S+ us  factor differs by (\S+)  max \|U X - I\| = (\S+)  "
+                     r"max \|strict lower of X\| = (\S+)", out.stdout)
+    assert [int(r[0]) for r in inv] == [128, 384, 1024, 2048, 4096], out.stdout[-2000:]
+    for _, eu, ei, el in inv:
+        assert float(eu) == 0.0 and float(ei) < 1e-10 and float(el) == 0.0
