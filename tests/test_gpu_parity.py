@@ -687,6 +687,94 @@ def test_golden_posterior(name):
     p.close()
 
 
+def _random_posterior_case(seed):
+    """Posterior paths at a random shape: prediction (means, variances), both covariance families, the covariance
+    sampler, training statistics, against the oracle; iso and Cov_se_fat with random option sets; ragged chunks."""
+    rng = np.random.default_rng(7000 + seed)
+    iso = seed % 2 == 0
+    n = int(rng.integers(50, 3000))
+    m = int(rng.integers(3, 300))
+    d = int(rng.choice([1, 2, 3, 5, 8, 13]))
+    nt = int(rng.integers(1, 400))
+    s2 = float(10.0 ** rng.uniform(-2, 0))
+    chunk_rows = int(rng.choice([0, 128, 256, 1024]))
+    if iso:
+        X, y, Z = synth(7100 + seed, n, min(m, n), d)
+        if m > n:
+            Z = np.asfortranarray(np.hstack([Z, rng.normal(size=(d, m - n))]))
+        Xt = np.asfortranarray(rng.normal(size=(d, nt)))
+        k = O.SeIsoKernel(0.5 * np.log(d) + rng.uniform(-0.3, 0.3), rng.uniform(-0.5, 0.5))
+        p = gpr_amd.Problem(gpr_amd.COV_SE_ISO, n, d, d, m, chunk_rows=chunk_rows)
+        args = dict(log_ell=k.log_ell, log_sf2=k.log_sf2)
+    else:
+        D = d + int(rng.integers(0, 4))
+        X = np.asfortranarray(rng.normal(size=(D, n)))
+        Xt = np.asfortranarray(rng.normal(size=(D, nt)))
+        y = np.sin(X.sum(0)) + 0.1 * rng.normal(size=n)
+        P = np.asfortranarray(rng.normal(size=(D, d)) / np.sqrt(D * d)) if (D != d or rng.integers(0, 2)) else None
+        Z = np.asfortranarray(rng.normal(size=(d, m)) * 0.5)
+        het = rng.uniform(-6, -3, size=m) if rng.integers(0, 2) else None
+        ms = rng.uniform(-0.5, 0.5, size=(d, m)) if rng.integers(0, 3) == 0 else None
+        k = O.SeFatKernel(d, rng.uniform(-0.5, 0.5), P, het, ms)
+        p = gpr_amd.Problem(gpr_amd.COV_SE_FAT, n, D, d, m, chunk_rows=chunk_rows)
+        args = dict(log_sf2=k.log_sf2)
+        if P is not None:
+            args["tproj"] = P
+        if het is not None:
+            args["log_hetero_skedasticity"] = het
+        if ms is not None:
+            args["log_multiscales_m05"] = np.asfortranarray(ms)
+    ref = O.evaluate(k, Z, X, y, s2, want_grad=False, keep=True)
+    p.set_inputs(X)
+    p.set_targets(y)
+    ev = p.eval(sigma2=s2, inducing=Z, want_grad=False, **args)
+    assert abs(ev.l - ref["l"]) <= TOL_L * max(1.0, abs(ref["l"]))
+    means, var = p.predict(Xt, predictive=False)
+    mref = O.predict_means(k, Z, ref["coeffs"], Xt)
+    vref = O.predict_variances(k, Z, ref["model"], Xt, predictive=False)
+    scale_m = max(np.max(np.abs(mref)), 1e-3)
+    assert np.max(np.abs(means - mref)) <= 1e-7 * scale_m
+    assert np.max(np.abs(var - vref)) <= 1e-8 * max(np.max(np.abs(vref)), k.sf2)
+    ntc = min(nt, 150)
+    fitc = O.fitc_covariances(k, Z, ref["model"], Xt[:, :ntc])
+    fic = O.fic_covariances(k, Z, ref["model"], Xt[:, :ntc])
+    scale = max(np.max(np.abs(fitc)), np.max(np.abs(fic)), k.sf2)
+    cov = p.covariances(Xt[:, :ntc], kind="FITC", predictive=False)
+    assert np.max(np.abs(np.triu(cov) - fitc)) <= 1e-8 * scale
+    assert np.max(np.abs(np.triu(p.covariances(Xt[:, :ntc], kind="FIC", predictive=False)) - fic)) <= 1e-8 * scale
+    z = rng.normal(size=(ntc, 3))
+    smp = O.cov_sampler_calc(mref[:ntc], fitc, s2, predictive=True)
+    S = p.cov_samples(cov, mref[:ntc], z, add_diag=s2)
+    assert np.max(np.abs(S - O.cov_sampler_samples(smp, z))) <= 1e-7 * max(np.max(np.abs(S)), 1.0)
+    sums, tm = p.train_stats(want_means=True)
+    knm, _ = O.spec_calc_shared_cross(k, X, Z)
+    tref = knm @ ref["coeffs"]
+    assert np.max(np.abs(tm - tref)) <= 1e-7 * max(np.max(np.abs(tref)), 1e-3)
+    assert abs(sums[0] - float(np.sum((y - tref) ** 2))) <= 1e-7 * max(float(np.sum((y - tref) ** 2)), 1e-6)
+    p.close()
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_random_posterior_paths_against_oracle(seed):
+    _random_posterior_case(seed)
+
+
+def test_random_posterior_long_sweep():
+    """GPR_FUZZ_POSTERIOR="lo:hi": the same over a seed range (log: profiles/r03_fuzz_posterior.txt)."""
+    spec = os.environ.get("GPR_FUZZ_POSTERIOR")
+    if not spec:
+        pytest.skip("GPR_FUZZ_POSTERIOR not set")
+    lo, hi = (int(v) for v in spec.split(":"))
+    bad = []
+    for seed in range(lo, hi):
+        try:
+            _random_posterior_case(seed)
+        except AssertionError as e:
+            bad.append((seed, str(e)[:200]))
+    print("random posterior sweep: seeds %d..%d, %d cases, %d failures %s" % (lo, hi - 1, hi - lo, len(bad), bad))
+    assert not bad, bad
+
+
 def test_device_resident_inputs_equal_host_inputs():
     """gprhip_set_inputs_device / gprhip_set_targets_device (inputs already in HBM, point-major [n][D]) give
     bitwise the same evaluation as the host-pointer entry points (Fortran D x n)."""
