@@ -518,6 +518,10 @@ void potrf_upper_blocked(hipStream_t s, double* A, int mp, double* dinv, int* in
   // Y[j, :] <- U_jj^-T Y[j, :], update: Y[r, :] -= U[j, r]^T Y[j, :]), Y ends as U^-T and X = Y^T.  The extra tiles run
   // on compute units the latency-bound steps leave idle; the recursive-doubling inversion (eight engine launches,
   // 0.29 ms at m = 2048) and the block-inverse launch are not needed then.
+  if (Xinv && !Yscratch) {
+    set_error("gprhip: potrf_upper_blocked: the inverse needs an mp x mp scratch");
+    throw HipFail{ST_BAD_ARG};
+  }
   double* const Y = Xinv ? Yscratch : nullptr;
   if (Y) hipLaunchKernelGGL(set_identity_kernel, dim3((mp + 255) / 256, mp), dim3(256), 0, s, Y, mp);
   for (int j = 0; j < nb; ++j) {
