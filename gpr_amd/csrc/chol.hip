@@ -315,8 +315,9 @@ __global__ __launch_bounds__(256) void potrf_panel_kernel(double* __restrict__ A
 // X, read from L2 as they are (16 consecutive doubles per k).
 // ALL: every operand fragment is requested before the first MFMA (128 fragment registers, one wavefront per SIMD) -- the
 // kernel's time is launch latency plus load round trips, and left alone the scheduler keeps only five k-steps of loads
-// in flight (13 us of stalls for 3.4 us of MFMAs).  Used while a step's sub-tiles fit the chip in one round at that
-// occupancy; bigger steps run the compiler's pipelined order with four workgroups per CU.
+// in flight (13 us of stalls for 3.4 us of MFMAs).  Used for steps of up to GPRHIP_POTRF_ALL_TILES sub-tiles (768:
+// three rounds at that occupancy, measured to be as fast as or faster than the pipelined order up to there -- see
+// potrf_upper_blocked); bigger steps run the compiler's pipelined order with four workgroups per CU.
 // Workgroups beyond the symmetric part update the carried right-hand side: Y[r, c] -= X_r^T Y[j, c] for the row blocks
 // r > j and the column blocks c <= j (nsym = number of symmetric sub-tiles; Y may be null).
 template <bool ALL>
