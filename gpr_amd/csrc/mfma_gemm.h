@@ -46,6 +46,7 @@ struct GemmArgsT {
   int order = 0;         // block -> tile order of full grids (see tile_of_block)
   int ipw = 1;           // items per workgroup (set by launch_gemm: 2 for the paired order 3)
   int syrk = 0;          // set by launch_gemm: weighted TN launch with A == B and upper_only (diagonal tiles skip their lower sub-tiles)
+  int sgroup = 16;       // set by launch_gemm: slices per group of the SYRK item order (tile_of_block); 1 = slice by slice
   int dslices = 0;       // set by launch_gemm: k-slices of the diagonal tiles of such a launch (gemm_syrk_diag_slices), 0 = as kslices
   int nbatch = 1;        // independent problems of identical shape: gridDim.y, pointers advance by the strides
   int64_t batch_a = 0, batch_b = 0, batch_c = 0;
