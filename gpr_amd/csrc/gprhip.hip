@@ -155,7 +155,7 @@ struct gprhip_problem {
     return (int64_t)(nchunks - 1) * chunk + round_up(rows_of(nchunks - 1), TILE);
   }
   int ks_used = 8;
-  int64_t slice_rows = 8192;  // training points per split-K slice of the SYRK launches (4096 in the fp32-bulk mode)
+  int64_t slice_rows = 8192;  // training points per split-K slice of the SYRK launches (both precisions)
   int tile_order = 3;  // block -> tile order of the chunk GEMMs (mfma_gemm.hip tile_of_block): paired column tiles, XCD-local groups
   int grad_scalar = 0;  // GPRHIP_GRAD_SCALAR: use the scalar gradient kernel even where the MFMA one applies
   // Cov_se_fat `Proj hypers: rows of the exchange-2 column block beyond d+1, and the D x d second term
@@ -1328,7 +1328,9 @@ int gprhip_problem_create_ex(int device, int cov_kind, int precision, int64_t n,
     p->nchunks = (int)((n + chunk - 1) / chunk);
     // partial-sum buffers of the split-K SYRK launches: one m x m slice per `slice_rows` training points,
     // capped at 40 GB
-    if (p->f32) p->slice_rows = 4096;  // fp32 accumulation never runs over more than 4096 rows before the fp64 sum
+    // (fp32-bulk mode: fp32 accumulation runs over one slice before the fp64 slice sum.  Measured at config 3 against
+    // the fp64 evaluation, tools/lab10.sh: 2048 / 4096 / 8192 / 16384-row slices give the evidence to 7.4e-8 / 7.3e-8 /
+    // 5.6e-8 / 2.3e-8 and SYRK launches of 119.9 / 120.3 / 119.0 / 118.9 ms -- no reason for shorter slices than fp64's.)
     if (const char* e = getenv("GPRHIP_SLICE_ROWS")) p->slice_rows = std::max<int64_t>(1024, atoll(e));
     p->kslices = (int)std::max<int64_t>(8, std::min<int64_t>((round_up(n, p->slice_rows) / p->slice_rows + 23) / 8 * 8,
                                                               (40LL << 30) / (p->mp * (int64_t)p->mp * 8) / 8 * 8));
