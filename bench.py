@@ -304,7 +304,7 @@ def main():
         achieved = flops_per_launch / (syrk_ms * 1e-3) * 1e-12 if syrk_ms > 0 else None
         stage = {k_: float(np.mean(v_)) for k_, v_ in sorted(tim.items()) if not k_.startswith("kernel_")}
         engine_ms = sum(stage.get(k_, 0.0) for k_ in
-                        ("p1_syrk_B", "p2_syrk_W", "p1_trmm_V", "p2_trmm_Q", "p2_trmm_S", "p2_trmm_X"))
+                        ("p1_syrk_B", "p2_syrk_W", "p1_trmm_V", "p2_trmm_Q", "p2_trmm_S", "p2_trmm_X", "p2_trmm_SX"))
         cov_ms = stage.get("p1_cov")
         traffic = profile_traffic(n_local, m) if (n, m, d, world) == (1_000_000, 2048, 8, 1) else None
         first = traffic["launches"][0] if traffic and traffic["launches"] else None

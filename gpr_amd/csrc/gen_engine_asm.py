@@ -36,8 +36,9 @@ WOFF = 18304           # weights of the stage inside an operand image
 
 
 class Cfg:
-    def __init__(self, f64, op, var, diag=None):
+    def __init__(self, f64, op, var, diag=None, cont=False):
         self.f64, self.op, self.var, self.diag = f64, op, var, diag
+        self.cont = cont                    # second phase of a two-phase item: the accumulators are kept, not zeroed
         self.nkk = 4 if f64 else 8          # k-steps (of 4) per stage
         self.fw = 2 if f64 else 1           # dwords per fragment element
         self.aw = 8 if f64 else 4           # accumulator registers per 16x16 sub-tile
@@ -47,9 +48,10 @@ class Cfg:
         self.mfma = "v_mfma_f64_16x16x4_f64" if f64 else "v_mfma_f32_16x16x4_f32"
 
     def name(self):
-        return "ENGINE_LOOP_%s_%s%s%s" % ("F64" if self.f64 else "F32", self.op.upper(),
-                                          {0: "", 1: "_W", 2: "_WS"}[self.var],
-                                          {None: "", "khi": "_KHI", "klo": "_KLO", "sy": "_SY"}[self.diag])
+        return "ENGINE_LOOP_%s_%s%s%s%s" % ("F64" if self.f64 else "F32", self.op.upper(),
+                                            {0: "", 1: "_W", 2: "_WS"}[self.var],
+                                            {None: "", "khi": "_KHI", "klo": "_KLO", "sy": "_SY"}[self.diag],
+                                            "_CONT" if self.cont else "")
 
 
 def reg(base, width):
@@ -231,8 +233,9 @@ def gen(c):
     if c.b_x:
         for kk in range(1, nkk):
             emit("v_xor_b32 %s, %d, %%[addrB]" % (BX(kk), kk * (32 if c.f64 else 16)))
-    for r in range(128, 128 + 16 * aw):
-        emit("v_mov_b32 v%d, 0" % r)
+    if not c.cont:
+        for r in range(128, 128 + 16 * aw):
+            emit("v_mov_b32 v%d, 0" % r)
     # stage 0 has landed for every wave -> stage 1 into buffer 1; first fragments
     emit("s_waitcnt vmcnt(0)")
     emit("s_barrier")
@@ -307,11 +310,13 @@ def gen(c):
 def main():
     out = ["// Generated by gen_engine_asm.py -- do not edit.", ""]
     for f64 in (True, False):
-        for op, var, diag in (("nn", 0, None), ("nt", 0, None), ("tn", 0, None), ("tn", 1, None), ("tn", 2, None),
-                              ("nn", 0, "khi"), ("nt", 0, "klo"), ("tn", 1, "sy"), ("tn", 2, "sy")):
-            c = Cfg(f64, op, var, diag)
+        for op, var, diag, cont in (("nn", 0, None, False), ("nt", 0, None, False), ("tn", 0, None, False),
+                                    ("tn", 1, None, False), ("tn", 2, None, False), ("nn", 0, "khi", False),
+                                    ("nt", 0, "klo", False), ("tn", 1, "sy", False), ("tn", 2, "sy", False),
+                                    ("nt", 0, None, True), ("nt", 0, "klo", True)):
+            c = Cfg(f64, op, var, diag, cont)
             for part, lines in zip(("PRO", "MAIN"), gen(c)):
-                if diag and part == "PRO":
+                if (diag or cont) and part == "PRO":
                     continue   # same fetch as the plain variant
                 out.append("#define %s \\" % c.name().replace("LOOP", part))
                 for ln in lines:

@@ -107,6 +107,7 @@ struct gprhip_problem {
   bool have_model = false;
   bool have_factors = false;  // U^-1 / R~^-1 valid (false after a means-only gprhip_load_predictor)
   bool have_v = false;        // Vstore / r hold V = K_nm U^-1 of the current kernel and inducing points (reuse_v)
+  bool merged_x = false;      // this evaluation forms X by the two-phase product (set in pass 2)
   bool have_k = false;        // Kstore holds K_nm of the current kernel and inducing points for every chunk
   int k_resident = 1;         // GPRHIP_K_RESIDENT=0 (read at creation): never keep K_nm (ablation)
   // n x m storage: double, or float in the fp32-bulk mode (element size `esz`)
@@ -116,6 +117,8 @@ struct gprhip_problem {
   void* Kstore = nullptr;
   bool kstore_tried = false;
   float *uinv_f = nullptr, *rinv_f = nullptr;  // fp32 copies of U^-1 / R~^-1 (fp32-bulk mode)
+  double* rfinv = nullptr;   // R^-1 = U^-1 R~^-1 (R = R~ U is the reference's r_mat): B operand of the two-phase X product
+  float* rfinv_f = nullptr;
   float *is_f = nullptr, *yis_f = nullptr, *v_f = nullptr;  // fp32 copies of the SYRK row weights (fp32-bulk mode)
   int f32 = 0;
   size_t esz = 8;
@@ -183,6 +186,15 @@ template <> const float* row_weights<float>(gprhip_problem* p, const double* w, 
 template <typename TS> const TS* inv_r(const gprhip_problem* p);
 template <> const double* inv_r<double>(const gprhip_problem* p) { return p->rinv; }
 template <> const float* inv_r<float>(const gprhip_problem* p) { return p->rinv_f; }
+template <typename TS> const TS* inv_rfull(const gprhip_problem* p);
+template <> const double* inv_rfull<double>(const gprhip_problem* p) { return p->rfinv; }
+template <> const float* inv_rfull<float>(const gprhip_problem* p) { return p->rfinv_f; }
+// GPRHIP_MERGED_X (read once): 0 = X~ and X = X~ U^-T as two launches, as in rounds 1-2 (A/B runs); 1 (default) = the
+// two-phase product for shards large enough to pay for R^-1; 2 = always (parity tests at small sizes)
+static const int g_merged_x = [] {
+  const char* e = getenv("GPRHIP_MERGED_X");
+  return e ? atoi(e) : 1;
+}();
 
 void tstart(gprhip_problem* p, const char* name) {
   if (!p->timer.on) return;
@@ -658,6 +670,27 @@ void do_pass2(gprhip_problem* p, const double* ar1, double* ar2) {
   if (p->want_grad) {
     tstart(p, "inverses");
     triu_xxt(p, p->rinv, p->binv);  // B~^-1 (upper tiles)
+    // The two-phase X product (below) needs R^-1 = U^-1 R~^-1, one more m x m product on the serial part of the
+    // evaluation (0.14 ms at m = 2048, 0.8 ms at m = 4096), and saves 2.5 us per 1000 training points at m = 2048 (6 us
+    // at m = 4096): taken from 48 m training points per shard on.
+    p->merged_x = g_merged_x == 2 || (g_merged_x == 1 && p->n >= 48 * (int64_t)p->m);
+    if (p->merged_x) {
+      GemmArgs rf;  // R^-1 = U^-1 R~^-1, both upper triangular
+      rf.A = p->uinv; rf.lda = mp; rf.B = p->rinv; rf.ldb = mp; rf.C = p->rfinv; rf.ldc = mp;
+      rf.M = mp; rf.N = mp; rf.K = mp; rf.tri = TRI_BAND; rf.upper_only = 1;
+      // the corner tile's k-range is the whole of m: eight k-slices keep the launch from waiting on it
+      const int rks = (mp >= 1024 && 8 * mm * 8 <= p->slices_bytes) ? 8 : 1;
+      if (rks > 1) {
+        rf.C = static_cast<double*>(p->slices);
+        rf.kslices = rks;
+        rf.slice_stride = mm;
+        launch_gemm(OP_NN, rf, s);
+        launch_sum_slices<double>(nullptr, static_cast<double*>(p->slices), rks, mm, mp, p->rfinv, s);
+      } else {
+        launch_gemm(OP_NN, rf, s);
+      }
+      if (p->f32) launch_to_float(p->rfinv, p->rfinv_f, mm, s);
+    }
     tstop(p);
     bool derive_inducing = false;
     for (int c = 0; c < p->nchunks; ++c) {
@@ -682,23 +715,40 @@ void do_pass2(gprhip_problem* p, const double* ar1, double* ar2) {
       launch_pass2_rows(ra, s);
       launch_reduce_rows(p->rowpart, pass1_row_blocks(rows_p), 4, ar2_tail, 1, s);
       tstop(p);
-      tstart(p, "p2_trmm_S");
-      GemmArgsT<TS> sg;  // X~ = diag(is) Q' R~^-T - diag(v) V - w t~^T   (S, U_mat and the ger of :936-938, :1204-1206)
-      sg.A = bufA; sg.lda = mp; sg.B = inv_r<TS>(p); sg.ldb = mp; sg.C = bufB; sg.ldc = mp;
-      sg.M = rows_p; sg.N = mp; sg.K = mp; sg.tri = TRI_KLO_BN; sg.order = p->tile_order;
-      sg.epi_rows_a = p->is + base; sg.epi_rows_b = p->v + base; sg.epi_rows_c = p->w + base;
-      sg.epi_col = p->ttil; sg.epi_mat = V; sg.epi_ldm = mp;
-      launch_gemm(OP_NT, sg, s);
-      tstop(p);
-      tstart(p, "p2_trmm_X");
-      GemmArgsT<TS> xg;  // X = X~ U^-T
-      xg.A = bufB; xg.lda = mp; xg.B = inv_u<TS>(p); xg.ldb = mp; xg.C = bufA; xg.ldc = mp;
-      xg.M = rows_p; xg.N = mp; xg.K = mp; xg.tri = TRI_KLO_BN; xg.order = p->tile_order;
-      launch_gemm(OP_NT, xg, s);
-      tstop(p);
+      const TS* Xc;  // X of this chunk
+      if (p->merged_x) {
+        // X = diag(is) Q' R^-T - diag(v) V U^-T - w t^T  (S, U_mat and the ger of lib/fitc_gp.ml:931-939, :1204-1206) as
+        // one launch of two-phase items: acc = V U^-T, rows scaled by -v/is, acc += Q' R^-T, epilogue is*acc - w t^T --
+        // one epilogue per tile instead of two, no X~ round trip, no operand read in the epilogue
+        tstart(p, "p2_trmm_SX");
+        GemmArgsT<TS> xg;
+        xg.A = bufA; xg.lda = mp; xg.B = inv_rfull<TS>(p); xg.ldb = mp; xg.C = bufB; xg.ldc = mp;
+        xg.A2 = V; xg.B2 = inv_u<TS>(p); xg.mid_num = p->v + base; xg.mid_den = p->is + base;
+        xg.M = rows_p; xg.N = mp; xg.K = mp; xg.tri = TRI_KLO_BN; xg.order = p->tile_order;
+        xg.epi_rows_a = p->is + base; xg.epi_rows_c = p->w + base; xg.epi_col = p->tvec;
+        launch_gemm(OP_NT, xg, s);
+        tstop(p);
+        Xc = bufB;
+      } else {
+        tstart(p, "p2_trmm_S");
+        GemmArgsT<TS> sg;  // X~ = diag(is) Q' R~^-T - diag(v) V - w t~^T   (S, U_mat and the ger of :936-938, :1204-1206)
+        sg.A = bufA; sg.lda = mp; sg.B = inv_r<TS>(p); sg.ldb = mp; sg.C = bufB; sg.ldc = mp;
+        sg.M = rows_p; sg.N = mp; sg.K = mp; sg.tri = TRI_KLO_BN; sg.order = p->tile_order;
+        sg.epi_rows_a = p->is + base; sg.epi_rows_b = p->v + base; sg.epi_rows_c = p->w + base;
+        sg.epi_col = p->ttil; sg.epi_mat = V; sg.epi_ldm = mp;
+        launch_gemm(OP_NT, sg, s);
+        tstop(p);
+        tstart(p, "p2_trmm_X");
+        GemmArgsT<TS> xg;  // X = X~ U^-T
+        xg.A = bufB; xg.lda = mp; xg.B = inv_u<TS>(p); xg.ldb = mp; xg.C = bufA; xg.ldc = mp;
+        xg.M = rows_p; xg.N = mp; xg.K = mp; xg.tri = TRI_KLO_BN; xg.order = p->tile_order;
+        launch_gemm(OP_NT, xg, s);
+        tstop(p);
+        Xc = bufA;
+      }
       tstart(p, "p2_grad");
       GradArgs<TS> ga;
-      ga.X = bufA; ga.pts = p->pts() + base * p->d; ga.Z = p->Z;
+      ga.X = Xc; ga.pts = p->pts() + base * p->d; ga.Z = p->Z;
       ga.rows = (int)rows; ga.rows_p = rows_p; ga.m = p->m; ga.mp = mp; ga.d = p->d;
       ga.log_sf2 = p->cp.log_sf2; ga.inv_ell2_05 = p->cp.inv_ell2_05;
       ga.colpart = p->colpart; ga.scalpart = p->scalpart;
@@ -719,9 +769,10 @@ void do_pass2(gprhip_problem* p, const double* ar1, double* ar2) {
       // forces the scalar one (parity tests run both)
       int nbx = p->grad_scalar ? 0 : grad_mfma_col_blocks(ga);
       if (p->d > 64 || ga.D > 64) {
-        // wide points: K of the chunk is rebuilt into the buffer X~ has left, and E = X .* K read from memory
-        cov_chunk<TS>(p, c, bufB);
-        launch_grad_wide(ga, static_cast<const TS*>(bufB), s);
+        // wide points: K of the chunk is rebuilt into the chunk buffer that does not hold X, and E = X .* K read from memory
+        TS* const Kw = (Xc == bufA) ? bufB : bufA;
+        cov_chunk<TS>(p, c, Kw);
+        launch_grad_wide(ga, static_cast<const TS*>(Kw), s);
         nbx = (mp + 255) / 256;
       } else if (nbx > 0) {
         launch_grad_mfma(ga, s);
@@ -1359,6 +1410,7 @@ int gprhip_problem_create_ex(int device, int cov_kind, int precision, int64_t n,
     p->km = p->alloc<double>(mm); p->kj = p->alloc<double>(mm); p->umat = p->alloc<double>(mm);
     p->uinv = p->alloc<double>(mm); p->bmat = p->alloc<double>(mm);
     p->rinv = p->alloc<double>(mm); p->binv = p->alloc<double>(mm); p->wtil = p->alloc<double>(mm);
+    p->rfinv = p->alloc<double>(mm);
     p->wmat = p->alloc<double>(mm);
     p->tmp = p->alloc<double>((int64_t)mp * TILE);
     p->dinv = p->alloc<double>((int64_t)(mp / TILE) * TILE * TILE);
@@ -1376,6 +1428,7 @@ int gprhip_problem_create_ex(int device, int cov_kind, int precision, int64_t n,
     if (p->f32) {
       p->uinv_f = p->alloc<float>(mm);
       p->rinv_f = p->alloc<float>(mm);
+      p->rfinv_f = p->alloc<float>(mm);
       p->is_f = p->alloc<float>(npad); p->yis_f = p->alloc<float>(npad); p->v_f = p->alloc<float>(npad);
     }
     p->slices_bytes = (int64_t)p->kslices * mm * p->esz;

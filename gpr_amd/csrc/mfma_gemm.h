@@ -52,7 +52,16 @@ struct GemmArgsT {
   int64_t batch_a = 0, batch_b = 0, batch_c = 0;
   int kslices = 1;       // split K over the grid; slice z writes C + z*slice_stride
   int64_t slice_stride = 0;
+  // optional first phase of an OP_NT item (two products into one accumulator tile, one epilogue): with A2 != null the
+  // tile is   acc = A2 B2^T;   acc[i][:] *= -mid_num[i] / mid_den[i]  (0 where mid_den[i] == 0);   acc += A B^T
+  // over the same triangular k-range; A2 / B2 share the leading dimensions (and alignment) of A / B.
+  // (X = diag(is) Q' R^-T - diag(v) V U^-T - w t^T of the gradient pass in one launch: lib/fitc_gp.ml:931-939, :1204-1206)
+  const T* A2 = nullptr;
+  const T* B2 = nullptr;
+  const double* mid_num = nullptr;
+  const double* mid_den = nullptr;
   // optional fused epilogue (when epi_rows_a != null): C[i][j] = ra[i]*acc - rb[i]*M[i][j] - rc[i]*cv[j]
+  // (epi_mat == null: no M term, C[i][j] = ra[i]*acc - rc[i]*cv[j])
   const double* epi_rows_a = nullptr;
   const double* epi_rows_b = nullptr;
   const double* epi_rows_c = nullptr;

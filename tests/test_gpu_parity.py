@@ -1266,6 +1266,25 @@ def test_degenerate_and_tile_boundary_shapes(n, m, d):
         assert np.max(np.abs(ev.coeffs - ref["coeffs"])) <= TOL_COEFF * max(1.0, np.max(np.abs(ref["coeffs"])))
 
 
+@pytest.mark.parametrize("name", ["iso_c1", "iso_ragged", "iso_c1_var", "fat_proj", "fat_all", "illcond_c1_hi", "illcond_small_lo"])
+def test_two_phase_and_two_launch_x_products_agree(name, monkeypatch):
+    """X = diag(is) Q' R^-T - diag(v) V U^-T - w t^T comes from one launch of two-phase engine items on large shards
+    (from 48 m training points on) and from X~, X = X~ U^-T otherwise; GPRHIP_MERGED_X=2 / 0 force either.  Both meet the
+    fixture's tolerance (the ill-conditioned ones included) and agree with each other."""
+    g = load_golden(name)
+    tol = 1e-8 if name.startswith("illcond") else TOL_GRAD
+    res = {}
+    for mode in ("2", "0"):
+        monkeypatch.setenv("GPRHIP_MERGED_X", mode)
+        p = _problem_for(g, chunk_rows=512)
+        res[mode] = _eval_golden(p, g)
+        p.close()
+        assert relinf(res[mode].grad, g["grad"]) <= tol, mode
+        assert abs(res[mode].dl_dsigma2 - g["dl_dsigma2"]) <= TOL_DS2 * abs(g["dl_dsigma2"])
+    assert res["2"].l == res["0"].l
+    assert relinf(res["2"].grad, res["0"].grad) <= (1e-8 if name.startswith("illcond") else 1e-10)
+
+
 def test_inputs_with_a_large_common_offset():
     """The matrix-core gradient kernel expands |p - z|^2 around the centroid of the inducing points: data far from
     the origin (offset 1e4 at unit spread) must not cost digits against the oracle's direct differences."""

@@ -192,6 +192,53 @@ int check_f32(GemmOp op, int M, int N, int K, int tri, bool scale, bool epi) {
   return ok ? 0 : 1;
 }
 
+// Two-phase NT item with the M-less fused epilogue (the X product of the gradient pass):
+//   C[i][j] = ra[i] * (A B^T - (num[i] / den[i]) A2 B2^T)[i][j] - rc[i] * cv[j],   rows with den == 0 take no A2 term
+template <typename T>
+int check_two_phase(int M, int N, int K) {
+  std::vector<T> hA((int64_t)M * K), hA2((int64_t)M * K), hB((int64_t)N * K), hB2((int64_t)N * K);
+  std::vector<double> ra(M), rc(M), num(M), den(M), cv(N);
+  for (auto& v : hA) v = (T)frand();
+  for (auto& v : hA2) v = (T)frand();
+  for (auto& v : hB) v = (T)frand();
+  for (auto& v : hB2) v = (T)frand();
+  for (int j = 0; j < N; ++j) for (int k = 0; k < K; ++k) if (k < j) hB[(int64_t)j * K + k] = hB2[(int64_t)j * K + k] = 0;
+  for (int i = 0; i < M; ++i) { ra[i] = frand(); rc[i] = frand(); num[i] = frand(); den[i] = (i % 37 == 5) ? 0.0 : 0.5 + fabs(frand()); }
+  for (auto& v : cv) v = frand();
+  T *dA, *dA2, *dB, *dB2, *dC; double *dra, *drc, *dnum, *dden, *dcv, *dR1, *dR2;
+  hipMalloc(&dA, hA.size() * sizeof(T)); hipMalloc(&dA2, hA.size() * sizeof(T)); hipMalloc(&dB, hB.size() * sizeof(T));
+  hipMalloc(&dB2, hB.size() * sizeof(T)); hipMalloc(&dC, (int64_t)M * N * sizeof(T));
+  hipMalloc(&dra, M * 8); hipMalloc(&drc, M * 8); hipMalloc(&dnum, M * 8); hipMalloc(&dden, M * 8); hipMalloc(&dcv, N * 8);
+  hipMalloc(&dR1, (int64_t)M * N * 8); hipMalloc(&dR2, (int64_t)M * N * 8);
+  hipMemcpy(dA, hA.data(), hA.size() * sizeof(T), hipMemcpyHostToDevice); hipMemcpy(dA2, hA2.data(), hA.size() * sizeof(T), hipMemcpyHostToDevice);
+  hipMemcpy(dB, hB.data(), hB.size() * sizeof(T), hipMemcpyHostToDevice); hipMemcpy(dB2, hB2.data(), hB.size() * sizeof(T), hipMemcpyHostToDevice);
+  hipMemcpy(dra, ra.data(), M * 8, hipMemcpyHostToDevice); hipMemcpy(drc, rc.data(), M * 8, hipMemcpyHostToDevice);
+  hipMemcpy(dnum, num.data(), M * 8, hipMemcpyHostToDevice); hipMemcpy(dden, den.data(), M * 8, hipMemcpyHostToDevice);
+  hipMemcpy(dcv, cv.data(), N * 8, hipMemcpyHostToDevice);
+  hipMemset(dC, 0xff, (int64_t)M * N * sizeof(T));
+  GemmArgsT<T> g; g.A = dA; g.lda = K; g.B = dB; g.ldb = K; g.C = dC; g.ldc = N; g.M = M; g.N = N; g.K = K; g.tri = TRI_KLO_BN;
+  g.order = getenv("ORD") ? atoi(getenv("ORD")) : 0;
+  g.A2 = dA2; g.B2 = dB2; g.mid_num = dnum; g.mid_den = dden;
+  g.epi_rows_a = dra; g.epi_rows_c = drc; g.epi_col = dcv;
+  launch_gemm(OP_NT, g, 0);
+  naive_t<T><<<dim3((N + 255) / 256, M), 256>>>(OP_NT, dA, K, dB, K, dR1, N, M, N, K, nullptr);
+  naive_t<T><<<dim3((N + 255) / 256, M), 256>>>(OP_NT, dA2, K, dB2, K, dR2, N, M, N, K, nullptr);
+  std::vector<T> hC((int64_t)M * N); std::vector<double> h1((int64_t)M * N), h2((int64_t)M * N);
+  hipMemcpy(hC.data(), dC, hC.size() * sizeof(T), hipMemcpyDeviceToHost);
+  hipMemcpy(h1.data(), dR1, h1.size() * 8, hipMemcpyDeviceToHost); hipMemcpy(h2.data(), dR2, h2.size() * 8, hipMemcpyDeviceToHost);
+  double maxerr = 0;
+  for (int i = 0; i < M; ++i) for (int j = 0; j < N; ++j) {
+    const double f = den[i] != 0.0 ? num[i] / den[i] : 0.0;
+    const double ref = ra[i] * (h1[(int64_t)i * N + j] - f * h2[(int64_t)i * N + j]) - rc[i] * cv[j];
+    maxerr = std::max(maxerr, fabs((double)hC[(int64_t)i * N + j] - ref));
+  }
+  const bool ok = maxerr < (sizeof(T) == 8 ? 1e-10 : 4e-6) * K;
+  printf("check two-phase %s M=%d N=%d K=%d maxerr=%.3e %s\n", sizeof(T) == 8 ? "f64" : "f32", M, N, K, maxerr, ok ? "OK" : "FAIL");
+  hipFree(dA); hipFree(dA2); hipFree(dB); hipFree(dB2); hipFree(dC); hipFree(dra); hipFree(drc); hipFree(dnum); hipFree(dden);
+  hipFree(dcv); hipFree(dR1); hipFree(dR2);
+  return ok ? 0 : 1;
+}
+
 void timeit_f32(GemmOp op, int M, int N, int K, int tri, int upper, int kslices, const char* name) {
   int64_t ar = op == OP_TN ? K : M, ac = op == OP_TN ? M : K;
   int64_t br = op == OP_NT ? N : K, bc = op == OP_NT ? K : N;
@@ -373,6 +420,8 @@ int main() {
     bad += check_f32(OP_NT, 8192, 512, 512, TRI_KLO_BN, false, true);
     bad += check_syrk_cs<float>(256, 1056, 8);
     bad += check_syrk_cs<float>(384, 4096 + 96, 3);
+    bad += check_two_phase<float>(384, 256, 256);
+    bad += check_two_phase<float>(8192, 512, 512);
     printf("f32 checks failed: %d\n", bad);
     timeit_f32(OP_NN, 8192, 8192, 8192, TRI_NONE, 0, 1, "square NN 8192");
     timeit_f32(OP_NN, 32768, 4096, 4096, TRI_KHI_BN, 0, 1, "K*Uinv triu m4096");
@@ -402,6 +451,9 @@ int main() {
   }
   bad += check_syrk_cs<double>(256, 1040, 8);
   bad += check_syrk_cs<double>(384, 4096 + 48, 3);
+  bad += check_two_phase<double>(384, 256, 256);
+  bad += check_two_phase<double>(8192, 512, 512);    // the paired order
+  bad += check_two_phase<double>(32768, 1024, 1024);
   printf("checks failed: %d\n", bad);
   timeit(OP_NN, 8192, 8192, 8192, TRI_NONE, 0, 1, "square NN 8192");
   timeit(OP_NN, 32768, 2048, 2048, TRI_NONE, 0, 1, "K*Uinv full");
