@@ -386,3 +386,58 @@ def test_oracle_against_an_80_bit_evaluation(n, m, d, log_ell):
     assert abs(ref["l"] - l) <= 1e-11 * abs(l)
     # measured: l 4e-14 / 2e-13 / 1e-15, coefficients 1.0e-9 / 1.1e-9 / 1.8e-13
     assert np.max(np.abs(ref["coeffs"] - t)) <= (1e-8 if d <= 3 else 1e-10) * np.max(np.abs(t))
+
+
+def test_oracle_gradient_against_80_bit_central_differences():
+    """Selected entries of the oracle's gradient (length scale, amplitude, noise, inducing coordinates: the reference's
+    per-hyper trace formulas, lib/fitc_gp.ml:943-1021) against central differences of the 80-bit evidence: with
+    h = 1e-6 in long double the difference quotient is good to ~1e-11 of the gradient's scale, five orders below what
+    an fp64 difference quotient resolves."""
+    from tests.util import longdouble_fitc, synth
+    n, m, d = 500, 40, 3
+    X, y, Z = synth(77, n, m, d)
+    le, lsf, s2 = 0.45, -0.1, 0.08
+    ref = O.evaluate(O.SeIsoKernel(le, lsf), Z, X, y, s2)
+    LD = np.longdouble
+    h = LD(1e-6)
+
+    def l_of(dle=0, dlsf=0, ds2=0, dz=None):
+        Zp = np.asarray(Z, LD).copy()
+        if dz is not None:
+            Zp[dz[0], dz[1]] += dz[2]
+        # (longdouble_fitc converts its inputs itself; pass longdouble scalars through)
+        return _ld_l(X, y, Zp, LD(le) + dle, LD(lsf) + dlsf, LD(s2) + ds2)
+
+    def _ld_l(X, y, Zp, a, b, c):
+        import tests.util as U
+        Xl, yl = np.asarray(X, LD), np.asarray(y, LD)
+        ie, sf2 = np.exp(LD(-2) * a), np.exp(b)
+
+        def cov(A, B):
+            return sf2 * np.exp(LD(-0.5) * ie * ((A.T[:, None, :] - B.T[None, :, :]) ** 2).sum(-1))
+        Um = U._ld_chol_upper(cov(Zp, Zp) + LD(1e-6) * np.eye(m, dtype=LD))
+        K = cov(Xl, Zp)
+        V = np.zeros_like(K)
+        for j in range(m):
+            V[:, j] = (K[:, j] - V[:, :j] @ Um[:j, j]) / Um[j, j]
+        s = sf2 - (V * V).sum(1) + c
+        R = U._ld_chol_upper(np.eye(m, dtype=LD) + V.T @ (V / s[:, None]))
+        cc = V.T @ (yl / s)
+        bb = np.zeros_like(cc)
+        for i in range(m):
+            bb[i] = (cc[i] - np.dot(R[:i, i], bb[:i])) / R[i, i]
+        return (LD(-0.5) * (2 * np.sum(np.log(np.diag(R))) + np.sum(np.log(s)) + n * np.log(2 * LD(np.pi)))
+                - LD(0.5) * (np.dot(yl, yl / s) - np.dot(bb, bb)))
+
+    l0, _ = longdouble_fitc(X, y, Z, le, lsf, s2)
+    assert abs(float(l_of()) - l0) <= 1e-15 * abs(l0)
+    scale = np.max(np.abs(ref["grad"]))
+    g_le = float((l_of(dle=h) - l_of(dle=-h)) / (2 * h))
+    g_sf = float((l_of(dlsf=h) - l_of(dlsf=-h)) / (2 * h))
+    g_s2 = float((l_of(ds2=h) - l_of(ds2=-h)) / (2 * h))
+    assert abs(ref["grad"][0] - g_le) <= 1e-9 * scale          # Hyper.get_all order: Log_ell, Log_sf2, inducing ...
+    assert abs(ref["grad"][1] - g_sf) <= 1e-9 * scale
+    assert abs(ref["dl_dsigma2"] - g_s2) <= 1e-9 * max(abs(g_s2), 1.0)
+    for ind, dim in ((0, 0), (7, 2), (39, 1)):                 # Inducing_hyper {ind; dim}: index 2 + ind * d + dim
+        g = float((l_of(dz=(dim, ind, h)) - l_of(dz=(dim, ind, -h))) / (2 * h))
+        assert abs(ref["grad"][2 + ind * d + dim] - g) <= 1e-9 * scale, (ind, dim)
