@@ -441,3 +441,52 @@ def test_oracle_gradient_against_80_bit_central_differences():
     for ind, dim in ((0, 0), (7, 2), (39, 1)):                 # Inducing_hyper {ind; dim}: index 2 + ind * d + dim
         g = float((l_of(dz=(dim, ind, h)) - l_of(dz=(dim, ind, -h))) / (2 * h))
         assert abs(ref["grad"][2 + ind * d + dim] - g) <= 1e-9 * scale, (ind, dim)
+
+
+def test_oracle_fat_gradient_against_80_bit_central_differences():
+    """Cov_se_fat with projection + heteroskedastic noise + multiscales: one entry of every hyper family of the oracle's
+    gradient (Log_sf2, Inducing_hyper, Proj, Log_hetero_skedasticity, Log_multiscale_m05: the derivative formulas of
+    lib/cov_se_fat.ml:418-641 through lib/fitc_gp.ml:943-1021) against central differences of the covariance *values*
+    evaluated in 80-bit arithmetic (tests/util.py::longdouble_fat_evidence) -- the derivative code is not involved in
+    the reference value, and h = 1e-6 in long double resolves ~1e-10 of the gradient's scale."""
+    from tests.util import longdouble_fat_evidence
+    LD = np.longdouble
+    rng = np.random.default_rng(21)
+    n, m, D, d = 400, 30, 4, 2
+    X = np.asfortranarray(rng.normal(size=(D, n)))
+    y = np.sin(X.sum(0)) + 0.1 * rng.normal(size=n)
+    P = np.asfortranarray(rng.normal(size=(D, d)) / np.sqrt(D * d))
+    Z = np.asfortranarray((P.T @ X)[:, :m] + 0.05 * rng.normal(size=(d, m)))
+    het = rng.uniform(-5, -3, size=m)
+    lms = np.asfortranarray(rng.uniform(-0.5, 0.5, size=(d, m)))
+    lsf, s2 = 0.15, 0.06
+    k = O.SeFatKernel(d, lsf, P, het, lms)
+    ref = O.evaluate(k, Z, X, y, s2)
+    hyp = O.se_fat_hypers(k, m)
+    assert len(hyp) == ref["grad"].shape[0]
+    l0 = longdouble_fat_evidence(X, y, Z, lsf, s2, P, het, lms)
+    assert abs(float(l0) - ref["l"]) <= 1e-11 * abs(ref["l"])
+    h = LD(1e-6)
+    scale = np.max(np.abs(ref["grad"]))
+
+    def fd(**kw):
+        def ev(sign):
+            a = dict(Z=np.asarray(Z, LD).copy(), lsf=LD(lsf), s2=LD(s2), P=np.asarray(P, LD).copy(),
+                     het=np.asarray(het, LD).copy(), lms=np.asarray(lms, LD).copy())
+            for key, idx in kw.items():
+                if idx is None:
+                    a[key] = a[key] + sign * h
+                else:
+                    a[key][idx] += sign * h
+            return longdouble_fat_evidence(X, y, a["Z"], a["lsf"], a["s2"], a["P"], a["het"], a["lms"])
+        return float((ev(1) - ev(-1)) / (2 * h))
+
+    checks = [(("log_sf2",), fd(lsf=None)),
+              (("inducing", 5, 2), fd(Z=(1, 4))),            # hyper indices are 1-based, Fortran (dim, ind) storage
+              (("proj", 3, 1), fd(P=(2, 0))),
+              (("log_hetero", 11), fd(het=(10,))),
+              (("log_multiscale", 7, 2), fd(lms=(1, 6)))]
+    for name, g in checks:
+        got = ref["grad"][hyp.index(name)]
+        assert abs(got - g) <= 1e-8 * scale, (name, got, g)
+    assert abs(ref["dl_dsigma2"] - fd(s2=None)) <= 1e-8 * max(1.0, abs(ref["dl_dsigma2"]))

@@ -100,3 +100,47 @@ def longdouble_fitc(X, y, Z, log_ell, log_sf2, sigma2, jitter=1e-6):
     l = (LD(-0.5) * (2 * np.sum(np.log(np.diag(R))) + np.sum(np.log(s)) + n * np.log(2 * LD(np.pi)))
          - LD(0.5) * (np.dot(yl, yl / s) - np.dot(b, b)))
     return float(l), t.astype(np.float64)
+
+
+def longdouble_fat_evidence(X, y, Z, log_sf2, sigma2, tproj=None, log_hetero=None, log_multiscales_m05=None, jitter=1e-6):
+    """FITC log evidence of Cov_se_fat in numpy longdouble (all inputs may be longdouble arrays): values only --
+    k(p, z_c) = sf2 exp(-1/2 sum_k [(p_k - z_kc)^2 / ms_kc + log ms_kc]) with p = tproj^T x, ms = exp(log_ms) + 1/2
+    (1 without multiscales); K_m off-diagonal with scale ms_kr + ms_kc - 1, diagonal sf2 exp(-1/2 sum_k log(2 ms_kc - 1))
+    + exp(log_hetero_c) + jitter  (lib/cov_se_fat.ml:62-75, :85-142, :224-252).  Used to difference numerically."""
+    LD = np.longdouble
+    Xl, Zl, yl = np.asarray(X, LD), np.asarray(Z, LD), np.asarray(y, LD)
+    d, m = Zl.shape
+    n = Xl.shape[1]
+    lsf = LD(log_sf2)
+    P = Xl if tproj is None else np.asarray(tproj, LD).T @ Xl
+    ms = None if log_multiscales_m05 is None else np.exp(np.asarray(log_multiscales_m05, LD)) + LD(0.5)
+    acc = np.zeros((n, m), LD)
+    for k in range(d):
+        diff = P[k, :][:, None] - Zl[k, :][None, :]
+        acc += diff * diff if ms is None else diff * (diff / ms[k, :][None, :]) + np.log(ms[k, :][None, :])
+    K = np.exp(lsf - LD(0.5) * acc)
+    accm = np.zeros((m, m), LD)
+    for k in range(d):
+        diff = Zl[k, :][:, None] - Zl[k, :][None, :]
+        if ms is None:
+            accm += diff * diff
+        else:
+            sc = ms[k, :][:, None] + ms[k, :][None, :] - LD(1)
+            accm += diff * (diff / sc) + np.log(sc)
+    Km = np.exp(lsf - LD(0.5) * accm)
+    dg = np.full(m, np.exp(lsf)) if ms is None else np.exp(lsf - LD(0.5) * np.log(2 * ms - 1).sum(0))
+    if log_hetero is not None:
+        dg = dg + np.exp(np.asarray(log_hetero, LD))
+    Km[np.diag_indices(m)] = dg + LD(jitter)
+    U = _ld_chol_upper(Km)
+    V = np.zeros_like(K)
+    for j in range(m):
+        V[:, j] = (K[:, j] - V[:, :j] @ U[:j, j]) / U[j, j]
+    s = np.exp(lsf) - (V * V).sum(1) + LD(sigma2)          # calc_diag = sf2 (lib/cov_se_fat.ml:222)
+    R = _ld_chol_upper(np.eye(m, dtype=LD) + V.T @ (V / s[:, None]))
+    c = V.T @ (yl / s)
+    b = np.zeros_like(c)
+    for i in range(m):
+        b[i] = (c[i] - np.dot(R[:i, i], b[:i])) / R[i, i]
+    return (LD(-0.5) * (2 * np.sum(np.log(np.diag(R))) + np.sum(np.log(s)) + n * np.log(2 * LD(np.pi)))
+            - LD(0.5) * (np.dot(yl, yl / s) - np.dot(b, b)))
