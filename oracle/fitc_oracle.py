@@ -21,6 +21,9 @@ The oracle is pinned instead by (see tests/test_oracle.py):
   * the algebraic identity  l1+l2 == dense textbook FITC log-likelihood,
   * central finite differences of that dense likelihood for every hyper,
   * an mpmath 50-digit evaluation at tiny n,
+  * 80-bit (x87 long double) evaluations of the textbook formulas at n ~ 1000 (tests/util.py::longdouble_fitc,
+    longdouble_fat_evidence): evidence, mean coefficients, and -- by central differences of the 80-bit evidence --
+    gradient entries of every hyper family of both kernels (tests/test_oracle.py::test_oracle_*80_bit*),
   * the formulas of the reference's Octave cross-check test/oct.m:88-180,
   * the reference's own gradient self-test recipe (lib/fitc_gp.ml:1223-1462).
 
