@@ -1295,14 +1295,19 @@ def test_mean_coefficients_against_an_80_bit_evaluation(n, m, d, log_ell, tol):
     few dimensions on the device path is at or below the oracle's own distance from the 80-bit values (1e-9 .. 1e-14)."""
     from tests.util import longdouble_fitc
     X, y, Z = synth(5000 + n, n, m, d)
-    l, t = longdouble_fitc(X, y, Z, log_ell, 0.1, 0.05)
+    Xt = np.asfortranarray(np.random.default_rng(6).normal(size=(d, 200)))
+    l, t, mean, var = longdouble_fitc(X, y, Z, log_ell, 0.1, 0.05, Xt=Xt)
     p = gpr_amd.Problem(gpr_amd.COV_SE_ISO, n, d, d, m, chunk_rows=1024)
     p.set_inputs(X)
     p.set_targets(y)
     ev = p.eval(log_ell=log_ell, log_sf2=0.1, sigma2=0.05, inducing=Z, want_grad=False)
+    dmean, dvar = p.predict(Xt, predictive=False)
     p.close()
     assert abs(ev.l - l) <= 1e-10 * abs(l)
     assert np.max(np.abs(ev.coeffs - t)) <= tol * np.max(np.abs(t))
+    # posterior means and variances at new inputs against the same 80-bit evaluation
+    assert np.max(np.abs(dmean - mean)) <= max(tol, 1e-9) * max(np.max(np.abs(mean)), 1e-3)
+    assert np.max(np.abs(dvar - var)) <= 1e-7 * np.exp(0.1)
 
 
 def test_inputs_with_a_large_common_offset():

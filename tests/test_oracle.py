@@ -382,8 +382,13 @@ def test_oracle_against_an_80_bit_evaluation(n, m, d, log_ell):
     X, y, Z = synth(900 + n, n, m, d)
     k = O.SeIsoKernel(log_ell, 0.2)
     ref = O.evaluate(k, Z, X, y, 0.07, want_grad=False)
-    l, t = longdouble_fitc(X, y, Z, log_ell, 0.2, 0.07)
+    Xt = np.asfortranarray(np.random.default_rng(5).normal(size=(d, 64)))
+    ref = O.evaluate(k, Z, X, y, 0.07, want_grad=False, keep=True)
+    l, t, mean, var = longdouble_fitc(X, y, Z, log_ell, 0.2, 0.07, Xt=Xt)
     assert abs(ref["l"] - l) <= 1e-11 * abs(l)
+    # posterior at new inputs (Means.calc / Variances.calc): measured 1e-10 .. 1e-14 / 1e-9 .. 1e-15
+    assert np.max(np.abs(O.predict_means(k, Z, ref["coeffs"], Xt) - mean)) <= 1e-9 * max(np.max(np.abs(mean)), 1e-3)
+    assert np.max(np.abs(O.predict_variances(k, Z, ref["model"], Xt, predictive=False) - var)) <= 1e-8 * k.sf2
     # measured: l 4e-14 / 2e-13 / 1e-15, coefficients 1.0e-9 / 1.1e-9 / 1.8e-13
     assert np.max(np.abs(ref["coeffs"] - t)) <= (1e-8 if d <= 3 else 1e-10) * np.max(np.abs(t))
 

@@ -67,8 +67,9 @@ def _ld_chol_upper(A):
     return U
 
 
-def longdouble_fitc(X, y, Z, log_ell, log_sf2, sigma2, jitter=1e-6):
-    """Returns (l, t) in float64 from an evaluation in numpy longdouble: U = chol(K_m + jitter I), V = K_nm U^-1,
+def longdouble_fitc(X, y, Z, log_ell, log_sf2, sigma2, jitter=1e-6, Xt=None):
+    """Returns (l, t) in float64 -- with test inputs Xt also the posterior means K_tm t and variances
+    sf2 - |K_tm U^-1|^2 + |K_tm R^-1|^2, R = R~ U (lib/fitc_gp.ml:418-425, :498-518) -- from an evaluation in numpy longdouble: U = chol(K_m + jitter I), V = K_nm U^-1,
     s = sf2 - |V_i|^2 + sigma2, B~ = I + V^T S^-1 V = R~^T R~, t = U^-1 R~^-1 R~^-T V^T (y / s),
     l = -1/2 (log|B~| + sum log s + n log 2 pi) - 1/2 (y^T S^-1 y - |R~^-T V^T (y/s)|^2)."""
     LD = np.longdouble
@@ -99,7 +100,17 @@ def longdouble_fitc(X, y, Z, log_ell, log_sf2, sigma2, jitter=1e-6):
         t[i] = (tt[i] - np.dot(U[i, i + 1:], t[i + 1:])) / U[i, i]
     l = (LD(-0.5) * (2 * np.sum(np.log(np.diag(R))) + np.sum(np.log(s)) + n * np.log(2 * LD(np.pi)))
          - LD(0.5) * (np.dot(yl, yl / s) - np.dot(b, b)))
-    return float(l), t.astype(np.float64)
+    if Xt is None:
+        return float(l), t.astype(np.float64)
+    Kt = cov(np.asarray(Xt, LD), Zl)
+    Vt = np.zeros_like(Kt)
+    for j in range(m):
+        Vt[:, j] = (Kt[:, j] - Vt[:, :j] @ U[:j, j]) / U[j, j]
+    Qt = np.zeros_like(Kt)
+    for j in range(m):   # Q_t = V_t R~^-1 = K_tm R^-1
+        Qt[:, j] = (Vt[:, j] - Qt[:, :j] @ R[:j, j]) / R[j, j]
+    var = sf2 - (Vt * Vt).sum(1) + (Qt * Qt).sum(1)
+    return float(l), t.astype(np.float64), (Kt @ t).astype(np.float64), var.astype(np.float64)
 
 
 def longdouble_fat_evidence(X, y, Z, log_sf2, sigma2, tproj=None, log_hetero=None, log_multiscales_m05=None, jitter=1e-6):
