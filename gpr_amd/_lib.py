@@ -12,7 +12,8 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgprhip.so")
 
-OK, EBADARG, ENOTPOSDEF, EHIP, EOOM, ESTATE = range(6)
+OK, EBADARG, ENOTPOSDEF, EHIP, EOOM, ESTATE, ECOMM = range(7)
+COMM_NONE, COMM_RCCL, COMM_SAME_DEVICE = 0, 1, 2
 COV_SE_ISO, COV_SE_FAT = 0, 1
 F64, F32_BULK = 0, 1
 
@@ -86,6 +87,21 @@ SIGNATURES = {
     "gprhip_load_predictor": (C.c_int, [_vp, C.POINTER(Hypers), _dp, _dp, _dp]),
     "gprhip_debug_fetch": (C.c_int, [_vp, C.c_char_p, _dp, C.c_int64]),
     "gprhip_last_timings": (C.c_int, [_vp, C.POINTER(C.c_char_p), C.POINTER(C.c_float), C.c_int]),
+    "gprhip_shard_rows": (C.c_int, [C.c_int64, C.c_int, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "gprhip_ctx_create": (C.c_int, [C.POINTER(C.c_int), C.c_int, C.POINTER(_vp)]),
+    "gprhip_ctx_destroy": (None, [_vp]),
+    "gprhip_ctx_ndev": (C.c_int, [_vp]),
+    "gprhip_ctx_comm_mode": (C.c_int, [_vp]),
+    "gprhip_sharded_create": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int64,
+                                        C.POINTER(_vp)]),
+    "gprhip_sharded_destroy": (None, [_vp]),
+    "gprhip_sharded_shard": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "gprhip_sharded_problem": (_vp, [_vp, C.c_int]),
+    "gprhip_sharded_set_inputs": (C.c_int, [_vp, _dp, C.c_int64]),
+    "gprhip_sharded_set_targets": (C.c_int, [_vp, _dp]),
+    "gprhip_sharded_eval": (C.c_int, [_vp, C.POINTER(Hypers), C.c_int, C.POINTER(Result), _dp, _dp]),
+    "gprhip_sharded_comm_stats": (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int64), C.POINTER(C.c_float)]),
+    "gprhip_sharded_set_timing": (C.c_int, [_vp, C.c_int]),
     "gprhip_last_error": (C.c_char_p, []),
     "gprhip_version": (C.c_char_p, []),
 }

@@ -477,17 +477,22 @@ __global__ __launch_bounds__(256) void triu_matvec_kernel(const double* __restri
 }
 
 void launch_potrf_diag_flags(double* A, int mp, int j, double* dinv, int* info, int flags, hipStream_t s);
+// dynamic-LDS opt-in of the two step kernels, once per device
+static void potrf_attrs() {
+  static uint64_t done = 0;
+  once_per_device(done, [] {
+    GPR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&potrf_diag_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, POTRF_LDS));
+    GPR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&potrf_panel_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, PANEL_LDS));
+  });
+}
 void launch_potrf_diag(double* A, int mp, int j, double* dinv, int* info, hipStream_t s) {
   launch_potrf_diag_flags(A, mp, j, dinv, info, 0, s);
 }
 // flags: ablation switches of tools/potrf_check (bit0 skip factor, bit1 skip invert); 0 in the library
 void launch_potrf_diag_flags(double* A, int mp, int j, double* dinv, int* info, int flags, hipStream_t s) {
-  static bool attr = false;
-  if (!attr) {
-    GPR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&potrf_diag_kernel),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, POTRF_LDS));
-    attr = true;
-  }
+  potrf_attrs();
   hipLaunchKernelGGL(potrf_diag_kernel, dim3(1), dim3(PT), POTRF_LDS, s, A, mp, j, dinv, info, flags);
   GPR_HIP(hipGetLastError());
 }
@@ -496,14 +501,7 @@ void launch_potrf_diag_flags(double* A, int mp, int j, double* dinv, int* info, 
 // dinv: per step a factor-only diagonal kernel, the substitution panel and the small-tile trailing update; the block
 // inverses (which nothing on the chain needs any more) are formed by one launch over all blocks at the end.
 void potrf_upper_blocked(hipStream_t s, double* A, int mp, double* dinv, int* info, double* Yscratch, double* Xinv) {
-  static bool attr = false;
-  if (!attr) {
-    GPR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&potrf_diag_kernel),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, POTRF_LDS));
-    GPR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&potrf_panel_kernel),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, PANEL_LDS));
-    attr = true;
-  }
+  potrf_attrs();
   static const int all_tiles = [] {  // largest step (in 64 x 64 sub-tiles) that runs the all-loads-first update kernel
     const char* e = getenv("GPRHIP_POTRF_ALL_TILES");
     return e ? atoi(e) : 768;

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdint>
 #include <cstdio>
+#include <mutex>
 #include <string>
 
 namespace gprhip {
@@ -33,6 +34,19 @@ struct HipFail {
                                                          : ::gprhip::ST_HIP_ERROR};     \
     }                                                                                   \
   } while (0)
+
+// One-time setup per HIP device (function attributes are per device; a context drives several devices, possibly from
+// one host thread per device): runs f() the first time the calling thread's current device is seen for `mask`.
+std::mutex& device_once_mutex();
+template <typename F>
+static inline void once_per_device(uint64_t& mask, F&& f) {
+  std::lock_guard<std::mutex> g(device_once_mutex());
+  int dev = 0;
+  GPR_HIP(hipGetDevice(&dev));
+  if ((mask >> (dev & 63)) & 1) return;
+  f();
+  mask |= uint64_t(1) << (dev & 63);
+}
 
 constexpr int TILE = 128;  // MFMA engine block tile (rows and columns)
 constexpr int BK = 16;     // fp64 MFMA engine k-depth per LDS stage (fp32: 32)

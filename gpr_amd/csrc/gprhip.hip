@@ -21,6 +21,7 @@
 #include "common.h"
 #include "kernels.h"
 #include "mfma_gemm.h"
+#include "problem_internal.h"
 
 namespace gprhip {
 const std::string& last_error();
@@ -110,6 +111,11 @@ struct gprhip_problem {
   bool merged_x = false;      // this evaluation forms X by the two-phase product (set in pass 2)
   bool have_k = false;        // Kstore holds K_nm of the current kernel and inducing points for every chunk
   int k_resident = 1;         // GPRHIP_K_RESIDENT=0 (read at creation): never keep K_nm (ablation)
+  // GPRHIP_MERGED_X (read at creation): 0 = X~ and X = X~ U^-T as two launches, as in rounds 1-2 (A/B runs); 1 (default) =
+  // the two-phase product for shards large enough to pay for R^-1; 2 = always (parity tests at small sizes)
+  int merged_x_mode = 1;
+  // GPRHIP_POTRF_ENGINE=1 (read at creation): the round-2 factorisation (engine launches per step) + recursive-doubling inverse
+  bool engine_steps = false;
   // n x m storage: double, or float in the fp32-bulk mode (element size `esz`)
   void *bufA = nullptr, *bufB = nullptr, *Vstore = nullptr;
   // Cov_se_fat with projection hypers: K_nm of all rows, kept from pass 1 for the gradient kernel of pass 2 (which then
@@ -140,6 +146,9 @@ struct gprhip_problem {
   std::vector<double> hTproj, hHet, hMs;  // host copies: projection, exp(log_hetero), multiscales [mp][d]
   double* het = nullptr;                  // device copy of hHet
   double *ms = nullptr, *rowes = nullptr, *es2 = nullptr;  // multiscales [mp][d]; per-row E/ms partials
+  // host staging of the finish stage (filled by asynchronous copies between do_finish_enqueue and do_finish_collect)
+  std::vector<double> f_scal, f_tail, f_a1tail, f_t, f_col, f_km, f_wdiag;
+  int f_info[2] = {0, 0};
   Timer timer;
   std::vector<std::string> tnames;
   std::vector<float> tms;
@@ -189,12 +198,6 @@ template <> const float* inv_r<float>(const gprhip_problem* p) { return p->rinv_
 template <typename TS> const TS* inv_rfull(const gprhip_problem* p);
 template <> const double* inv_rfull<double>(const gprhip_problem* p) { return p->rfinv; }
 template <> const float* inv_rfull<float>(const gprhip_problem* p) { return p->rfinv_f; }
-// GPRHIP_MERGED_X (read once): 0 = X~ and X = X~ U^-T as two launches, as in rounds 1-2 (A/B runs); 1 (default) = the
-// two-phase product for shards large enough to pay for R^-1; 2 = always (parity tests at small sizes)
-static const int g_merged_x = [] {
-  const char* e = getenv("GPRHIP_MERGED_X");
-  return e ? atoi(e) : 1;
-}();
 
 void tstart(gprhip_problem* p, const char* name) {
   if (!p->timer.on) return;
@@ -239,14 +242,10 @@ void tcollect(gprhip_problem* p) {
 
 // Blocked upper Cholesky A = U^T U in place (dpotrf `U; lib/fitc_gp.ml:56) -- diagonal blocks in
 // LDS, panel solve and trailing update on the MFMA engine.  dinv receives inv(U_jj) per block.
-void potrf_upper_n(hipStream_t s, double* A, int mp, double* dinv, int* info) {
-  // default: the engine-free step kernels of chol.hip (potrf_upper_blocked); GPRHIP_POTRF_ENGINE=1 (read once) keeps the
-  // round-2 sequence below for A/B timing -- diagonal block with its full inverse, panel and trailing update as engine
-  // launches
-  static const bool engine_steps = [] {
-    const char* e = getenv("GPRHIP_POTRF_ENGINE");
-    return e && atoi(e) != 0;
-  }();
+void potrf_upper_n(hipStream_t s, double* A, int mp, double* dinv, int* info, bool engine_steps) {
+  // default: the engine-free step kernels of chol.hip (potrf_upper_blocked); engine_steps (GPRHIP_POTRF_ENGINE=1 at
+  // problem creation) keeps the round-2 sequence below for A/B timing -- diagonal block with its full inverse, panel
+  // and trailing update as engine launches
   if (!engine_steps) {
     potrf_upper_blocked(s, A, mp, dinv, info);
     return;
@@ -270,11 +269,9 @@ void potrf_upper_n(hipStream_t s, double* A, int mp, double* dinv, int* info) {
     }
   }
 }
-void potrf_upper(gprhip_problem* p, double* A, int* info) { potrf_upper_n(p->stream, A, p->mp, p->dinv, info); }
-static const bool g_engine_steps = [] {  // GPRHIP_POTRF_ENGINE=1: the round-2 factorisation + recursive-doubling inverse
-  const char* e = getenv("GPRHIP_POTRF_ENGINE");
-  return e && atoi(e) != 0;
-}();
+void potrf_upper(gprhip_problem* p, double* A, int* info) {
+  potrf_upper_n(p->stream, A, p->mp, p->dinv, info, p->engine_steps);
+}
 
 // A non-batched m x m product with few output tiles and a long k-range, split over `ks` k-slices so that the
 // launch fills the chip; partial products go to the split-K scratch and are summed in a fixed order.
@@ -354,7 +351,7 @@ void trtri_upper(gprhip_problem* p, const double* U, double* X, double* tmp) {
 // U = chol(A) in place and X = inv(U): one pass of the step kernels with the identity riding along as right-hand side
 // (chol.hip); `tmp` is an mp x mp scratch
 void potrf_trtri(gprhip_problem* p, double* A, double* X, double* tmp, int* info) {
-  if (g_engine_steps) {
+  if (p->engine_steps) {
     potrf_upper(p, A, info);
     trtri_upper(p, A, X, tmp);
     return;
@@ -673,7 +670,7 @@ void do_pass2(gprhip_problem* p, const double* ar1, double* ar2) {
     // The two-phase X product (below) needs R^-1 = U^-1 R~^-1, one more m x m product on the serial part of the
     // evaluation (0.14 ms at m = 2048, 0.8 ms at m = 4096), and saves 2.5 us per 1000 training points at m = 2048 (6 us
     // at m = 4096): taken from 48 m training points per shard on.
-    p->merged_x = g_merged_x == 2 || (g_merged_x == 1 && p->n >= 48 * (int64_t)p->m);
+    p->merged_x = p->merged_x_mode == 2 || (p->merged_x_mode == 1 && p->n >= 48 * (int64_t)p->m);
     if (p->merged_x) {
       GemmArgs rf;  // R^-1 = U^-1 R~^-1, both upper triangular
       rf.A = p->uinv; rf.lda = mp; rf.B = p->rinv; rf.ldb = mp; rf.C = p->rfinv; rf.ldc = mp;
@@ -812,7 +809,11 @@ void do_pass2(gprhip_problem* p, const double* ar1, double* ar2) {
   p->stage = 2;
 }
 
-void do_finish(gprhip_problem* p, const double* ar2, gprhip_result* res, double* grad, double* coeffs) {
+// Finish stage, first half: the m x m work of the gradient (W, traces) and the asynchronous copies of everything the
+// host assembly needs, all on the problem's stream; nothing blocks.  `light` (shards of a multi-device context other
+// than the first): only the factorisation flags are fetched -- the reduced buffers are identical on every device, and
+// one device's assembly serves the caller.
+void do_finish_enqueue(gprhip_problem* p, const double* ar2, bool light = false) {
   if (p->stage != 2) {
     set_error("gprhip: eval_finish called before eval_pass2");
     throw HipFail{ST_STATE};
@@ -820,11 +821,13 @@ void do_finish(gprhip_problem* p, const double* ar2, gprhip_result* res, double*
   GPR_HIP(hipSetDevice(p->device));
   hipStream_t s = p->stream;
   const int mp = p->mp, m = p->m, d = p->d;
-  const int64_t mm = (int64_t)mp * mp;
   const double* ar2_col = ar2 + packed_upper_len(mp);
   const double* ar2_proj = ar2_col + p->col_rows() * mp;
   const double* ar2_tail = ar2_proj + (int64_t)p->dbig() * d;
   const int nkslab = (m + km_slab_rows() - 1) / km_slab_rows();
+  GPR_HIP(hipMemcpyAsync(p->f_info, p->info, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
+  p->stage = 3;
+  if (light) return;
   if (p->want_grad) {
     tstart(p, "finish");
     launch_build_w(p->binv, p->ttil, ar2, mp, p->wtil, s);
@@ -846,31 +849,41 @@ void do_finish(gprhip_problem* p, const double* ar2, gprhip_result* res, double*
     }
     tstop(p);
   }
-  std::vector<double> hscal(NSCAL), htail(A2_TAIL), ha1tail(A1_TAIL), ht(mp);
-  std::vector<double> hcol, hkm;
-  int hinfo[2] = {0, 0};
-  GPR_HIP(hipMemcpyAsync(hscal.data(), p->scal, NSCAL * sizeof(double), hipMemcpyDeviceToHost, s));
-  GPR_HIP(hipMemcpyAsync(htail.data(), ar2_tail, A2_TAIL * sizeof(double), hipMemcpyDeviceToHost, s));
-  GPR_HIP(hipMemcpyAsync(ht.data(), p->tvec, mp * sizeof(double), hipMemcpyDeviceToHost, s));
-  GPR_HIP(hipMemcpyAsync(hinfo, p->info, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
+  p->f_scal.resize(NSCAL); p->f_tail.resize(A2_TAIL); p->f_a1tail.resize(A1_TAIL); p->f_t.resize(mp);
+  GPR_HIP(hipMemcpyAsync(p->f_scal.data(), p->scal, NSCAL * sizeof(double), hipMemcpyDeviceToHost, s));
+  GPR_HIP(hipMemcpyAsync(p->f_tail.data(), ar2_tail, A2_TAIL * sizeof(double), hipMemcpyDeviceToHost, s));
+  GPR_HIP(hipMemcpyAsync(p->f_t.data(), p->tvec, mp * sizeof(double), hipMemcpyDeviceToHost, s));
   if (p->want_grad) {
-    hcol.resize((size_t)(p->col_rows() * mp + (int64_t)p->dbig() * d));  // column block + Proj second term
-    hkm.resize((size_t)p->km_rows() * mp);
-    GPR_HIP(hipMemcpyAsync(hcol.data(), ar2_col, hcol.size() * sizeof(double), hipMemcpyDeviceToHost, s));
-    GPR_HIP(hipMemcpyAsync(hkm.data(), p->kmred, hkm.size() * sizeof(double), hipMemcpyDeviceToHost, s));
+    p->f_col.resize((size_t)(p->col_rows() * mp + (int64_t)p->dbig() * d));  // column block + Proj second term
+    p->f_km.resize((size_t)p->km_rows() * mp);
+    GPR_HIP(hipMemcpyAsync(p->f_col.data(), ar2_col, p->f_col.size() * sizeof(double), hipMemcpyDeviceToHost, s));
+    GPR_HIP(hipMemcpyAsync(p->f_km.data(), p->kmred, p->f_km.size() * sizeof(double), hipMemcpyDeviceToHost, s));
   }
-  std::vector<double> hwdiag;
   if (p->want_grad && (p->has_het() || p->has_ms())) {  // W_ii for the `Diag_vec / multiscale diagonal terms
-    hwdiag.resize(m);
-    GPR_HIP(hipMemcpy2DAsync(hwdiag.data(), sizeof(double), p->wmat, (size_t)(mp + 1) * sizeof(double),
+    p->f_wdiag.resize(m);
+    GPR_HIP(hipMemcpy2DAsync(p->f_wdiag.data(), sizeof(double), p->wmat, (size_t)(mp + 1) * sizeof(double),
                              sizeof(double), (size_t)m, hipMemcpyDeviceToHost, s));
   }
   // scalar tail of the (reduced) exchange-1 buffer, kept in p->ar1 by pass 2
-  GPR_HIP(hipMemcpyAsync(ha1tail.data(), p->ar1 + packed_upper_len(mp) + mp, A1_TAIL * sizeof(double),
+  GPR_HIP(hipMemcpyAsync(p->f_a1tail.data(), p->ar1 + packed_upper_len(mp) + mp, A1_TAIL * sizeof(double),
                          hipMemcpyDeviceToHost, s));
-  GPR_HIP(hipStreamSynchronize(s));
+}
+
+// Finish stage, second half: wait for the stream, check the factorisations, assemble l1, l2, dl/dsigma2 and the gradient
+// in the reference's Hyper.get_all order on the host.  light: flags and state only (see do_finish_enqueue).
+void do_finish_collect(gprhip_problem* p, gprhip_result* res, double* grad, double* coeffs, bool light = false) {
+  if (p->stage != 3) {
+    set_error("gprhip: finish collected before it was enqueued");
+    throw HipFail{ST_STATE};
+  }
+  GPR_HIP(hipSetDevice(p->device));
+  const int mp = p->mp, m = p->m, d = p->d;
+  GPR_HIP(hipStreamSynchronize(p->stream));
   p->stage = 0;
   if (p->timer.on || p->timer.kernel) tcollect(p);
+  const int* hinfo = p->f_info;
+  const std::vector<double>&hscal = p->f_scal, &htail = p->f_tail, &ha1tail = p->f_a1tail, &ht = p->f_t, &hcol = p->f_col,
+                           &hkm = p->f_km, &hwdiag = p->f_wdiag;
   if (hinfo[0] != 0 || hinfo[1] != 0) {
     p->have_v = p->have_k = false;  // V came out of a failed factor
     char buf[160];
@@ -882,6 +895,7 @@ void do_finish(gprhip_problem* p, const double* ar2, gprhip_result* res, double*
   }
   p->have_model = true;
   p->have_factors = true;
+  if (light) return;
   const bool mo = p->h.model_only != 0;
   const double sum_log_s = ha1tail[A1_SUMLOGS], sum_isr = ha1tail[A1_ISR], sum_isy2 = ha1tail[A1_ISY2];
   // l1: lib/fitc_gp.ml:204-208 with log|R^T R| - log|K_m| = log|B~| ; variational: :262-263
@@ -1196,7 +1210,7 @@ void do_cov_samples(gprhip_problem* p, const double* cov, int64_t ld, int64_t nt
                            (size_t)nt * sizeof(double), (size_t)nt, hipMemcpyHostToDevice, s));
   GPR_HIP(hipMemsetAsync(info, 0, sizeof(int), s));
   launch_sym_from_upper(raw, nt, (int)nt, A, np, add_diag + jitter, s);
-  potrf_upper_n(s, A, np, dinv, info);
+  potrf_upper_n(s, A, np, dinv, info, p->engine_steps);
   int hinfo = 0;
   GPR_HIP(hipMemcpyAsync(&hinfo, info, sizeof(int), hipMemcpyDeviceToHost, s));
   // z: Fortran nt x ns == row-major [ns][nt]
@@ -1332,6 +1346,20 @@ int guarded(F&& f, gprhip_problem* p = nullptr) {
 
 }  // namespace
 
+namespace gprhip {
+double* problem_ar1(gprhip_problem* p) { return p->ar1; }
+double* problem_ar2(gprhip_problem* p) { return p->ar2; }
+hipStream_t problem_hip_stream(gprhip_problem* p) { return p->stream; }
+int problem_device(const gprhip_problem* p) { return p->device; }
+int64_t problem_rows(const gprhip_problem* p) { return p->n; }
+int problem_finish_enqueue(gprhip_problem* p, const double* d_ar2, int light) {
+  return guarded([&] { do_finish_enqueue(p, d_ar2, light != 0); }, p);
+}
+int problem_finish_collect(gprhip_problem* p, gprhip_result* res, double* grad, double* coeffs, int light) {
+  return guarded([&] { do_finish_collect(p, res, grad, coeffs, light != 0); }, p);
+}
+}  // namespace gprhip
+
 extern "C" {
 
 const char* gprhip_last_error(void) { return last_error().c_str(); }
@@ -1393,6 +1421,8 @@ int gprhip_problem_create_ex(int device, int cov_kind, int precision, int64_t n,
     if (const char* e = getenv("GPRHIP_TILE_ORDER")) p->tile_order = atoi(e);
     if (const char* e = getenv("GPRHIP_GRAD_SCALAR")) p->grad_scalar = atoi(e);
     if (const char* e = getenv("GPRHIP_K_RESIDENT")) p->k_resident = atoi(e);
+    if (const char* e = getenv("GPRHIP_MERGED_X")) p->merged_x_mode = atoi(e);
+    if (const char* e = getenv("GPRHIP_POTRF_ENGINE")) p->engine_steps = atoi(e) != 0;
     GPR_HIP(hipStreamCreate(&p->stream));
     GPR_HIP(hipStreamCreate(&p->stream2));
     GPR_HIP(hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming));
@@ -1572,7 +1602,8 @@ int gprhip_eval_finish(gprhip_problem* p, const double* d_ar2, gprhip_result* re
       set_error("gprhip_eval_finish: NULL argument");
       throw HipFail{ST_BAD_ARG};
     }
-    do_finish(p, d_ar2, res, grad, coeffs);
+    do_finish_enqueue(p, d_ar2);
+    do_finish_collect(p, res, grad, coeffs);
   }, p);
 }
 
@@ -1590,7 +1621,8 @@ int gprhip_eval(gprhip_problem* p, const gprhip_hypers* h, int want_grad, gprhip
       do_pass1<double>(p, h, want_grad, p->n, p->ar1);
       do_pass2<double>(p, p->ar1, p->ar2);
     }
-    do_finish(p, p->ar2, res, grad, coeffs);
+    do_finish_enqueue(p, p->ar2);
+    do_finish_collect(p, res, grad, coeffs);
   }, p);
 }
 
@@ -1699,6 +1731,45 @@ int gprhip_debug_fetch(gprhip_problem* p, const char* name, double* out, int64_t
     else if (nm == "v") { src = p->v; avail = p->n; }
     else if (nm == "w") { src = p->w; avail = p->n; }
     else if (nm == "t") { src = p->tvec; avail = p->m; }
+    else if (nm == "km" || nm == "knm_rows") {
+      // element-wise pins of the covariance kernels (the counterpart of Test.check_deriv_hyper's matrix checks,
+      // lib/fitc_gp.ml:1223-1396): K_m as stored, and the first rows of K_nm rebuilt by the chunk builder
+      need_model(p, "gprhip_debug_fetch");
+      GPR_HIP(hipSetDevice(p->device));
+      const int m = p->m, mp = p->mp;
+      if (nm == "km") {
+        if (len < (int64_t)m * m) {
+          set_error("gprhip_debug_fetch: \"km\" needs m*m doubles");
+          throw HipFail{ST_BAD_ARG};
+        }
+        std::vector<double> h((size_t)mp * mp);
+        GPR_HIP(hipMemcpyAsync(h.data(), p->km, h.size() * sizeof(double), hipMemcpyDeviceToHost, p->stream));
+        GPR_HIP(hipStreamSynchronize(p->stream));
+        for (int c = 0; c < m; ++c)
+          for (int r = 0; r < m; ++r) out[(size_t)c * m + r] = (r <= c) ? h[(size_t)r * mp + c] : 0.0;
+        return;
+      }
+      const int64_t rows = len / m;
+      if (rows < 1 || rows > p->rows_of(0) || !p->have_inputs) {
+        set_error("gprhip_debug_fetch: \"knm_rows\" needs len = rows*m with 1 <= rows <= the first row chunk");
+        throw HipFail{ST_BAD_ARG};
+      }
+      std::vector<double> h((size_t)rows * mp);
+      if (p->f32) {
+        cov_chunk<float>(p, 0, static_cast<float*>(p->bufA));
+        std::vector<float> hf((size_t)rows * mp);
+        GPR_HIP(hipMemcpyAsync(hf.data(), p->bufA, hf.size() * sizeof(float), hipMemcpyDeviceToHost, p->stream));
+        GPR_HIP(hipStreamSynchronize(p->stream));
+        for (size_t i = 0; i < hf.size(); ++i) h[i] = hf[i];
+      } else {
+        cov_chunk<double>(p, 0, static_cast<double*>(p->bufA));
+        GPR_HIP(hipMemcpyAsync(h.data(), p->bufA, h.size() * sizeof(double), hipMemcpyDeviceToHost, p->stream));
+        GPR_HIP(hipStreamSynchronize(p->stream));
+      }
+      for (int c = 0; c < m; ++c)
+        for (int64_t r = 0; r < rows; ++r) out[(size_t)c * rows + r] = h[(size_t)r * mp + c];
+      return;
+    }
     else {
       set_error("gprhip_debug_fetch: unknown name");
       throw HipFail{ST_BAD_ARG};

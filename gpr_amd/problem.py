@@ -271,6 +271,18 @@ class Problem:
         _lib.check(self._lib.gprhip_debug_fetch(self._handle(), name.encode(), _f64_ptr(out), length))
         return out
 
+    def debug_fetch_matrix(self, name, rows=None):
+        """"km": K_m of the last evaluation (m x m, upper triangle valid, zeros below); "knm_rows": the first `rows`
+        rows of K_nm rebuilt with the last evaluation's kernel (rows x m)."""
+        if name == "km":
+            out = np.empty((self.m, self.m), dtype=np.float64, order="F")
+        elif name == "knm_rows":
+            out = np.empty((int(rows), self.m), dtype=np.float64, order="F")
+        else:
+            raise ValueError("debug_fetch_matrix: unknown name %r" % name)
+        _lib.check(self._lib.gprhip_debug_fetch(self._handle(), name.encode(), _f64_ptr(out), out.size))
+        return out
+
     def last_timings(self):
         names = (C.c_char_p * 32)()
         ms = (C.c_float * 32)()

@@ -34,7 +34,8 @@ enum {
   GPRHIP_ENOTPOSDEF = 2, /* reference: Lacaml Failure on potrf info > 0                          */
   GPRHIP_EHIP = 3,       /* HIP runtime error                                                    */
   GPRHIP_EOOM = 4,       /* device out of memory                                                 */
-  GPRHIP_ESTATE = 5      /* call sequence violated (e.g. pass2 before pass1)                     */
+  GPRHIP_ESTATE = 5,     /* call sequence violated (e.g. pass2 before pass1)                     */
+  GPRHIP_ECOMM = 6       /* RCCL could not be loaded / initialised, or a collective failed       */
 };
 
 enum { GPRHIP_COV_SE_ISO = 0, GPRHIP_COV_SE_FAT = 1 }; /* lib/cov_se_iso.ml, lib/cov_se_fat.ml */
@@ -146,6 +147,64 @@ int gprhip_sync(gprhip_problem* p);
 /* The HIP stream (hipStream_t) the problem enqueues on, for callers that order other work after it. */
 void* gprhip_stream(gprhip_problem* p);
 
+/* ---- Single-process, multi-device evaluation ---------------------------------------------------------------------
+ * The reference's host is ONE process (bin/ocaml_gpr.ml:176-177, :340-342: one functor application, one optimiser
+ * loop), so the way it reaches the GPUs of a node is a context that owns one shard per device and does the exchange
+ * steps itself -- the calls above with "the caller does the all-reduce" serve one-process-per-GPU hosts
+ * (gpr_amd/dist.py under torch.distributed).
+ *
+ *   gprhip_ctx_create(devices, ndev)        the devices of the node to use; loads RCCL (dlopen, so that single-device
+ *                                           use of the library has no RCCL dependency) and creates one communicator
+ *                                           per device (ncclCommInitAll) when ndev > 1
+ *   gprhip_sharded_create(ctx, ...)         one gprhip_problem per device; shard i owns the contiguous training rows
+ *                                           [lo_i, hi_i) (sizes differ by at most one, as gpr_amd.dist.shard_rows)
+ *   gprhip_sharded_set_inputs / _targets    the whole D x n / n host arrays; every shard copies its own rows
+ *   gprhip_sharded_eval                     pass 1 on every device (one host thread per device enqueues on that
+ *                                           device's stream), grouped ncclAllReduce(sum, fp64) of the packed exchange
+ *                                           buffers on those same streams -- no host synchronisation, no event hop --
+ *                                           pass 2, second all-reduce (gradient evaluations only), finish on the first
+ *                                           device.  Results are those of gprhip_eval on the unsharded problem up to the
+ *                                           summation order of the exchange buffers; with ndev == 1 they are bit-identical.
+ * Validation mode: if `devices` names ONE device ndev > 1 times, the shards share that device and the exchange step is
+ * a fixed-order device-local sum instead of RCCL (which refuses duplicate devices) -- the ndev-way partition and all of
+ * its bookkeeping can then be exercised on a one-GPU box.  Mixed lists (some devices repeated) are refused.
+ * GPRHIP_CTX_RCCL=1 in the environment at creation makes a one-device context go through RCCL as well (a one-rank
+ * communicator): exercises the dlopen / ncclCommInitAll / ncclAllReduce path on a one-GPU box.
+ * GPRHIP_RCCL_LIB names the shared object to load (default: librccl.so.1, then librccl.so, then /opt/rocm/lib). */
+typedef struct gprhip_ctx gprhip_ctx;
+typedef struct gprhip_sharded gprhip_sharded;
+
+enum { GPRHIP_COMM_NONE = 0, GPRHIP_COMM_RCCL = 1, GPRHIP_COMM_SAME_DEVICE = 2 };
+
+/* The row partition itself (pure arithmetic, no device): shard idx of ndev owns rows [*row_lo, *row_hi) of n. */
+int gprhip_shard_rows(int64_t n, int ndev, int idx, int64_t* row_lo, int64_t* row_hi);
+
+int gprhip_ctx_create(const int* devices, int ndev, gprhip_ctx** out);
+void gprhip_ctx_destroy(gprhip_ctx* ctx);
+int gprhip_ctx_ndev(const gprhip_ctx* ctx);
+int gprhip_ctx_comm_mode(const gprhip_ctx* ctx); /* GPRHIP_COMM_* */
+
+/* Arguments as gprhip_problem_create_ex, n = training points of the WHOLE problem (>= ndev). */
+int gprhip_sharded_create(gprhip_ctx* ctx, int cov_kind, int precision, int64_t n, int D, int d, int m,
+                          int64_t chunk_rows, gprhip_sharded** out);
+void gprhip_sharded_destroy(gprhip_sharded* sp);
+/* Shard idx (0 <= idx < ndev): its device, its row range [*row_lo, *row_hi) of the whole problem (any pointer may be
+ * NULL), and its device problem -- the m x m model state is replicated, so gprhip_predict, gprhip_covariances,
+ * gprhip_co_variance_coeffs, ... work on any shard's problem after an evaluation; gprhip_train_stats and the per-row
+ * names of gprhip_debug_fetch cover that shard's rows. */
+int gprhip_sharded_shard(const gprhip_sharded* sp, int idx, int* device, int64_t* row_lo, int64_t* row_hi);
+gprhip_problem* gprhip_sharded_problem(gprhip_sharded* sp, int idx);
+int gprhip_sharded_set_inputs(gprhip_sharded* sp, const double* inputs, int64_t ld); /* Fortran D x n, host */
+int gprhip_sharded_set_targets(gprhip_sharded* sp, const double* targets);           /* n, host          */
+/* As gprhip_eval. */
+int gprhip_sharded_eval(gprhip_sharded* sp, const gprhip_hypers* h, int want_grad, gprhip_result* res, double* grad,
+                        double* coeffs);
+/* Exchange steps of the last evaluation: their count (1 evidence-only, 2 gradient; 0 with one device and no forced
+ * RCCL), bytes per device of each, and -- after gprhip_sharded_set_timing(sp, 1) -- their milliseconds on the first
+ * shard's stream (HIP events; includes waiting for the slowest shard). */
+int gprhip_sharded_comm_stats(const gprhip_sharded* sp, int* collectives, int64_t bytes[2], float ms[2]);
+int gprhip_sharded_set_timing(gprhip_sharded* sp, int level);
+
 /* Posterior prediction at test points with the model state left by the last evaluation on `p`
  * (kernel, inducing points, U = chol_km, R = r_mat, mean coefficients):
  *   means[i]     = K_tm[i,:] . coeffs                          Means.calc     lib/fitc_gp.ml:418-425
@@ -198,7 +257,13 @@ int gprhip_load_predictor(gprhip_problem* p, const gprhip_hypers* h, const doubl
                           const double* r_mat);
 
 /* Intermediates of the last evaluation, for parity tests (copied to host; sizes in doubles):
- *   "r" n, "is" n, "v" n, "w" n, "t" m.  Returns GPRHIP_EBADARG for an unknown name. */
+ *   "r" n, "is" n, "v" n, "w" n, "t" m;
+ *   "km"  m*m : K_m as Inducing.calc_upper leaves it (lib/cov_se_iso.ml:56-87, lib/cov_se_fat.ml:110-142, without jitter
+ *               or heteroskedastic noise), Fortran m x m, upper triangle valid, zeros below;
+ *   "knm_rows" rows*m (rows = len / m <= the first row chunk): the first rows of K_nm recomputed with the kernel of the
+ *               last evaluation (Inputs.calc_cross, lib/cov_se_iso.ml:128-159, lib/cov_se_fat.ml:224-256), Fortran
+ *               rows x m (column-major, leading dimension rows); fp32-bulk problems return the rounded stored values.
+ * Returns GPRHIP_EBADARG for an unknown name. */
 int gprhip_debug_fetch(gprhip_problem* p, const char* name, double* out, int64_t len);
 
 /* Timing of evaluations with HIP events on the problem's own stream.  level 0: none (default; GPRHIP_TIMING in the

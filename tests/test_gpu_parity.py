@@ -1276,9 +1276,16 @@ def test_two_phase_and_two_launch_x_products_agree(name, monkeypatch):
     res = {}
     for mode in ("2", "0"):
         monkeypatch.setenv("GPRHIP_MERGED_X", mode)
-        p = _problem_for(g, chunk_rows=512)
+        p = _problem_for(g, chunk_rows=512)  # the switch is read when the problem is created
+        p.set_timing(2)
         res[mode] = _eval_golden(p, g)
+        stages = set(p.last_timings())
         p.close()
+        # the switch must have selected the code path (it used to be a load-time static no test could toggle)
+        if mode == "2":
+            assert "p2_trmm_SX" in stages and "p2_trmm_S" not in stages, stages
+        else:
+            assert {"p2_trmm_S", "p2_trmm_X"} <= stages and "p2_trmm_SX" not in stages, stages
         assert relinf(res[mode].grad, g["grad"]) <= tol, mode
         assert abs(res[mode].dl_dsigma2 - g["dl_dsigma2"]) <= TOL_DS2 * abs(g["dl_dsigma2"])
     assert res["2"].l == res["0"].l
@@ -1653,3 +1660,191 @@ def test_diagonal_block_harness():
     assert [int(r[0]) for r in inv] == [128, 384, 1024, 2048, 4096], out.stdout[-2000:]
     for _, eu, ei, el in inv:
         assert float(eu) == 0.0 and float(ei) < 1e-10 and float(el) == 0.0
+
+
+# ---- round 4: single-process multi-device context (gprhip_ctx_* / gprhip_sharded_*), element-wise covariance pins
+
+def _ctx_eval(devices, kind, X, y, Z, hyp, D=None, chunk_rows=0, precision=None, want_stats=False):
+    d, m = Z.shape
+    Dn, n = X.shape
+    ctx = gpr_amd.Context(devices)
+    sp = gpr_amd.ShardedDeviceProblem(ctx, kind, n, Dn, d, m, chunk_rows=chunk_rows,
+                                      precision=gpr_amd.F64 if precision is None else precision)
+    sp.set_inputs(X)
+    sp.set_targets(y)
+    if want_stats:
+        sp.set_timing(1)
+    ev = sp.eval(**hyp)
+    ev0 = sp.eval(want_grad=False, **hyp)
+    stats = (sp.comm_stats(), ctx.comm_mode, [sp.shard(i) for i in range(ctx.ndev)])
+    t = sp.problem(0).debug_fetch("t")
+    sp.close()
+    ctx.close()
+    return ev, ev0, stats, t
+
+
+def test_context_with_one_device_is_bit_identical_to_the_plain_evaluation():
+    """gprhip_sharded_eval over a one-device context runs the very same enqueue sequence as gprhip_eval."""
+    n, m, d = 3001, 140, 4
+    X, y, Z = synth(12, n, m, d)
+    hyp = dict(log_ell=0.6, log_sf2=0.1, sigma2=0.2, inducing=Z)
+    p = gpr_amd.Problem(gpr_amd.COV_SE_ISO, n, d, d, m)
+    p.set_inputs(X)
+    p.set_targets(y)
+    ref = p.eval(**hyp)
+    ref0 = p.eval(want_grad=False, **hyp)
+    p.close()
+    ev, ev0, (stats, mode, shards), t = _ctx_eval([0], gpr_amd.COV_SE_ISO, X, y, Z, hyp)
+    assert mode == gpr_amd.context.COMM_NONE and stats["collectives"] == 0
+    assert shards == [(0, 0, n)]
+    assert ev.l == ref.l and ev.l1 == ref.l1 and ev.dl_dsigma2 == ref.dl_dsigma2
+    assert np.array_equal(ev.grad, ref.grad) and np.array_equal(ev.coeffs, ref.coeffs)
+    assert ev0.l == ref0.l
+    assert np.array_equal(t, ref.coeffs)
+
+
+def test_context_through_rccl_with_one_rank():
+    """GPRHIP_CTX_RCCL=1: the library dlopens RCCL, creates a one-rank communicator (ncclCommInitAll) and runs its two
+    all-reduces on its own stream -- the in-library collective path on the one GPU a test box has.  Run in a fresh
+    process so that the RCCL the library loads is its own choice, not one torch brought in."""
+    import subprocess
+    import sys
+    code = (
+        "import os, sys, json, numpy as np\n"
+        "sys.path.insert(0, %r)\n"
+        "os.environ['GPRHIP_CTX_RCCL'] = '1'\n"
+        "import gpr_amd\n"
+        "from tests.util import synth\n"
+        "n, m, d = 3001, 140, 4\n"
+        "X, y, Z = synth(12, n, m, d)\n"
+        "hyp = dict(log_ell=0.6, log_sf2=0.1, sigma2=0.2, inducing=Z)\n"
+        "p = gpr_amd.Problem(gpr_amd.COV_SE_ISO, n, d, d, m); p.set_inputs(X); p.set_targets(y); ref = p.eval(**hyp); p.close()\n"
+        "ctx = gpr_amd.Context([0])\n"
+        "sp = gpr_amd.ShardedDeviceProblem(ctx, gpr_amd.COV_SE_ISO, n, d, d, m)\n"
+        "sp.set_inputs(X); sp.set_targets(y); sp.set_timing(1)\n"
+        "ev = sp.eval(**hyp); st = sp.comm_stats(); ev0 = sp.eval(want_grad=False, **hyp); st0 = sp.comm_stats()\n"
+        "print(json.dumps(dict(mode=ctx.comm_mode, st=st, st0=st0, same=bool(ev.l == ref.l and np.array_equal(ev.grad, ref.grad)),\n"
+        "      same0=bool(abs(ev0.l - ref.l) <= 1e-12 * abs(ref.l)), torch='torch' in sys.modules)))\n"
+    ) % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+    import json
+    r = json.loads(out.stdout.strip().splitlines()[-1])
+    assert r["mode"] == gpr_amd.context.COMM_RCCL and not r["torch"]
+    assert r["st"]["collectives"] == 2 and r["st0"]["collectives"] == 1
+    assert r["st"]["bytes"][0] > 0 and r["st"]["bytes"][1] > 0 and all(t > 0.0 for t in r["st"]["ms"])
+    assert r["same"] and r["same0"]  # a one-rank sum is the identity: bit-identical results
+
+
+@pytest.mark.parametrize("ndev", [2, 3, 8])
+def test_context_shards_on_one_device_equal_the_whole(ndev):
+    """Validation mode of the context (one device named ndev times): ragged row shards, device-local exchange, every
+    hyper family of Cov_se_fat -- against the unsharded evaluation (TOL_SHARD: only the summation order differs)."""
+    g = load_golden("fat_all")
+    p = _problem_for(g)
+    ref = _eval_golden(p, g)
+    p.close()
+    hyp = dict(log_sf2=float(g["log_sf2"]), sigma2=float(g["sigma2"]), inducing=g["Z"], tproj=g["tproj"],
+               log_hetero_skedasticity=g["log_hetero"], log_multiscales_m05=g["log_multiscales"])
+    ev, ev0, (stats, mode, shards), t = _ctx_eval([0] * ndev, gpr_amd.COV_SE_FAT, g["X"], g["y"], g["Z"], hyp,
+                                                  chunk_rows=256)
+    n = g["X"].shape[1]
+    assert mode == gpr_amd.context.COMM_SAME_DEVICE
+    assert shards[0][1] == 0 and shards[-1][2] == n and all(a[2] == b[1] for a, b in zip(shards, shards[1:]))
+    assert max(hi - lo for _, lo, hi in shards) - min(hi - lo for _, lo, hi in shards) <= 1
+    assert stats["collectives"] == 1  # the evidence-only evaluation ran last
+    assert abs(ev.l - ref.l) <= TOL_SHARD * abs(ref.l)
+    assert abs(ev0.l - ref.l) <= TOL_SHARD * abs(ref.l)
+    assert abs(ev.dl_dsigma2 - ref.dl_dsigma2) <= TOL_SHARD * abs(ref.dl_dsigma2)
+    assert relinf(ev.grad, ref.grad) <= 100 * TOL_SHARD
+    assert relinf(ev.coeffs, ref.coeffs) <= 100 * TOL_SHARD
+    assert relinf(ev.grad, g["grad"]) <= TOL_GRAD
+
+
+def test_context_eight_way_partition_at_4096_inducing_points():
+    """BASELINE.json configs[3]'s partition (8 row shards, m = 4096, d = 16) at a size one GPU holds: ragged rows
+    (160003 mod 8 != 0), the packed exchange buffers of m = 4096, gradient and evidence against the unsharded
+    evaluation, and the bytes per exchange step against the packed lengths."""
+    n, m, d = 160003, 4096, 16
+    X, y, Z = synth(4, n, m, d)
+    hyp = dict(log_ell=0.5 * np.log(d), log_sf2=0.0, sigma2=0.1, inducing=Z)
+    p = gpr_amd.Problem(gpr_amd.COV_SE_ISO, n, d, d, m)
+    p.set_inputs(X)
+    p.set_targets(y)
+    ref = p.eval(**hyp)
+    a1, a2 = p.ar1_len(), p.ar2_len()
+    p.close()
+    ctx = gpr_amd.Context([0] * 8)
+    sp = gpr_amd.ShardedDeviceProblem(ctx, gpr_amd.COV_SE_ISO, n, d, d, m)
+    sp.set_inputs(X)
+    sp.set_targets(y)
+    ev = sp.eval(**hyp)
+    st = sp.comm_stats()
+    sizes = [sp.shard(i)[2] - sp.shard(i)[1] for i in range(8)]
+    sp.close()
+    ctx.close()
+    assert sorted(set(sizes)) == [20000, 20001] and sum(sizes) == n
+    nt = m // 128
+    packed = nt * (nt + 1) // 2 * 128 * 128
+    assert a1 == packed + m + 4 and a2 == packed + (d + 1) * m + 8
+    assert st["collectives"] == 2 and st["bytes"] == [a1 * 8, a2 * 8]
+    assert abs(ev.l - ref.l) <= TOL_SHARD * abs(ref.l)
+    assert abs(ev.dl_dsigma2 - ref.dl_dsigma2) <= 10 * TOL_SHARD * abs(ref.dl_dsigma2)
+    assert relinf(ev.grad, ref.grad) <= 100 * TOL_SHARD
+    assert relinf(ev.coeffs, ref.coeffs) <= 1e-6  # cond(K_m) at m = 4096, d = 16 amplifies the summation-order difference
+
+
+def test_context_argument_checks():
+    with pytest.raises(gpr_amd.GprHipError):
+        gpr_amd.Context([])
+    with pytest.raises(gpr_amd.GprHipError):
+        gpr_amd.Context([99])
+    with pytest.raises(gpr_amd.GprHipError):
+        gpr_amd.Context([0, 0, 99])
+    ctx = gpr_amd.Context([0, 0, 0])
+    with pytest.raises(gpr_amd.GprHipError):  # fewer training points than shards
+        gpr_amd.ShardedDeviceProblem(ctx, gpr_amd.COV_SE_ISO, 2, 2, 2, 1)
+    sp = gpr_amd.ShardedDeviceProblem(ctx, gpr_amd.COV_SE_ISO, 50, 2, 2, 4)
+    X, y, Z = synth(0, 50, 4, 2)
+    with pytest.raises(gpr_amd.GprHipError):  # inputs not set
+        sp.eval(log_ell=0.0, log_sf2=0.0, sigma2=0.1, inducing=Z)
+    sp.set_inputs(X)
+    sp.set_targets(y)
+    with pytest.raises(gpr_amd.GprHipError):  # Model.check_sigma2 on every shard
+        sp.eval(log_ell=0.0, log_sf2=0.0, sigma2=-1.0, inducing=Z)
+    ev = sp.eval(log_ell=0.0, log_sf2=0.0, sigma2=0.1, inducing=Z)  # usable after the failures
+    assert np.isfinite(ev.l)
+    sp.close()
+    ctx.close()
+
+
+def _oracle_km_knm(g):
+    k = oracle_kernel(g)
+    Km, _ = O.spec_calc_shared_upper(k, g["Z"])
+    if g["kind"] != "iso" and k.hetero_skedasticity is not None:
+        Km = Km.copy()
+        Km[np.diag_indices(Km.shape[0])] -= k.hetero_skedasticity  # the device keeps K_m and the noise apart
+    Knm, _ = O.spec_calc_shared_cross(k, g["X"], g["Z"])
+    return Km, Knm
+
+
+@pytest.mark.parametrize("name", ["iso_c1", "iso_ragged", "fat_proj", "fat_hetero", "fat_multiscale", "fat_all"])
+def test_covariance_kernels_element_by_element(name):
+    """The element-wise half of Test.check_deriv_hyper's recipe (lib/fitc_gp.ml:1223-1396): K_m and rows of K_nm as the
+    device kernels produce them, against the oracle's direct-difference loops (lib/cov_se_iso.ml:56-87, :128-159,
+    lib/cov_se_fat.ml:85-142, :224-256) -- the covariance kernels pinned by themselves, not through downstream sums."""
+    g = load_golden(name)
+    p = _problem_for(g)
+    _eval_golden(p, g)
+    m = g["Z"].shape[1]
+    n = g["X"].shape[1]
+    Km, Knm = _oracle_km_knm(g)
+    km = p.debug_fetch_matrix("km")
+    assert np.all(km[np.tril_indices(m, -1)] == 0.0)
+    iu = np.triu_indices(m)
+    assert np.max(np.abs(km[iu] - Km[iu])) <= 4e-16 * np.max(np.abs(Km[iu]))  # exp() within 1-2 ulp of libm's
+    rows = min(n, 300)
+    knm = p.debug_fetch_matrix("knm_rows", rows)
+    assert knm.shape == (rows, m)
+    assert np.max(np.abs(knm - Knm[:rows])) <= 4e-16 * np.max(np.abs(Knm))
+    p.close()

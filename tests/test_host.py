@@ -75,6 +75,31 @@ def test_shard_rows_partitions_exactly():
         assert max(sizes) - min(sizes) <= 1
 
 
+def test_library_row_partition_is_the_one_the_process_per_gpu_path_uses():
+    """gprhip_shard_rows -- the partition of the single-process context (gprhip_sharded_create) -- is pure arithmetic
+    and runs without a device: identical to gpr_amd.dist.shard_rows, ragged counts and argument checks included."""
+    import ctypes as C
+    from gpr_amd import _lib
+    lib = _lib.load()
+    for n, w in ((1_000_000, 8), (8_000_000, 8), (160003, 8), (10, 3), (7, 7), (1001, 4), (5, 1)):
+        for r in range(w):
+            lo, hi = C.c_int64(), C.c_int64()
+            assert lib.gprhip_shard_rows(n, w, r, C.byref(lo), C.byref(hi)) == _lib.OK
+            assert (lo.value, hi.value) == shard_rows(n, r, w)
+    lo, hi = C.c_int64(), C.c_int64()
+    for bad in ((0, 1, 0), (10, 0, 0), (10, 2, 2), (10, 2, -1)):
+        assert lib.gprhip_shard_rows(*bad, C.byref(lo), C.byref(hi)) == _lib.EBADARG
+    assert b"gprhip_shard_rows" in lib.gprhip_last_error()
+
+
+def test_context_without_a_device_fails_loudly(gpu_available):
+    import gpr_amd
+    if gpu_available:
+        pytest.skip("a GPU is present")
+    with pytest.raises(gpr_amd.GprHipError):
+        gpr_amd.Context([0])
+
+
 def _factory(log_ell, log_sf2, tproj):
     return O.SeIsoKernel(log_ell, log_sf2)
 
