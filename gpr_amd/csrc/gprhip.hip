@@ -109,6 +109,7 @@ struct gprhip_problem {
   bool have_factors = false;  // U^-1 / R~^-1 valid (false after a means-only gprhip_load_predictor)
   bool have_v = false;        // Vstore / r hold V = K_nm U^-1 of the current kernel and inducing points (reuse_v)
   bool merged_x = false;      // this evaluation forms X by the two-phase product (set in pass 2)
+  const void* x_last = nullptr;  // single-chunk gradient evaluations: the chunk buffer that holds X (debug fetch "x_rows")
   bool have_k = false;        // Kstore holds K_nm of the current kernel and inducing points for every chunk
   int k_resident = 1;         // GPRHIP_K_RESIDENT=0 (read at creation): never keep K_nm (ablation)
   // GPRHIP_MERGED_X (read at creation): 0 = X~ and X = X~ U^-T as two launches, as in rounds 1-2 (A/B runs); 1 (default) =
@@ -506,6 +507,7 @@ void do_pass1(gprhip_problem* p, const gprhip_hypers* h, int want_grad, int64_t 
   // the state of the previous evaluation is void from here on; finish() re-validates it
   p->have_model = p->have_factors = false;
   p->stage = 0;
+  p->x_last = nullptr;
   upload_hypers(p, h);
   p->want_grad = want_grad;
   p->n_total = n_total;
@@ -743,6 +745,7 @@ void do_pass2(gprhip_problem* p, const double* ar1, double* ar2) {
         tstop(p);
         Xc = bufA;
       }
+      p->x_last = (p->nchunks == 1) ? static_cast<const void*>(Xc) : nullptr;
       tstart(p, "p2_grad");
       GradArgs<TS> ga;
       ga.X = Xc; ga.pts = p->pts() + base * p->d; ga.Z = p->Z;
@@ -1731,6 +1734,42 @@ int gprhip_debug_fetch(gprhip_problem* p, const char* name, double* out, int64_t
     else if (nm == "v") { src = p->v; avail = p->n; }
     else if (nm == "w") { src = p->w; avail = p->n; }
     else if (nm == "t") { src = p->tvec; avail = p->m; }
+    else if (nm == "w_mat" || nm == "x_rows") {
+      // the gradient factors of Trained.prepare_hyper (lib/fitc_gp.ml:1192-1207) as the last gradient evaluation left
+      // them: W (m x m, symmetric, Fortran) and the first rows of X (Fortran rows x m) -- with "km", "knm_rows" and "v"
+      // they let a test contract finite differences of the covariance matrices exactly as Shared.calc_log_evidence does
+      // (lib/fitc_gp.ml:1005-1021)
+      need_model(p, "gprhip_debug_fetch");
+      if (!p->want_grad) {
+        set_error("gprhip_debug_fetch: the last evaluation was evidence-only");
+        throw HipFail{ST_STATE};
+      }
+      GPR_HIP(hipSetDevice(p->device));
+      const int m = p->m, mp = p->mp;
+      if (nm == "w_mat") {
+        if (len < (int64_t)m * m) {
+          set_error("gprhip_debug_fetch: \"w_mat\" needs m*m doubles");
+          throw HipFail{ST_BAD_ARG};
+        }
+        std::vector<double> h((size_t)mp * mp);
+        GPR_HIP(hipMemcpyAsync(h.data(), p->wmat, h.size() * sizeof(double), hipMemcpyDeviceToHost, p->stream));
+        GPR_HIP(hipStreamSynchronize(p->stream));
+        for (int c = 0; c < m; ++c)
+          for (int r = 0; r < m; ++r) out[(size_t)c * m + r] = h[(size_t)r * mp + c];
+        return;
+      }
+      const int64_t rows = len / m;
+      if (!p->x_last || p->f32 || rows < 1 || rows > p->rows_of(0)) {
+        set_error("gprhip_debug_fetch: \"x_rows\" needs an fp64 problem whose rows fit one chunk, and len = rows*m");
+        throw HipFail{ST_BAD_ARG};
+      }
+      std::vector<double> h((size_t)rows * mp);
+      GPR_HIP(hipMemcpyAsync(h.data(), p->x_last, h.size() * sizeof(double), hipMemcpyDeviceToHost, p->stream));
+      GPR_HIP(hipStreamSynchronize(p->stream));
+      for (int c = 0; c < m; ++c)
+        for (int64_t r = 0; r < rows; ++r) out[(size_t)c * rows + r] = h[(size_t)r * mp + c];
+      return;
+    }
     else if (nm == "km" || nm == "knm_rows") {
       // element-wise pins of the covariance kernels (the counterpart of Test.check_deriv_hyper's matrix checks,
       // lib/fitc_gp.ml:1223-1396): K_m as stored, and the first rows of K_nm rebuilt by the chunk builder
@@ -1754,16 +1793,17 @@ int gprhip_debug_fetch(gprhip_problem* p, const char* name, double* out, int64_t
         set_error("gprhip_debug_fetch: \"knm_rows\" needs len = rows*m with 1 <= rows <= the first row chunk");
         throw HipFail{ST_BAD_ARG};
       }
+      void* const kbuf = (p->x_last == p->bufA) ? p->bufB : p->bufA;  // the chunk buffer that does not hold X
       std::vector<double> h((size_t)rows * mp);
       if (p->f32) {
-        cov_chunk<float>(p, 0, static_cast<float*>(p->bufA));
+        cov_chunk<float>(p, 0, static_cast<float*>(kbuf));
         std::vector<float> hf((size_t)rows * mp);
-        GPR_HIP(hipMemcpyAsync(hf.data(), p->bufA, hf.size() * sizeof(float), hipMemcpyDeviceToHost, p->stream));
+        GPR_HIP(hipMemcpyAsync(hf.data(), kbuf, hf.size() * sizeof(float), hipMemcpyDeviceToHost, p->stream));
         GPR_HIP(hipStreamSynchronize(p->stream));
         for (size_t i = 0; i < hf.size(); ++i) h[i] = hf[i];
       } else {
-        cov_chunk<double>(p, 0, static_cast<double*>(p->bufA));
-        GPR_HIP(hipMemcpyAsync(h.data(), p->bufA, h.size() * sizeof(double), hipMemcpyDeviceToHost, p->stream));
+        cov_chunk<double>(p, 0, static_cast<double*>(kbuf));
+        GPR_HIP(hipMemcpyAsync(h.data(), kbuf, h.size() * sizeof(double), hipMemcpyDeviceToHost, p->stream));
         GPR_HIP(hipStreamSynchronize(p->stream));
       }
       for (int c = 0; c < m; ++c)

@@ -83,6 +83,9 @@ struct GemmArgsT {
   double* rp_dot = nullptr;
   const double* rp_vec = nullptr;
   int lab_skip = 0;  // tools/gemm_check.hip only (timing ablation): 1 = no epilogue at all
+  int lab_nostep = 0;  // engine lab (GPRHIP_LAB_NOSTEP=1, timing only, results wrong): the operand pointers do not advance
+                       // from stage to stage, so every refill after the first hits the L2 -- how much of a launch is
+                       // memory latency the two-buffer ring fails to hide
   unsigned long long* lab_ts = nullptr;  // tools/gemm_check.hip only: 8 words per workgroup (phase time stamps, HW_ID, XCC_ID)
 };
 using GemmArgs = GemmArgsT<double>;

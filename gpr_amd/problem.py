@@ -274,9 +274,9 @@ class Problem:
     def debug_fetch_matrix(self, name, rows=None):
         """"km": K_m of the last evaluation (m x m, upper triangle valid, zeros below); "knm_rows": the first `rows`
         rows of K_nm rebuilt with the last evaluation's kernel (rows x m)."""
-        if name == "km":
+        if name in ("km", "w_mat"):
             out = np.empty((self.m, self.m), dtype=np.float64, order="F")
-        elif name == "knm_rows":
+        elif name in ("knm_rows", "x_rows"):
             out = np.empty((int(rows), self.m), dtype=np.float64, order="F")
         else:
             raise ValueError("debug_fetch_matrix: unknown name %r" % name)

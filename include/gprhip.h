@@ -262,7 +262,10 @@ int gprhip_load_predictor(gprhip_problem* p, const gprhip_hypers* h, const doubl
  *               or heteroskedastic noise), Fortran m x m, upper triangle valid, zeros below;
  *   "knm_rows" rows*m (rows = len / m <= the first row chunk): the first rows of K_nm recomputed with the kernel of the
  *               last evaluation (Inputs.calc_cross, lib/cov_se_iso.ml:128-159, lib/cov_se_fat.ml:224-256), Fortran
- *               rows x m (column-major, leading dimension rows); fp32-bulk problems return the rounded stored values.
+ *               rows x m (column-major, leading dimension rows); fp32-bulk problems return the rounded stored values;
+ *   "w_mat" m*m : W of Trained.prepare_hyper (lib/fitc_gp.ml:1196-1203) after a gradient evaluation, Fortran m x m, symmetric;
+ *   "x_rows" rows*m : the first rows of X (lib/fitc_gp.ml:1204-1206), Fortran rows x m -- fp64 problems whose training
+ *               points fit one row chunk only (the chunk buffers are reused otherwise).
  * Returns GPRHIP_EBADARG for an unknown name. */
 int gprhip_debug_fetch(gprhip_problem* p, const char* name, double* out, int64_t len);
 

@@ -1848,3 +1848,84 @@ def test_covariance_kernels_element_by_element(name):
     assert knm.shape == (rows, m)
     assert np.max(np.abs(knm - Knm[:rows])) <= 4e-16 * np.max(np.abs(Knm))
     p.close()
+
+
+def _hyper_args(g):
+    args = dict(log_sf2=float(g["log_sf2"]), sigma2=float(g["sigma2"]), inducing=g["Z"].copy(),
+                variational=bool(g.get("variational", False)))
+    if g["kind"] == "iso":
+        args["log_ell"] = float(g["log_ell"])
+    else:
+        if "tproj" in g:
+            args["tproj"] = g["tproj"].copy()
+        if "log_hetero" in g:
+            args["log_hetero_skedasticity"] = g["log_hetero"].copy()
+        if "log_multiscales" in g:
+            args["log_multiscales_m05"] = g["log_multiscales"].copy()
+    return args
+
+
+def _device_covariances(p, args, n):
+    """K_m (full symmetric, heteroskedastic noise included -- without the jitter, like Inducing.calc_upper) and K_nm as the
+    device kernels build them for `args`."""
+    p.eval(want_grad=False, **args)
+    km = p.debug_fetch_matrix("km")
+    km = km + np.triu(km, 1).T
+    if args.get("log_hetero_skedasticity") is not None:
+        km = km + np.diag(np.exp(args["log_hetero_skedasticity"]))
+    return km, p.debug_fetch_matrix("knm_rows", n)
+
+
+@pytest.mark.parametrize("name", ["iso_c1", "iso_c1_var", "fat_all", "fat_proj_var"])
+def test_gradient_factors_against_differences_of_the_device_covariances(name):
+    """The device counterpart of Test.check_deriv_hyper + Shared.calc_log_evidence (lib/fitc_gp.ml:1223-1396, :1005-1021):
+    the derivative matrices of the spec never exist on the device (they are contracted inside the gradient kernels), so
+    the check contracts central differences of the covariance matrices the device kernels produce with the device's own
+    W, X and v,   dl/dtheta = -1/2 (v . diag K'_n - tr(W K'_m)) - tr(X^T K'_nm),   for one hyper of every family, and
+    compares with the gradient entry the fused kernels returned.  No oracle on either side."""
+    g = load_golden(name)
+    p = _problem_for(g)
+    n, m = g["X"].shape[1], g["Z"].shape[1]
+    d = g["Z"].shape[0]
+    args = _hyper_args(g)
+    ev = p.eval(**args)
+    W = p.debug_fetch_matrix("w_mat")
+    X = p.debug_fetch_matrix("x_rows", n)
+    v = p.debug_fetch("v")
+    assert np.max(np.abs(W - W.T)) <= 1e-12 * np.max(np.abs(W))
+    sf2 = np.exp(args["log_sf2"])
+    iso = g["kind"] == "iso"
+    # (position in the gradient, perturbation, diag K'_n) per hyper family, in Hyper.get_all order
+    cases = []
+    pos = 0
+    if iso:
+        cases.append(("Log_ell", pos, ("log_ell", None), 0.0)); pos += 1
+    cases.append(("Log_sf2", pos, ("log_sf2", None), sf2)); pos += 1
+    ind, dim = m // 2, d - 1
+    cases.append(("Inducing_hyper", pos + ind * d + dim, ("inducing", (dim, ind)), 0.0)); pos += m * d
+    if "tproj" in args:
+        D = g["X"].shape[0]
+        big, small = D - 2, 1
+        cases.append(("Proj", pos + big * d + small, ("tproj", (big, small)), 0.0)); pos += D * d
+    if "log_hetero_skedasticity" in args:
+        cases.append(("Log_hetero_skedasticity", pos + 3, ("log_hetero_skedasticity", 3), 0.0)); pos += m
+    if "log_multiscales_m05" in args:
+        cases.append(("Log_multiscale_m05", pos + ind * d + dim, ("log_multiscales_m05", (dim, ind)), 0.0)); pos += m * d
+    assert pos == ev.grad.shape[0]
+    h = 1e-5
+    for label, gi, (key, idx), dkn_diag in cases:
+        mats = []
+        for sgn in (+1.0, -1.0):
+            a = {k: (val.copy() if isinstance(val, np.ndarray) else val) for k, val in args.items()}
+            if idx is None:
+                a[key] = a[key] + sgn * h
+            else:
+                a[key][idx] += sgn * h
+            mats.append(_device_covariances(p, a, n))
+        dkm = (mats[0][0] - mats[1][0]) / (2 * h)
+        dknm = (mats[0][1] - mats[1][1]) / (2 * h)
+        terms = (-0.5 * dkn_diag * np.sum(v), 0.5 * np.sum(W * dkm), -np.sum(X * dknm))
+        fd = sum(terms)
+        scale = max(abs(t) for t in terms) + 1e-300
+        assert abs(fd - ev.grad[gi]) <= 2e-6 * scale + 1e-9, (label, fd, ev.grad[gi], terms)
+    p.close()
