@@ -249,3 +249,209 @@ CAMLprim value gprhip_ml_version(value unit) {
   (void)unit;
   return caml_copy_string(gprhip_version());
 }
+
+/* ---- single-process, multi-device: gprhip_ctx_* / gprhip_sharded_* (include/gprhip.h) ------------------------------
+ * The reference's host is one process (bin/ocaml_gpr.ml:176-177, :340-342), so this is the path its functor takes:
+ * a context over the node's devices, one sharded problem per set of training inputs, RCCL inside the library. */
+#define Ctx_val(v) (*((gprhip_ctx**)Data_custom_val(v)))
+#define Sharded_val(v) (*((gprhip_sharded**)Data_custom_val(v)))
+
+static void ctx_finalize(value v) {
+  gprhip_ctx* c = Ctx_val(v);
+  if (c) {
+    gprhip_ctx_destroy(c); /* deferred by the library while sharded problems of it are alive */
+    Ctx_val(v) = NULL;
+  }
+}
+static void sharded_finalize(value v) {
+  gprhip_sharded* s = Sharded_val(v);
+  if (s) {
+    gprhip_sharded_destroy(s);
+    Sharded_val(v) = NULL;
+  }
+}
+static struct custom_operations ctx_ops = {"gprhip.ctx",
+                                           ctx_finalize,
+                                           custom_compare_default,
+                                           custom_hash_default,
+                                           custom_serialize_default,
+                                           custom_deserialize_default,
+                                           custom_compare_ext_default,
+                                           custom_fixed_length_default};
+static struct custom_operations sharded_ops = {"gprhip.sharded",
+                                               sharded_finalize,
+                                               custom_compare_default,
+                                               custom_hash_default,
+                                               custom_serialize_default,
+                                               custom_deserialize_default,
+                                               custom_compare_ext_default,
+                                               custom_fixed_length_default};
+/* a shard's device problem, owned by its sharded problem: no finaliser (the OCaml side keeps the owner reachable) */
+static struct custom_operations borrowed_problem_ops = {"gprhip.problem.borrowed",
+                                                        custom_finalize_default,
+                                                        custom_compare_default,
+                                                        custom_hash_default,
+                                                        custom_serialize_default,
+                                                        custom_deserialize_default,
+                                                        custom_compare_ext_default,
+                                                        custom_fixed_length_default};
+
+/* external ctx_create : int array -> ctx */
+CAMLprim value gprhip_ml_ctx_create(value devices) {
+  CAMLparam1(devices);
+  CAMLlocal1(res);
+  int devs[64], n = (int)Wosize_val(devices), i;
+  gprhip_ctx* c = NULL;
+  if (n < 1 || n > 64) caml_invalid_argument("Gpr_hip.ctx_create: 1 to 64 devices");
+  for (i = 0; i < n; ++i) devs[i] = Int_val(Field(devices, i));
+  check(gprhip_ctx_create(devs, n, &c));
+  res = caml_alloc_custom(&ctx_ops, sizeof(gprhip_ctx*), 0, 1);
+  Ctx_val(res) = c;
+  CAMLreturn(res);
+}
+CAMLprim value gprhip_ml_ctx_destroy(value ctx) {
+  ctx_finalize(ctx);
+  return Val_unit;
+}
+CAMLprim value gprhip_ml_ctx_ndev(value ctx) { return Val_int(gprhip_ctx_ndev(Ctx_val(ctx))); }
+CAMLprim value gprhip_ml_ctx_comm_mode(value ctx) { return Val_int(gprhip_ctx_comm_mode(Ctx_val(ctx))); }
+
+/* external sharded_create : ctx -> int -> int -> int -> int -> int -> int -> int -> sharded
+ *   cov_kind precision n big_d d m chunk_rows */
+CAMLprim value gprhip_ml_sharded_create(value ctx, value kind, value precision, value n, value big_d, value d,
+                                        value m, value chunk_rows) {
+  CAMLparam1(ctx);
+  CAMLlocal1(res);
+  gprhip_sharded* s = NULL;
+  check(gprhip_sharded_create(Ctx_val(ctx), Int_val(kind), Int_val(precision), (int64_t)Long_val(n), Int_val(big_d),
+                              Int_val(d), Int_val(m), (int64_t)Long_val(chunk_rows), &s));
+  res = caml_alloc_custom(&sharded_ops, sizeof(gprhip_sharded*), 0, 1);
+  Sharded_val(res) = s;
+  CAMLreturn(res);
+}
+CAMLprim value gprhip_ml_sharded_create_bc(value* a, int n) {
+  (void)n;
+  return gprhip_ml_sharded_create(a[0], a[1], a[2], a[3], a[4], a[5], a[6], a[7]);
+}
+CAMLprim value gprhip_ml_sharded_destroy(value sp) {
+  sharded_finalize(sp);
+  return Val_unit;
+}
+
+/* external sharded_shard : sharded -> int -> int * int * int       (device, row_lo, row_hi) of a shard */
+CAMLprim value gprhip_ml_sharded_shard(value sp, value idx) {
+  CAMLparam1(sp);
+  CAMLlocal1(res);
+  int dev = 0;
+  int64_t lo = 0, hi = 0;
+  check(gprhip_sharded_shard(Sharded_val(sp), Int_val(idx), &dev, &lo, &hi));
+  res = caml_alloc_tuple(3);
+  Store_field(res, 0, Val_int(dev));
+  Store_field(res, 1, Val_long(lo));
+  Store_field(res, 2, Val_long(hi));
+  CAMLreturn(res);
+}
+/* external shard_rows : n:int -> ndev:int -> idx:int -> int * int      (the partition itself; no device involved) */
+CAMLprim value gprhip_ml_shard_rows(value n, value ndev, value idx) {
+  CAMLparam0();
+  CAMLlocal1(res);
+  int64_t lo = 0, hi = 0;
+  check(gprhip_shard_rows((int64_t)Long_val(n), Int_val(ndev), Int_val(idx), &lo, &hi));
+  res = caml_alloc_tuple(2);
+  Store_field(res, 0, Val_long(lo));
+  Store_field(res, 1, Val_long(hi));
+  CAMLreturn(res);
+}
+
+/* external sharded_problem : sharded -> int -> problem     (borrowed: valid while the sharded problem lives) */
+CAMLprim value gprhip_ml_sharded_problem(value sp, value idx) {
+  CAMLparam1(sp);
+  CAMLlocal1(res);
+  gprhip_problem* p = gprhip_sharded_problem(Sharded_val(sp), Int_val(idx));
+  if (!p) caml_invalid_argument("Gpr_hip.sharded_problem: no such shard");
+  res = caml_alloc_custom(&borrowed_problem_ops, sizeof(gprhip_problem*), 0, 1);
+  Problem_val(res) = p;
+  CAMLreturn(res);
+}
+
+CAMLprim value gprhip_ml_sharded_set_inputs(value sp, value mat) {
+  CAMLparam2(sp, mat);
+  struct caml_ba_array* ba = Caml_ba_array_val(mat);
+  check(gprhip_sharded_set_inputs(Sharded_val(sp), (const double*)ba->data, (int64_t)ba->dim[0]));
+  CAMLreturn(Val_unit);
+}
+CAMLprim value gprhip_ml_sharded_set_targets(value sp, value vec) {
+  CAMLparam2(sp, vec);
+  check(gprhip_sharded_set_targets(Sharded_val(sp), (const double*)Caml_ba_data_val(vec)));
+  CAMLreturn(Val_unit);
+}
+
+/* external sharded_eval : sharded -> hypers -> want_grad:bool -> grad:vec -> coeffs:vec
+ *                         -> float * float * float * float * int        as gprhip_ml_eval */
+CAMLprim value gprhip_ml_sharded_eval(value sp, value h, value want_grad, value grad, value coeffs) {
+  CAMLparam5(sp, h, want_grad, grad, coeffs);
+  CAMLlocal1(res);
+  gprhip_hypers hy;
+  gprhip_result r;
+  gprhip_sharded* s = Sharded_val(sp);
+  double* g = (double*)Caml_ba_data_val(grad);
+  double* c = (double*)Caml_ba_data_val(coeffs);
+  int wg = Bool_val(want_grad), status;
+  hypers_of_value(h, &hy);
+  caml_release_runtime_system();
+  status = gprhip_sharded_eval(s, &hy, wg, &r, g, c);
+  caml_acquire_runtime_system();
+  check(status);
+  res = caml_alloc_tuple(5);
+  Store_field(res, 0, caml_copy_double(r.l1));
+  Store_field(res, 1, caml_copy_double(r.l2));
+  Store_field(res, 2, caml_copy_double(r.l));
+  Store_field(res, 3, caml_copy_double(r.dl_dsigma2));
+  Store_field(res, 4, Val_long(r.n_hypers));
+  CAMLreturn(res);
+}
+
+/* external sharded_comm_stats : sharded -> int * (int * int) * (float * float)   collectives, bytes, milliseconds */
+CAMLprim value gprhip_ml_sharded_comm_stats(value sp) {
+  CAMLparam1(sp);
+  CAMLlocal3(res, b, t);
+  int k = 0;
+  int64_t bytes[2] = {0, 0};
+  float ms[2] = {0.f, 0.f};
+  check(gprhip_sharded_comm_stats(Sharded_val(sp), &k, bytes, ms));
+  b = caml_alloc_tuple(2);
+  Store_field(b, 0, Val_long(bytes[0]));
+  Store_field(b, 1, Val_long(bytes[1]));
+  t = caml_alloc_tuple(2);
+  Store_field(t, 0, caml_copy_double(ms[0]));
+  Store_field(t, 1, caml_copy_double(ms[1]));
+  res = caml_alloc_tuple(3);
+  Store_field(res, 0, Val_int(k));
+  Store_field(res, 1, b);
+  Store_field(res, 2, t);
+  CAMLreturn(res);
+}
+CAMLprim value gprhip_ml_sharded_set_timing(value sp, value level) {
+  check(gprhip_sharded_set_timing(Sharded_val(sp), Int_val(level)));
+  return Val_unit;
+}
+
+/* external condition : problem -> float * float       (cond estimate of K_m + jitter, mean-coefficient error bound) */
+CAMLprim value gprhip_ml_condition(value prob) {
+  CAMLparam1(prob);
+  CAMLlocal1(res);
+  double c = 0.0, b = 0.0;
+  check(gprhip_condition(Problem_val(prob), &c, &b));
+  res = caml_alloc_tuple(2);
+  Store_field(res, 0, caml_copy_double(c));
+  Store_field(res, 1, caml_copy_double(b));
+  CAMLreturn(res);
+}
+
+/* external debug_fetch : problem -> string -> vec -> unit      intermediates of the last evaluation (parity tests) */
+CAMLprim value gprhip_ml_debug_fetch(value prob, value name, value out) {
+  CAMLparam3(prob, name, out);
+  check(gprhip_debug_fetch(Problem_val(prob), String_val(name), (double*)Caml_ba_data_val(out),
+                           (int64_t)Caml_ba_array_val(out)->dim[0]));
+  CAMLreturn(Val_unit);
+}

@@ -12,7 +12,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgprhip.so")
 
-OK, EBADARG, ENOTPOSDEF, EHIP, EOOM, ESTATE, ECOMM = range(7)
+OK, EBADARG, ENOTPOSDEF, EHIP, EOOM, ESTATE, ECOMM, EPRECISION = range(8)
 COMM_NONE, COMM_RCCL, COMM_SAME_DEVICE = 0, 1, 2
 COV_SE_ISO, COV_SE_FAT = 0, 1
 F64, F32_BULK = 0, 1
@@ -22,6 +22,10 @@ class GprHipError(RuntimeError):
     def __init__(self, status, msg):
         super().__init__(msg)
         self.status = status
+
+
+class UntrustworthyCoefficients(GprHipError):
+    """fp32-bulk mean coefficients refused (GPRHIP_EPRECISION): K_m is too ill-conditioned for them."""
 
 
 class NotPositiveDefinite(GprHipError):
@@ -85,6 +89,7 @@ SIGNATURES = {
                                      C.c_int64, _dp]),
     "gprhip_co_variance_coeffs": (C.c_int, [_vp, _dp, _dp]),
     "gprhip_load_predictor": (C.c_int, [_vp, C.POINTER(Hypers), _dp, _dp, _dp]),
+    "gprhip_condition": (C.c_int, [_vp, _dp, _dp]),
     "gprhip_debug_fetch": (C.c_int, [_vp, C.c_char_p, _dp, C.c_int64]),
     "gprhip_last_timings": (C.c_int, [_vp, C.POINTER(C.c_char_p), C.POINTER(C.c_float), C.c_int]),
     "gprhip_shard_rows": (C.c_int, [C.c_int64, C.c_int, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
@@ -134,6 +139,8 @@ def check(status):
     msg = load().gprhip_last_error().decode("utf-8", "replace")
     if status == ENOTPOSDEF:
         raise NotPositiveDefinite(status, msg)
+    if status == EPRECISION:
+        raise UntrustworthyCoefficients(status, msg)
     if status == EBADARG:
         raise GprHipError(status, msg)
     raise GprHipError(status, msg or ("gprhip status %d" % status))

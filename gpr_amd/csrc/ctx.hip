@@ -165,6 +165,7 @@ struct gprhip_ctx {
   std::vector<rccl_comm_t> comms;
   std::vector<std::unique_ptr<Worker>> workers;
   int live_problems = 0;
+  bool closed = false;  // gprhip_ctx_destroy was called while sharded problems were alive: the last of them frees the context
 };
 
 struct gprhip_sharded {
@@ -316,8 +317,7 @@ int gprhip_ctx_create(const int* devices, int ndev, gprhip_ctx** out) {
   });
 }
 
-void gprhip_ctx_destroy(gprhip_ctx* c) {
-  if (!c) return;
+static void ctx_free(gprhip_ctx* c) {
   c->workers.clear();
   for (size_t i = 0; i < c->comms.size(); ++i)
     if (c->comms[i]) {
@@ -328,13 +328,24 @@ void gprhip_ctx_destroy(gprhip_ctx* c) {
   delete c;
 }
 
+// Sharded problems keep their context alive: destroying the context first (a host whose garbage collector finalises
+// the two handles in either order) only marks it, and the last sharded problem frees it.
+void gprhip_ctx_destroy(gprhip_ctx* c) {
+  if (!c) return;
+  if (c->live_problems > 0) {
+    c->closed = true;
+    return;
+  }
+  ctx_free(c);
+}
+
 int gprhip_ctx_ndev(const gprhip_ctx* c) { return c ? (int)c->devices.size() : 0; }
 int gprhip_ctx_comm_mode(const gprhip_ctx* c) { return c ? c->mode : GPRHIP_COMM_NONE; }
 
 int gprhip_sharded_create(gprhip_ctx* c, int cov_kind, int precision, int64_t n, int D, int d, int m, int64_t chunk_rows,
                           gprhip_sharded** out) {
   return guarded([&] {
-    if (!c || !out) fail(GPRHIP_EBADARG, "gprhip_sharded_create: NULL argument");
+    if (!c || !out || c->closed) fail(GPRHIP_EBADARG, "gprhip_sharded_create: NULL argument or destroyed context");
     *out = nullptr;
     const int nd = (int)c->devices.size();
     if (n < nd) fail(GPRHIP_EBADARG, "gprhip_sharded_create: fewer training points than devices");
@@ -391,8 +402,9 @@ void gprhip_sharded_destroy(gprhip_sharded* sp) {
     if (sp->t0[k]) hipEventDestroy(sp->t0[k]);
     if (sp->t1[k]) hipEventDestroy(sp->t1[k]);
   }
-  --sp->ctx->live_problems;
+  gprhip_ctx* const c = sp->ctx;
   delete sp;
+  if (--c->live_problems == 0 && c->closed) ctx_free(c);
 }
 
 int gprhip_sharded_shard(const gprhip_sharded* sp, int idx, int* device, int64_t* row_lo, int64_t* row_hi) {

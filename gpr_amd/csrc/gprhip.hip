@@ -41,6 +41,28 @@ __global__ __launch_bounds__(256) void dot_kernel(const double* __restrict__ x,
   if (threadIdx.x == 0) out[0] = red[0];
 }
 
+// x <- x / |x| over the first n entries (single block); nrm[0] = |x| before the scaling
+__global__ __launch_bounds__(256) void normalize_kernel(double* __restrict__ x, int n, double* __restrict__ nrm) {
+  __shared__ double red[256];
+  double s = 0.0;
+  for (int i = threadIdx.x; i < n; i += 256) s += x[i] * x[i];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  const double r = sqrt(red[0]);
+  const double inv = r > 0.0 ? 1.0 / r : 0.0;
+  for (int i = threadIdx.x; i < n; i += 256) x[i] *= inv;
+  if (threadIdx.x == 0) nrm[0] = r;
+}
+
+__global__ void copy_diag_kernel(const double* __restrict__ A, int mp, double* __restrict__ out) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < mp) out[i] = A[(int64_t)i * (mp + 1)];
+}
+
 // dst = I + a on upper tiles, 0 elsewhere; a: packed upper tiles (the exchange-1 buffer)
 __global__ void add_identity_upper_kernel(const double* __restrict__ a, int mp, double* __restrict__ dst) {
   const int c = blockIdx.x * 256 + threadIdx.x;
@@ -64,6 +86,8 @@ constexpr int NSCAL = 16;
 enum {  // device scalar slots
   SC_LOGDET_B = 0,  // log |B~| = log |B| - log |K_m + jitter|
   SC_BB = 1,        // |b|^2 = |Q_n^T y~|^2
+  SC_LMAX = 2,      // power-iteration estimates of lambda_max(K_m + jitter) and lambda_max((K_m + jitter)^-1)
+  SC_LMAX_INV = 3,
 };
 // tail of the exchange-1 buffer
 enum { A1_SUMLOGS = 0, A1_ISY2 = 1, A1_ISR = 2, A1_TAIL = 4 };
@@ -109,6 +133,11 @@ struct gprhip_problem {
   bool have_factors = false;  // U^-1 / R~^-1 valid (false after a means-only gprhip_load_predictor)
   bool have_v = false;        // Vstore / r hold V = K_nm U^-1 of the current kernel and inducing points (reuse_v)
   bool merged_x = false;      // this evaluation forms X by the two-phase product (set in pass 2)
+  double cond_km = -1.0;       // 2-norm condition estimate of K_m + jitter of the last evaluation (< 0: not computed yet)
+  double f32_coeff_tol = 0.25; // GPRHIP_F32_COEFF_TOL (read at creation): fp32-bulk problems refuse to use their mean
+                               // coefficients when cond_km * 2^-24 exceeds it (0 = never refuse).  Measured over d = 1..16,
+                               // m = 50..512 (profiles/r04_f32_guard.txt): the coefficients' error is 1/17 .. 1/3600 of that
+                               // worst-case bound, i.e. <= ~1.5e-2 at the default threshold (cond ~ 4e6), typically 4e-3
   const void* x_last = nullptr;  // single-chunk gradient evaluations: the chunk buffer that holds X (debug fetch "x_rows")
   bool have_k = false;        // Kstore holds K_nm of the current kernel and inducing points for every chunk
   int k_resident = 1;         // GPRHIP_K_RESIDENT=0 (read at creation): never keep K_nm (ablation)
@@ -142,14 +171,21 @@ struct gprhip_problem {
   int64_t n_total = 0;
   int stage = 0;  // 0 idle, 1 pass1 done, 2 pass2 done
   bool have_inputs = false, have_targets = false;
-  std::vector<double> hShift;  // centroid of the inducing points
-  std::vector<double> hZ;  // host copy of inducing (padded point-major) for the gradient assembly
-  std::vector<double> hTproj, hHet, hMs;  // host copies: projection, exp(log_hetero), multiscales [mp][d]
+  // Per-evaluation parameters cross the PCIe link as ONE block: [Z (mp x d) | centroid (64) | tproj (D x d) | het (mp) |
+  // multiscales (mp x d)] (the last three for Cov_se_fat), assembled in pinned host memory (hy_host, whose parts the
+  // gradient assembly reads again) and copied by one asynchronous transfer of the prefix in use.
+  double *hy_dev = nullptr, *hy_host = nullptr;
+  int64_t hy_len = 0;
+  hipEvent_t ev_hy = nullptr;  // the last upload of hy_host has been consumed
+  double *hShift = nullptr, *hZ = nullptr, *hTproj = nullptr, *hHet = nullptr, *hMs = nullptr;  // parts of hy_host
   double* het = nullptr;                  // device copy of hHet
+  // Results of an evaluation come back as one block as well: [scalars (NSCAL) | potrf flags (2 ints in one double) |
+  // t (mp) | K_m traces (km_rows x mp) | diag W (mp)] = res_dev -> res_host (pinned), plus the tails of the two exchange
+  // buffers (ex_host: [A1_TAIL | column block .. end of the exchange-2 buffer]).
+  double *res_dev = nullptr, *res_host = nullptr, *ex_host = nullptr;
+  int64_t res_len = 0, ex_len = 0;
   double *ms = nullptr, *rowes = nullptr, *es2 = nullptr;  // multiscales [mp][d]; per-row E/ms partials
-  // host staging of the finish stage (filled by asynchronous copies between do_finish_enqueue and do_finish_collect)
-  std::vector<double> f_scal, f_tail, f_a1tail, f_t, f_col, f_km, f_wdiag;
-  int f_info[2] = {0, 0};
+  double* wdiag = nullptr;  // diag W inside the result block
   Timer timer;
   std::vector<std::string> tnames;
   std::vector<float> tms;
@@ -199,6 +235,8 @@ template <> const float* inv_r<float>(const gprhip_problem* p) { return p->rinv_
 template <typename TS> const TS* inv_rfull(const gprhip_problem* p);
 template <> const double* inv_rfull<double>(const gprhip_problem* p) { return p->rfinv; }
 template <> const float* inv_rfull<float>(const gprhip_problem* p) { return p->rfinv_f; }
+
+void need_trustworthy_coeffs(gprhip_problem* p, const char* who);
 
 void tstart(gprhip_problem* p, const char* name) {
   if (!p->timer.on) return;
@@ -402,26 +440,25 @@ void upload_hypers(gprhip_problem* p, const gprhip_hypers* h) {
   }
   p->h = *h;
   p->h.inducing = nullptr;  // borrowed; the padded copy lives in hZ
+  if (h->log_multiscales_m05 && p->kind == GPRHIP_COV_SE_ISO) {
+    set_error("gprhip: log_multiscales_m05 given for Cov_se_iso");
+    throw HipFail{ST_BAD_ARG};
+  }
+  // the pinned block may still be the source of the previous evaluation's transfer (a pass 1 repeated without a finish)
+  GPR_HIP(hipEventSynchronize(p->ev_hy));
+  int64_t used = (int64_t)p->mp * p->d + 64;  // doubles of the block this evaluation uploads (a prefix)
   if (h->log_hetero_skedasticity) {  // Kernel.create: Vec.map exp, lib/cov_se_fat.ml:63-65
-    p->hHet.resize(p->m);
     for (int i = 0; i < p->m; ++i) p->hHet[i] = std::exp(h->log_hetero_skedasticity[i]);
-    p->h.log_hetero_skedasticity = p->hHet.data();  // only used as a presence flag from here on
-    if (!p->het) p->het = p->alloc<double>(p->m);
-    GPR_HIP(hipMemcpyAsync(p->het, p->hHet.data(), (size_t)p->m * sizeof(double), hipMemcpyHostToDevice,
-                           p->stream));
+    for (int i = p->m; i < p->mp; ++i) p->hHet[i] = 0.0;
+    p->h.log_hetero_skedasticity = p->hHet;  // only used as a presence flag from here on
+    used = (p->hHet - p->hy_host) + p->mp;
   }
   if (h->log_multiscales_m05) {
-    if (p->kind == GPRHIP_COV_SE_ISO) {
-      set_error("gprhip: log_multiscales_m05 given for Cov_se_iso");
-      throw HipFail{ST_BAD_ARG};
-    }
     // Kernel.create: exp v +. 0.5, lib/cov_se_fat.ml:66-69 ; Fortran d x m == [m][d]; padding rows 1
-    p->hMs.assign((size_t)p->mp * p->d, 1.0);
     for (int64_t i = 0; i < (int64_t)p->m * p->d; ++i) p->hMs[i] = std::exp(h->log_multiscales_m05[i]) + 0.5;
-    p->h.log_multiscales_m05 = p->hMs.data();  // presence flag from here on
-    if (!p->ms) p->ms = p->alloc<double>((int64_t)p->mp * p->d);
-    GPR_HIP(hipMemcpyAsync(p->ms, p->hMs.data(), p->hMs.size() * sizeof(double), hipMemcpyHostToDevice,
-                           p->stream));
+    for (int64_t i = (int64_t)p->m * p->d; i < (int64_t)p->mp * p->d; ++i) p->hMs[i] = 1.0;
+    p->h.log_multiscales_m05 = p->hMs;  // presence flag from here on
+    used = (p->hMs - p->hy_host) + (int64_t)p->mp * p->d;
   }
   CovParams& cp = p->cp;
   cp.kind = p->kind;
@@ -436,24 +473,22 @@ void upload_hypers(gprhip_problem* p, const gprhip_hypers* h) {
     cp.inv_ell2_05 = -0.5;
   }
   // inducing: Fortran d x m == point-major [m][d]; pad to mp rows with zeros
-  p->hZ.assign((size_t)p->mp * p->d, 0.0);
-  std::memcpy(p->hZ.data(), h->inducing, (size_t)p->m * p->d * sizeof(double));
-  GPR_HIP(hipMemcpyAsync(p->Z, p->hZ.data(), p->hZ.size() * sizeof(double), hipMemcpyHostToDevice,
-                         p->stream));
+  std::memcpy(p->hZ, h->inducing, (size_t)p->m * p->d * sizeof(double));
+  std::memset(p->hZ + (size_t)p->m * p->d, 0, (size_t)(p->mp - p->m) * p->d * sizeof(double));
   {  // centroid of the inducing points
-    p->hShift.assign(64, 0.0);
+    for (int k = 0; k < 64; ++k) p->hShift[k] = 0.0;
     for (int c = 0; c < p->m; ++c)
       for (int k = 0; k < p->d && k < 64; ++k) p->hShift[k] += p->hZ[(size_t)c * p->d + k];
     for (int k = 0; k < 64; ++k) p->hShift[k] /= p->m;
-    GPR_HIP(hipMemcpyAsync(p->zshift, p->hShift.data(), 64 * sizeof(double), hipMemcpyHostToDevice, p->stream));
   }
   if (h->tproj) {
-    p->hTproj.assign(h->tproj, h->tproj + (size_t)p->D * p->d);  // borrowed pointer: copy before returning
-    p->h.tproj = p->hTproj.data();
-    GPR_HIP(hipMemcpyAsync(p->tproj, p->hTproj.data(), (size_t)p->D * p->d * sizeof(double),
-                           hipMemcpyHostToDevice, p->stream));
-    launch_project(p->X, p->n, p->D, p->d, p->tproj, p->P, p->stream);
+    std::memcpy(p->hTproj, h->tproj, (size_t)p->D * p->d * sizeof(double));  // borrowed pointer: copy before returning
+    p->h.tproj = p->hTproj;
+    used = std::max<int64_t>(used, (p->hTproj - p->hy_host) + (int64_t)p->D * p->d);
   }
+  GPR_HIP(hipMemcpyAsync(p->hy_dev, p->hy_host, (size_t)used * sizeof(double), hipMemcpyHostToDevice, p->stream));
+  GPR_HIP(hipEventRecord(p->ev_hy, p->stream));
+  if (h->tproj) launch_project(p->X, p->n, p->D, p->d, p->tproj, p->P, p->stream);
 }
 
 // Split-K factor of the SYRK-shaped accumulations over training points.  Slices are dealt to the
@@ -508,6 +543,7 @@ void do_pass1(gprhip_problem* p, const gprhip_hypers* h, int want_grad, int64_t 
   p->have_model = p->have_factors = false;
   p->stage = 0;
   p->x_last = nullptr;
+  p->cond_km = -1.0;
   upload_hypers(p, h);
   p->want_grad = want_grad;
   p->n_total = n_total;
@@ -556,8 +592,7 @@ void do_pass1(gprhip_problem* p, const gprhip_hypers* h, int want_grad, int64_t 
     GPR_HIP(hipEventRecord(p->ev_join, p->stream2));
   }
   tstart(p, "km_chol");
-  GPR_HIP(hipMemsetAsync(p->info, 0, 2 * sizeof(int), s));
-  GPR_HIP(hipMemsetAsync(p->scal, 0, NSCAL * sizeof(double), s));
+  GPR_HIP(hipMemsetAsync(p->scal, 0, (NSCAL + 2) * sizeof(double), s));  // the scalars and the two potrf flags behind them
   GPR_HIP(hipMemsetAsync(ar1_c, 0, (size_t)(mp + A1_TAIL) * sizeof(double), s));
   // K_m + (hetero) + jitter goes straight into the factor's buffer (kj is scratch of the finish stage only)
   launch_cov_upper(p->cp, p->Z, p->m, mp, p->d, h->jitter, p->has_het() ? p->het : nullptr, p->km, p->umat, s);
@@ -828,9 +863,12 @@ void do_finish_enqueue(gprhip_problem* p, const double* ar2, bool light = false)
   const double* ar2_proj = ar2_col + p->col_rows() * mp;
   const double* ar2_tail = ar2_proj + (int64_t)p->dbig() * d;
   const int nkslab = (m + km_slab_rows() - 1) / km_slab_rows();
-  GPR_HIP(hipMemcpyAsync(p->f_info, p->info, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
   p->stage = 3;
-  if (light) return;
+  if (light) {
+    GPR_HIP(hipMemcpyAsync(p->res_host + NSCAL, p->info, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
+    return;
+  }
+  const bool wdiag = p->want_grad && (p->has_het() || p->has_ms());
   if (p->want_grad) {
     tstart(p, "finish");
     launch_build_w(p->binv, p->ttil, ar2, mp, p->wtil, s);
@@ -850,26 +888,23 @@ void do_finish_enqueue(gprhip_problem* p, const double* ar2, bool light = false)
       launch_km_traces(p->wmat, p->km, p->Z, m, mp, d, p->kmpart, p->cp, s);
       launch_reduce_rows(p->kmpart, nkslab, (d + 2) * mp, p->kmred, 0, s);
     }
+    // W_ii for the `Diag_vec / multiscale diagonal terms, into the result block
+    if (wdiag) hipLaunchKernelGGL(copy_diag_kernel, dim3((mp + 255) / 256), dim3(256), 0, s, p->wmat, mp, p->wdiag);
     tstop(p);
   }
-  p->f_scal.resize(NSCAL); p->f_tail.resize(A2_TAIL); p->f_a1tail.resize(A1_TAIL); p->f_t.resize(mp);
-  GPR_HIP(hipMemcpyAsync(p->f_scal.data(), p->scal, NSCAL * sizeof(double), hipMemcpyDeviceToHost, s));
-  GPR_HIP(hipMemcpyAsync(p->f_tail.data(), ar2_tail, A2_TAIL * sizeof(double), hipMemcpyDeviceToHost, s));
-  GPR_HIP(hipMemcpyAsync(p->f_t.data(), p->tvec, mp * sizeof(double), hipMemcpyDeviceToHost, s));
-  if (p->want_grad) {
-    p->f_col.resize((size_t)(p->col_rows() * mp + (int64_t)p->dbig() * d));  // column block + Proj second term
-    p->f_km.resize((size_t)p->km_rows() * mp);
-    GPR_HIP(hipMemcpyAsync(p->f_col.data(), ar2_col, p->f_col.size() * sizeof(double), hipMemcpyDeviceToHost, s));
-    GPR_HIP(hipMemcpyAsync(p->f_km.data(), p->kmred, p->f_km.size() * sizeof(double), hipMemcpyDeviceToHost, s));
-  }
-  if (p->want_grad && (p->has_het() || p->has_ms())) {  // W_ii for the `Diag_vec / multiscale diagonal terms
-    p->f_wdiag.resize(m);
-    GPR_HIP(hipMemcpy2DAsync(p->f_wdiag.data(), sizeof(double), p->wmat, (size_t)(mp + 1) * sizeof(double),
-                             sizeof(double), (size_t)m, hipMemcpyDeviceToHost, s));
-  }
-  // scalar tail of the (reduced) exchange-1 buffer, kept in p->ar1 by pass 2
-  GPR_HIP(hipMemcpyAsync(p->f_a1tail.data(), p->ar1 + packed_upper_len(mp) + mp, A1_TAIL * sizeof(double),
+  // three transfers into pinned memory bring everything the host assembly needs: the result block (its K_m-trace and
+  // diag-W parts only after a gradient evaluation), the scalar tail of the reduced exchange-1 buffer (kept in p->ar1 by
+  // pass 2), and the exchange-2 buffer from its column block on (its scalar tail only after an evidence-only evaluation)
+  const int64_t res_used = NSCAL + 2 + mp + (p->want_grad ? p->km_rows() * mp + (wdiag ? mp : 0) : 0);
+  GPR_HIP(hipMemcpyAsync(p->res_host, p->res_dev, (size_t)res_used * sizeof(double), hipMemcpyDeviceToHost, s));
+  GPR_HIP(hipMemcpyAsync(p->ex_host, p->ar1 + packed_upper_len(mp) + mp, A1_TAIL * sizeof(double),
                          hipMemcpyDeviceToHost, s));
+  if (p->want_grad)
+    GPR_HIP(hipMemcpyAsync(p->ex_host + A1_TAIL, ar2_col, (size_t)(ar2_tail + A2_TAIL - ar2_col) * sizeof(double),
+                           hipMemcpyDeviceToHost, s));
+  else
+    GPR_HIP(hipMemcpyAsync(p->ex_host + A1_TAIL + (ar2_tail - ar2_col), ar2_tail, A2_TAIL * sizeof(double),
+                           hipMemcpyDeviceToHost, s));
 }
 
 // Finish stage, second half: wait for the stream, check the factorisations, assemble l1, l2, dl/dsigma2 and the gradient
@@ -884,9 +919,15 @@ void do_finish_collect(gprhip_problem* p, gprhip_result* res, double* grad, doub
   GPR_HIP(hipStreamSynchronize(p->stream));
   p->stage = 0;
   if (p->timer.on || p->timer.kernel) tcollect(p);
-  const int* hinfo = p->f_info;
-  const std::vector<double>&hscal = p->f_scal, &htail = p->f_tail, &ha1tail = p->f_a1tail, &ht = p->f_t, &hcol = p->f_col,
-                           &hkm = p->f_km, &hwdiag = p->f_wdiag;
+  const double* const hscal = p->res_host;
+  int hinfo[2];
+  std::memcpy(hinfo, p->res_host + NSCAL, sizeof hinfo);
+  const double* const ht = p->res_host + NSCAL + 2;
+  const double* const hkm = ht + mp;
+  const double* const hwdiag = hkm + p->km_rows() * mp;
+  const double* const ha1tail = p->ex_host;
+  const double* const hcol = p->ex_host + A1_TAIL;  // column block + Proj second term + scalar tail of exchange 2
+  const double* const htail = hcol + p->col_rows() * mp + (int64_t)p->dbig() * d;
   if (hinfo[0] != 0 || hinfo[1] != 0) {
     p->have_v = p->have_k = false;  // V came out of a failed factor
     char buf[160];
@@ -911,7 +952,7 @@ void do_finish_collect(gprhip_problem* p, gprhip_result* res, double* grad, doub
   res->l = l1 + l2;
   res->dl_dsigma2 = 0.0;
   res->n_hypers = 0;
-  if (coeffs) std::memcpy(coeffs, ht.data(), (size_t)m * sizeof(double));
+  if (coeffs) std::memcpy(coeffs, ht, (size_t)m * sizeof(double));
   if (!p->want_grad) return;
   // dl/dsigma2: lib/fitc_gp.ml:1112-1119, :1187-1188
   double sumv = htail[A2_SUMV];
@@ -954,8 +995,8 @@ void do_finish_collect(gprhip_problem* p, gprhip_result* res, double* grad, doub
   // dknm `Dense x_big,r (z_small,c - p_small,r) [/ ms_small,c] K_rc
   if (p->has_proj()) {
     const int D = p->D;
-    const double* m1 = hcol.data() + (size_t)(d + 1) * mp;       // [big][c] = sum_r x_big,r E_rc
-    const double* term2 = hcol.data() + (size_t)p->col_rows() * mp;  // [big][small]
+    const double* m1 = hcol + (size_t)(d + 1) * mp;       // [big][c] = sum_r x_big,r E_rc
+    const double* term2 = hcol + (size_t)p->col_rows() * mp;  // [big][small]
     for (int big = 0; big < D; ++big) {
       for (int small = 0; small < d; ++small) {
         double term1 = 0.0;
@@ -976,7 +1017,7 @@ void do_finish_collect(gprhip_problem* p, gprhip_result* res, double* grad, doub
   //   dkm `Sparse_rows: inner_i K_i,ind for i != ind, (1/2 - ms)/(2 ms - 1) K_ind,ind on the diagonal
   //   dknm `Sparse_cols: inner_r K_r,ind with inner = (1/ms - ((p_kr - z_kc)/ms)^2) * (1/2)(1/2 - ms)
   if (msm) {
-    const double* gxx = hcol.data() + (size_t)(d + 1 + Dp) * mp;   // [k][c] = sum_r p_kr^2 E_rc
+    const double* gxx = hcol + (size_t)(d + 1 + Dp) * mp;   // [k][c] = sum_r p_kr^2 E_rc
     for (int c = 0; c < m; ++c) {
       double lsum = 0.0;  // K_cc without heteroskedastic noise: exp(log_sf2 - 1/2 sum log(2 ms - 1))
       for (int k = 0; k < d; ++k) lsum += std::log(2.0 * p->hMs[(size_t)c * d + k] - 1.0);
@@ -1007,6 +1048,7 @@ void do_predict(gprhip_problem* p, const double* test_inputs, int64_t ld, int64_
     set_error("gprhip_predict: the loaded predictor has no co-variance coefficients (chol_km, r_mat)");
     throw HipFail{ST_STATE};
   }
+  if (means) need_trustworthy_coeffs(p, "gprhip_predict");
   GPR_HIP(hipSetDevice(p->device));
   hipStream_t s = p->stream;
   const int mp = p->mp;
@@ -1076,6 +1118,62 @@ struct DevBuf {
   }
 };
 
+// 2-norm condition estimate of A = K_m + jitter = U^T U of the current model state by power iteration on A (x <- U^T U x)
+// and on A^-1 = U^-1 U^-T -- both factors are on the device, a step is two triangular matrix-vector products.  Power
+// iteration approaches an extreme eigenvalue from inside the spectrum, so the estimate is a lower bound of the true
+// condition number (within a small factor after 16 steps for the spectra a covariance matrix has).  Cached per evaluation.
+double condition_km(gprhip_problem* p) {
+  if (p->cond_km >= 0.0) return p->cond_km;
+  if (!p->have_factors) {
+    set_error("gprhip_condition: no factor of K_m on the device (evaluate, or load a predictor with co-variance coefficients)");
+    throw HipFail{ST_STATE};
+  }
+  GPR_HIP(hipSetDevice(p->device));
+  hipStream_t s = p->stream;
+  const int mp = p->mp, m = p->m;
+  DevBuf tmp;
+  double* x = tmp.get<double>(2 * (int64_t)mp);
+  double* y = x + mp;
+  std::vector<double> h0(mp, 0.0);
+  for (int i = 0; i < m; ++i) h0[i] = 1.0 + 0.5 * std::sin(1.0 + 0.37 * i);  // the padding (a decoupled identity block) stays 0
+  for (int which = 0; which < 2; ++which) {
+    const double* F = which == 0 ? p->umat : p->uinv;
+    GPR_HIP(hipMemcpyAsync(x, h0.data(), (size_t)mp * sizeof(double), hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(normalize_kernel, dim3(1), dim3(256), 0, s, x, mp, p->scal + SC_LMAX + which);
+    for (int it = 0; it < 16; ++it) {
+      if (which == 0) {  // x <- U^T (U x)
+        launch_triu_matvec(F, mp, x, y, 0, s);
+        launch_triu_matvec(F, mp, y, x, 1, s);
+      } else {           // x <- U^-1 (U^-T x)
+        launch_triu_matvec(F, mp, x, y, 1, s);
+        launch_triu_matvec(F, mp, y, x, 0, s);
+      }
+      hipLaunchKernelGGL(normalize_kernel, dim3(1), dim3(256), 0, s, x, mp, p->scal + SC_LMAX + which);
+    }
+  }
+  double lam[2] = {0.0, 0.0};
+  GPR_HIP(hipMemcpyAsync(lam, p->scal + SC_LMAX, 2 * sizeof(double), hipMemcpyDeviceToHost, s));
+  GPR_HIP(hipStreamSynchronize(s));
+  p->cond_km = lam[0] * lam[1];
+  return p->cond_km;
+}
+
+// fp32-bulk problems: the mean coefficients t = U^-1 t~ inherit cond(K_m + jitter) times the fp32 unit roundoff of the
+// n x m operands (measured: profiles/r03_f32_sweep.txt -- useless from cond ~ 1e6 on); their consumers refuse them then.
+void need_trustworthy_coeffs(gprhip_problem* p, const char* who) {
+  if (!p->f32 || p->f32_coeff_tol <= 0.0 || !p->have_factors) return;
+  const double bound = condition_km(p) * 5.9604644775390625e-8;
+  if (bound > p->f32_coeff_tol) {
+    char buf[320];
+    snprintf(buf, sizeof buf,
+             "%s: the mean coefficients of this fp32-bulk evaluation are not trustworthy: cond(K_m + jitter) ~ %.3g, "
+             "error bound %.3g > %.3g (GPRHIP_F32_COEFF_TOL); evaluate with GPRHIP_F64 for coefficients / predictions "
+             "(log evidence and gradient are unaffected)", who, p->cond_km, bound, p->f32_coeff_tol);
+    set_error(buf);
+    throw HipFail{GPRHIP_EPRECISION};
+  }
+}
+
 void need_factors(gprhip_problem* p, const char* who) {
   if (!p->have_factors) {
     set_error(std::string(who) + ": the loaded predictor has no co-variance coefficients (chol_km, r_mat)");
@@ -1099,6 +1197,7 @@ void do_train_stats(gprhip_problem* p, double* means, double* sums) {
     set_error("gprhip_train_stats: the last evaluation had no targets");
     throw HipFail{ST_STATE};
   }
+  need_trustworthy_coeffs(p, "gprhip_train_stats");
   GPR_HIP(hipSetDevice(p->device));
   hipStream_t s = p->stream;
   DevBuf tmp;
@@ -1289,6 +1388,7 @@ void do_load_predictor(gprhip_problem* p, const gprhip_hypers* h, const double* 
   const int mp = p->mp, m = p->m;
   const int64_t mm = (int64_t)mp * mp;
   p->have_model = p->have_factors = p->have_v = p->have_k = false;
+  p->cond_km = -1.0;
   upload_hypers(p, h);
   std::vector<double> t(mp, 0.0);
   if (coeffs) std::memcpy(t.data(), coeffs, (size_t)m * sizeof(double));
@@ -1424,6 +1524,7 @@ int gprhip_problem_create_ex(int device, int cov_kind, int precision, int64_t n,
     if (const char* e = getenv("GPRHIP_TILE_ORDER")) p->tile_order = atoi(e);
     if (const char* e = getenv("GPRHIP_GRAD_SCALAR")) p->grad_scalar = atoi(e);
     if (const char* e = getenv("GPRHIP_K_RESIDENT")) p->k_resident = atoi(e);
+    if (const char* e = getenv("GPRHIP_F32_COEFF_TOL")) p->f32_coeff_tol = atof(e);
     if (const char* e = getenv("GPRHIP_MERGED_X")) p->merged_x_mode = atoi(e);
     if (const char* e = getenv("GPRHIP_POTRF_ENGINE")) p->engine_steps = atoi(e) != 0;
     GPR_HIP(hipStreamCreate(&p->stream));
@@ -1435,11 +1536,23 @@ int gprhip_problem_create_ex(int device, int cov_kind, int precision, int64_t n,
     const int64_t npad = (int64_t)p->nchunks * chunk;
     p->X = p->alloc<double>(n * D);
     p->y = p->alloc<double>(npad);
-    if (cov_kind == GPRHIP_COV_SE_FAT) {
-      p->P = p->alloc<double>(n * d);
-      p->tproj = p->alloc<double>((int64_t)D * d);
+    if (cov_kind == GPRHIP_COV_SE_FAT) p->P = p->alloc<double>(n * d);
+    {  // the per-evaluation parameter block and its pinned host mirror (upload_hypers)
+      const bool fat = cov_kind == GPRHIP_COV_SE_FAT;
+      const int64_t o_shift = (int64_t)mp * d, o_tproj = o_shift + 64, o_het = o_tproj + (fat ? round_up((int64_t)D * d, 2) : 0),
+                    o_ms = o_het + (fat ? mp : 0);
+      p->hy_len = o_ms + (fat ? (int64_t)mp * d : 0);
+      p->hy_dev = p->alloc<double>(p->hy_len);
+      GPR_HIP(hipHostMalloc(reinterpret_cast<void**>(&p->hy_host), (size_t)p->hy_len * sizeof(double), hipHostMallocDefault));
+      GPR_HIP(hipEventCreateWithFlags(&p->ev_hy, hipEventDisableTiming));
+      p->Z = p->hy_dev; p->hZ = p->hy_host;
+      p->zshift = p->hy_dev + o_shift; p->hShift = p->hy_host + o_shift;
+      if (fat) {
+        p->tproj = p->hy_dev + o_tproj; p->hTproj = p->hy_host + o_tproj;
+        p->het = p->hy_dev + o_het; p->hHet = p->hy_host + o_het;
+        p->ms = p->hy_dev + o_ms; p->hMs = p->hy_host + o_ms;
+      }
     }
-    p->Z = p->alloc<double>((int64_t)mp * d);
     p->km = p->alloc<double>(mm); p->kj = p->alloc<double>(mm); p->umat = p->alloc<double>(mm);
     p->uinv = p->alloc<double>(mm); p->bmat = p->alloc<double>(mm);
     p->rinv = p->alloc<double>(mm); p->binv = p->alloc<double>(mm); p->wtil = p->alloc<double>(mm);
@@ -1447,9 +1560,19 @@ int gprhip_problem_create_ex(int device, int cov_kind, int precision, int64_t n,
     p->wmat = p->alloc<double>(mm);
     p->tmp = p->alloc<double>((int64_t)mp * TILE);
     p->dinv = p->alloc<double>((int64_t)(mp / TILE) * TILE * TILE);
-    p->bvec = p->alloc<double>(mp); p->ttil = p->alloc<double>(mp); p->tvec = p->alloc<double>(mp);
-    p->scal = p->alloc<double>(NSCAL);
-    p->info = p->alloc<int>(2);
+    p->bvec = p->alloc<double>(mp); p->ttil = p->alloc<double>(mp);
+    {  // the result block and its pinned mirror; the tails of the exchange buffers land in ex_host (do_finish_enqueue)
+      p->res_len = NSCAL + 2 + mp + p->km_rows() * mp + mp;
+      p->res_dev = p->alloc<double>(p->res_len);
+      p->scal = p->res_dev;
+      p->info = reinterpret_cast<int*>(p->res_dev + NSCAL);
+      p->tvec = p->res_dev + NSCAL + 2;
+      p->kmred = p->tvec + mp;
+      p->wdiag = p->kmred + p->km_rows() * mp;
+      p->ex_len = A1_TAIL + p->col_rows() * mp + (int64_t)p->dbig() * d + A2_TAIL;
+      GPR_HIP(hipHostMalloc(reinterpret_cast<void**>(&p->res_host), (size_t)p->res_len * sizeof(double), hipHostMallocDefault));
+      GPR_HIP(hipHostMalloc(reinterpret_cast<void**>(&p->ex_host), (size_t)p->ex_len * sizeof(double), hipHostMallocDefault));
+    }
     p->r = p->alloc<double>(npad); p->is = p->alloc<double>(npad); p->yis = p->alloc<double>(npad);
     p->w = p->alloc<double>(npad); p->v = p->alloc<double>(npad);
     if (cov_kind == GPRHIP_COV_SE_FAT) {
@@ -1472,9 +1595,7 @@ int gprhip_problem_create_ex(int device, int cov_kind, int precision, int64_t n,
     const int64_t nslab = (chunk + gslab - 1) / gslab;
     p->colpart = p->alloc<double>(nslab * p->col_rows() * mp);
     p->scalpart = p->alloc<double>(nslab * (mp / TILE) * 2);
-    p->zshift = p->alloc<double>(64);
     p->kmpart = p->alloc<double>((int64_t)((m + km_slab_rows() - 1) / km_slab_rows()) * p->km_rows() * mp);
-    p->kmred = p->alloc<double>(p->km_rows() * mp);
     p->ar1 = p->alloc<double>(gprhip_ar1_len(p));
     p->ar2 = p->alloc<double>(gprhip_ar2_len(p));
     GPR_HIP(hipMemsetAsync(p->y, 0, (size_t)npad * sizeof(double), p->stream));
@@ -1493,6 +1614,10 @@ void gprhip_problem_destroy(gprhip_problem* p) {
     hipStreamSynchronize(p->stream2);
     hipStreamDestroy(p->stream2);
   }
+  if (p->ev_hy) hipEventDestroy(p->ev_hy);
+  if (p->hy_host) hipHostFree(p->hy_host);
+  if (p->res_host) hipHostFree(p->res_host);
+  if (p->ex_host) hipHostFree(p->ex_host);
   if (p->ev_fork) hipEventDestroy(p->ev_fork);
   if (p->ev_join) hipEventDestroy(p->ev_join);
   if (p->timer.k0) {
@@ -1692,6 +1817,19 @@ int gprhip_load_predictor(gprhip_problem* p, const gprhip_hypers* h, const doubl
       throw HipFail{ST_BAD_ARG};
     }
     do_load_predictor(p, h, coeffs, chol_km, r_mat);
+  });
+}
+
+int gprhip_condition(gprhip_problem* p, double* cond_km, double* coeff_error_bound) {
+  return guarded([&] {
+    if (!p) {
+      set_error("gprhip_condition: NULL problem");
+      throw HipFail{ST_BAD_ARG};
+    }
+    need_model(p, "gprhip_condition");
+    const double c = condition_km(p);
+    if (cond_km) *cond_km = c;
+    if (coeff_error_bound) *coeff_error_bound = c * (p->f32 ? 5.9604644775390625e-8 : 1.1102230246251565e-16);
   });
 }
 

@@ -265,6 +265,12 @@ class Problem:
         """0: none; 1: HIP events around the dominant kernel (pass-1 SYRK); 2: around every stage."""
         _lib.check(self._lib.gprhip_set_timing(self._handle(), int(level)))
 
+    def condition(self):
+        """(cond estimate of K_m + jitter, relative error bound of the mean coefficients) of the current model state."""
+        c, b = C.c_double(), C.c_double()
+        _lib.check(self._lib.gprhip_condition(self._handle(), C.byref(c), C.byref(b)))
+        return c.value, b.value
+
     def debug_fetch(self, name):
         length = self.m if name == "t" else self.n
         out = np.empty(length, dtype=np.float64)

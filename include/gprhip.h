@@ -35,7 +35,8 @@ enum {
   GPRHIP_EHIP = 3,       /* HIP runtime error                                                    */
   GPRHIP_EOOM = 4,       /* device out of memory                                                 */
   GPRHIP_ESTATE = 5,     /* call sequence violated (e.g. pass2 before pass1)                     */
-  GPRHIP_ECOMM = 6       /* RCCL could not be loaded / initialised, or a collective failed       */
+  GPRHIP_ECOMM = 6,      /* RCCL could not be loaded / initialised, or a collective failed       */
+  GPRHIP_EPRECISION = 7  /* fp32-bulk mean coefficients refused: K_m too ill-conditioned for them */
 };
 
 enum { GPRHIP_COV_SE_ISO = 0, GPRHIP_COV_SE_FAT = 1 }; /* lib/cov_se_iso.ml, lib/cov_se_fat.ml */
@@ -180,6 +181,8 @@ enum { GPRHIP_COMM_NONE = 0, GPRHIP_COMM_RCCL = 1, GPRHIP_COMM_SAME_DEVICE = 2 }
 int gprhip_shard_rows(int64_t n, int ndev, int idx, int64_t* row_lo, int64_t* row_hi);
 
 int gprhip_ctx_create(const int* devices, int ndev, gprhip_ctx** out);
+/* May be called while sharded problems of the context are still alive (a garbage-collected host finalises handles in
+ * any order): the context is then released together with the last of them. */
 void gprhip_ctx_destroy(gprhip_ctx* ctx);
 int gprhip_ctx_ndev(const gprhip_ctx* ctx);
 int gprhip_ctx_comm_mode(const gprhip_ctx* ctx); /* GPRHIP_COMM_* */
@@ -255,6 +258,17 @@ int gprhip_co_variance_coeffs(gprhip_problem* p, double* chol_km, double* r_mat)
  * (create the problem with n = the largest test batch you intend to pass). */
 int gprhip_load_predictor(gprhip_problem* p, const gprhip_hypers* h, const double* coeffs, const double* chol_km,
                           const double* r_mat);
+
+/* Conditioning of the inducing covariance of the current model state: *cond_km = an estimate (power iteration on
+ * U^T U and U^-1 U^-T, a lower bound within a small factor) of the 2-norm condition number of K_m + jitter, and
+ * *coeff_error_bound = cond_km * unit roundoff of the n x m operands (2^-24 for GPRHIP_F32_BULK, 2^-53 for GPRHIP_F64):
+ * the relative accuracy the mean coefficients (Trained.calc_mean_coeffs, lib/fitc_gp.ml:294, :288-292) can be trusted
+ * to.  Log evidence and gradient do not carry that factor.  Either pointer may be NULL.
+ * GPRHIP_F32_BULK problems enforce it: when the bound exceeds GPRHIP_F32_COEFF_TOL (environment, read at problem
+ * creation; default 0.25, i.e. cond ~ 4e6 -- the measured coefficient error is 1/17 .. 1/3600 of this worst-case bound,
+ * <= ~1.5e-2 at the threshold; 0 = never refuse) gprhip_predict (means) and gprhip_train_stats return GPRHIP_EPRECISION
+ * instead of results computed from such coefficients. */
+int gprhip_condition(gprhip_problem* p, double* cond_km, double* coeff_error_bound);
 
 /* Intermediates of the last evaluation, for parity tests (copied to host; sizes in doubles):
  *   "r" n, "is" n, "v" n, "w" n, "t" m;

@@ -85,7 +85,10 @@ def test_ocaml_stub_sources_cover_the_abi():
     declared = set(re.findall(r"\b(gprhip_[a-z0-9_]+)\s*\(", header))
     used = set(re.findall(r"\b(gprhip_(?!ml_)[a-z0-9_]+)\s*\(", stubs))
     assert used <= declared, used - declared
-    needed = {"gprhip_problem_create_ex", "gprhip_problem_destroy", "gprhip_set_inputs", "gprhip_set_targets",
+    needed = {"gprhip_ctx_create", "gprhip_ctx_destroy", "gprhip_sharded_create", "gprhip_sharded_destroy",
+              "gprhip_sharded_set_inputs", "gprhip_sharded_set_targets", "gprhip_sharded_eval", "gprhip_sharded_problem",
+              "gprhip_sharded_shard", "gprhip_shard_rows", "gprhip_sharded_comm_stats", "gprhip_condition",
+              "gprhip_problem_create_ex", "gprhip_problem_destroy", "gprhip_set_inputs", "gprhip_set_targets",
               "gprhip_eval", "gprhip_n_hypers", "gprhip_predict", "gprhip_train_stats", "gprhip_covariances",
               "gprhip_cov_samples", "gprhip_co_variance_coeffs", "gprhip_load_predictor", "gprhip_eval_pass1",
               "gprhip_eval_pass2", "gprhip_eval_finish", "gprhip_ar1_len", "gprhip_ar2_len", "gprhip_last_error"}
@@ -98,3 +101,74 @@ def test_ocaml_stub_sources_cover_the_abi():
     ml = open(os.path.join(root, "bindings", "gpr_hip.ml")).read()
     for ext in re.findall(r'= "(gprhip_ml_[a-z0-9_]+)"', ml) + re.findall(r'"(gprhip_ml_[a-z0-9_]+)"\s+"', ml):
         assert "value %s(" % ext in stubs, ext
+
+
+def _sig_vals(text, start_marker, end_marker):
+    """{module path: [val names]} of a module type in lib/interfaces.ml between two markers (comments stripped)."""
+    a = text.index(start_marker, text.index("module Sigs = struct"))
+    body = text[a:text.index(end_marker, a)]
+    # strip OCaml comments (they nest)
+    res, depth, i = [], 0, 0
+    while i < len(body):
+        if body.startswith("(*", i):
+            depth += 1
+            i += 2
+        elif body.startswith("*)", i) and depth > 0:
+            depth -= 1
+            i += 2
+        else:
+            if depth == 0:
+                res.append(body[i])
+            i += 1
+    body = "".join(res)
+    out, stack = {}, []
+    for line in body.splitlines():
+        m = re.match(r"\s*module (\w+) : sig", line)
+        if m:
+            stack.append(m.group(1))
+            continue
+        if re.match(r"\s*end\b", line) and stack:
+            stack.pop()
+            continue
+        m = re.match(r"\s*val (\w+)", line)
+        if m and stack:
+            out.setdefault(".".join(stack), []).append(m.group(1))
+    return out
+
+
+@pytest.mark.skipif(not os.path.exists("/root/reference/lib/interfaces.ml"),
+                    reason="the reference tree exists in the build container only")
+def test_ocaml_module_defines_every_value_of_the_reference_signature():
+    """bindings/gpr_hip.ml (uncompiled here: no OCaml toolchain) is ascribed to Gpr.Interfaces.Sigs.Deriv: every `val`
+    that signature lists under Eval.* and Deriv.* (lib/interfaces.ml:373-1154) must be defined in the module of the
+    same name inside Make_variant -- a textual check, the strongest one available without a compiler."""
+    ref = open("/root/reference/lib/interfaces.ml").read()
+    ml = open(os.path.join(ROOT, "bindings", "gpr_hip.ml")).read()
+    ml = ml[ml.index("module Make_variant"):ml.index("module Make_deriv (S : Device_spec)")]
+    ev = _sig_vals(ref, "  module type Eval = sig\n    module Spec : Specs.Eval", "  module type Deriv = sig\n    module Eval : Eval")
+    dv = _sig_vals(ref, "  module type Deriv = sig\n    module Eval : Eval", "  module type Optimizer = sig")
+    assert {"Inducing", "Inputs", "Model", "Trained", "Stats", "Means", "Variances", "Covariances", "Cov_sampler"} <= set(ev)
+    assert {"Deriv.Inducing", "Deriv.Inputs", "Deriv.Model", "Deriv.Trained", "Deriv.Test", "Deriv.Optim.Gsl",
+            "Deriv.Optim.SGD", "Deriv.Optim.SMD"} <= set(dv)
+
+    def module_body(path, text):
+        for name in path:
+            m = re.search(r"module %s\b[^=\n]*= struct" % name, text)
+            assert m, "gpr_hip.ml has no module %s" % ".".join(path)
+            text = text[m.end():]
+        return text
+
+    eval_body = module_body(["Eval"], ml)
+    deriv_body = ml[ml.index("  module Deriv = struct"):]
+    missing = []
+    for mod, vals in ev.items():
+        body = module_body(mod.split("."), eval_body)
+        for v in vals:
+            if not re.search(r"\blet (rec )?%s\b" % v, body):
+                missing.append("Eval.%s.%s" % (mod, v))
+    for mod, vals in dv.items():
+        body = module_body(mod.split(".")[1:], deriv_body)
+        for v in vals:
+            if not re.search(r"\blet (rec )?%s\b" % v, body):
+                missing.append("%s.%s" % (mod, v))
+    assert not missing, missing

@@ -1435,7 +1435,7 @@ def test_fp32_bulk_posterior_paths():
     """Prediction, training-set statistics and covariances on a problem created in the fp32-bulk mode (the n x m
     work of prediction and statistics runs in fp32 there; covariances are always fp64), against the fp64 oracle
     within the fp32 tolerances."""
-    n, m, d, nt = 4000, 120, 3, 500
+    n, m, d, nt = 4000, 120, 8, 500  # (8 dimensions: the fp32-bulk coefficients are refused when K_m is ill-conditioned)
     X, y, Z = synth(43, n, m, d)
     Xt = np.asfortranarray(np.random.default_rng(2).normal(size=(d, nt)))
     k = O.SeIsoKernel(0.4, 0.1)
@@ -1929,3 +1929,60 @@ def test_gradient_factors_against_differences_of_the_device_covariances(name):
         scale = max(abs(t) for t in terms) + 1e-300
         assert abs(fd - ev.grad[gi]) <= 2e-6 * scale + 1e-9, (label, fd, ev.grad[gi], terms)
     p.close()
+
+
+def test_fp32_bulk_refuses_coefficients_it_cannot_stand_behind(monkeypatch):
+    """fp32-bulk mean coefficients inherit cond(K_m + jitter) * 2^-24 (profiles/r04_f32_guard.txt): with many inducing
+    points in few dimensions they are wrong in the first digit, and the library refuses to predict from them
+    (GPRHIP_EPRECISION) instead of returning numbers -- the evidence and the gradient stay within their fp32-bulk
+    tolerances; the fp64 problem predicts; GPRHIP_F32_COEFF_TOL=0 lifts the guard; well-conditioned problems pass it."""
+    n, m, d = 4000, 200, 3
+    X, y, Z = synth(11, n, m, d)
+    hyp = dict(log_ell=0.5 * np.log(d), log_sf2=0.0, sigma2=0.1, inducing=Z)
+    Xt = X[:, :50]
+    p64 = gpr_amd.Problem(gpr_amd.COV_SE_ISO, n, d, d, m)
+    p64.set_inputs(X)
+    p64.set_targets(y)
+    e64 = p64.eval(**hyp)
+    cond64, bound64 = p64.condition()
+    km = p64.debug_fetch_matrix("km")
+    w = np.linalg.eigvalsh(km + np.triu(km, 1).T + gpr_amd.CHOLESKY_JITTER * np.eye(m))
+    assert 0.5 * w[-1] / w[0] <= cond64 <= 1.001 * w[-1] / w[0]  # a lower bound, close
+    assert bound64 < 1e-7
+    mean64, _ = p64.predict(Xt)
+    p32 = gpr_amd.Problem(gpr_amd.COV_SE_ISO, n, d, d, m, precision=gpr_amd.F32_BULK)
+    p32.set_inputs(X)
+    p32.set_targets(y)
+    e32 = p32.eval(**hyp)
+    assert abs(e32.l - e64.l) <= 3e-4 * abs(e64.l) and relinf(e32.grad, e64.grad) <= 1e-2
+    cond32, bound32 = p32.condition()
+    assert abs(cond32 - cond64) <= 1e-3 * cond64 and bound32 > 0.25
+    with pytest.raises(gpr_amd.UntrustworthyCoefficients) as ei:
+        p32.predict(Xt)
+    assert ei.value.status == gpr_amd._lib.EPRECISION and "cond(K_m + jitter)" in str(ei.value)
+    with pytest.raises(gpr_amd.UntrustworthyCoefficients):
+        p32.train_stats()
+    p32.close()
+    monkeypatch.setenv("GPRHIP_F32_COEFF_TOL", "0")
+    q = gpr_amd.Problem(gpr_amd.COV_SE_ISO, n, d, d, m, precision=gpr_amd.F32_BULK)
+    q.set_inputs(X)
+    q.set_targets(y)
+    q.eval(**hyp)
+    q.predict(Xt)  # no refusal with the guard off
+    q.close()
+    monkeypatch.delenv("GPRHIP_F32_COEFF_TOL")
+    # a well-conditioned problem (8 dimensions) passes the guard and its predictions agree with fp64
+    n, m, d = 4000, 200, 8
+    X, y, Z = synth(12, n, m, d)
+    hyp = dict(log_ell=0.5 * np.log(d), log_sf2=0.0, sigma2=0.1, inducing=Z)
+    res = {}
+    for prec in (gpr_amd.F64, gpr_amd.F32_BULK):
+        r = gpr_amd.Problem(gpr_amd.COV_SE_ISO, n, d, d, m, precision=prec)
+        r.set_inputs(X)
+        r.set_targets(y)
+        r.eval(**hyp)
+        res[prec] = (r.predict(X[:, :50])[0], r.condition())
+        r.close()
+    assert res[gpr_amd.F32_BULK][1][1] <= 0.25
+    assert relinf(res[gpr_amd.F32_BULK][0], res[gpr_amd.F64][0]) <= 5e-3
+    p64.close()
