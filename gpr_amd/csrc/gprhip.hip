@@ -115,6 +115,7 @@ struct gprhip_problem {
   // second stream: the covariance of the first row chunk runs beside the K_m factorisation (do_pass1)
   hipStream_t stream2 = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  hipEvent_t ev_rf = nullptr, ev_binv = nullptr;  // pass 2: R^-1 and B~^-1 come from the second stream (do_pass2)
   std::vector<void*> allocs;
 
   double *X = nullptr, *y = nullptr, *P = nullptr;
@@ -399,7 +400,7 @@ void potrf_trtri(gprhip_problem* p, double* A, double* X, double* tmp, int* info
 }
 
 // C (upper tiles) = X X^T for upper-triangular X: (U^T U)^-1 = U^-1 U^-T   (Utils.ichol, lib/utils.ml:110-113)
-void triu_xxt(gprhip_problem* p, const double* X, double* C) {
+void triu_xxt(gprhip_problem* p, const double* X, double* C, hipStream_t st) {
   GemmArgs g;
   g.A = X; g.lda = p->mp; g.B = X; g.ldb = p->mp; g.C = C; g.ldc = p->mp;
   g.M = p->mp; g.N = p->mp; g.K = p->mp; g.tri = TRI_KLO_MAX; g.upper_only = 1;
@@ -410,10 +411,10 @@ void triu_xxt(gprhip_problem* p, const double* X, double* C) {
     g.C = static_cast<double*>(p->slices);
     g.kslices = ks;
     g.slice_stride = mm;
-    launch_gemm(OP_NT, g, p->stream);
-    launch_sum_slices<double>(nullptr, static_cast<double*>(p->slices), ks, mm, p->mp, C, p->stream);
+    launch_gemm(OP_NT, g, st);
+    launch_sum_slices<double>(nullptr, static_cast<double*>(p->slices), ks, mm, p->mp, C, st);
   } else {
-    launch_gemm(OP_NT, g, p->stream);
+    launch_gemm(OP_NT, g, st);
   }
 }
 
@@ -702,11 +703,21 @@ void do_pass2(gprhip_problem* p, const double* ar1, double* ar2) {
   if (p->want_grad) GPR_HIP(hipMemsetAsync(ar2, 0, (size_t)gprhip_ar2_len(p) * sizeof(double), s));
   else GPR_HIP(hipMemsetAsync(ar2_tail, 0, (size_t)A2_TAIL * sizeof(double), s));
   if (p->want_grad) {
+    // B~^-1 = R~^-1 R~^-T (needed by the finish stage only) and R^-1 = U^-1 R~^-1 (needed by the first X product) do not
+    // belong on the chain between the factorisation and the Q' products: they go to the second stream and run beside
+    // the first chunk's Q' launch (0.28 ms of every gradient evaluation at m = 2048).  Both use the split-K scratch,
+    // which the main stream touches next in the pass-2 SYRK -- it waits for ev_binv before that.  (Under the per-stage
+    // timer everything stays on the main stream, so that "inverses" keeps its meaning.)
+    const bool side = !p->timer.on;
+    hipStream_t si = side ? p->stream2 : s;
+    if (side) {
+      GPR_HIP(hipEventRecord(p->ev_fork, s));  // R~^-1 (and its fp32 copy), t~, t are enqueued on s
+      GPR_HIP(hipStreamWaitEvent(p->stream2, p->ev_fork, 0));
+    }
     tstart(p, "inverses");
-    triu_xxt(p, p->rinv, p->binv);  // B~^-1 (upper tiles)
-    // The two-phase X product (below) needs R^-1 = U^-1 R~^-1, one more m x m product on the serial part of the
-    // evaluation (0.14 ms at m = 2048, 0.8 ms at m = 4096), and saves 2.5 us per 1000 training points at m = 2048 (6 us
-    // at m = 4096): taken from 48 m training points per shard on.
+    // The two-phase X product (below) needs R^-1 = U^-1 R~^-1, one more m x m product (0.14 ms at m = 2048, 0.8 ms at
+    // m = 4096), and saves 2.5 us per 1000 training points at m = 2048 (6 us at m = 4096): taken from 48 m training
+    // points per shard on.
     p->merged_x = p->merged_x_mode == 2 || (p->merged_x_mode == 1 && p->n >= 48 * (int64_t)p->m);
     if (p->merged_x) {
       GemmArgs rf;  // R^-1 = U^-1 R~^-1, both upper triangular
@@ -718,13 +729,16 @@ void do_pass2(gprhip_problem* p, const double* ar1, double* ar2) {
         rf.C = static_cast<double*>(p->slices);
         rf.kslices = rks;
         rf.slice_stride = mm;
-        launch_gemm(OP_NN, rf, s);
-        launch_sum_slices<double>(nullptr, static_cast<double*>(p->slices), rks, mm, mp, p->rfinv, s);
+        launch_gemm(OP_NN, rf, si);
+        launch_sum_slices<double>(nullptr, static_cast<double*>(p->slices), rks, mm, mp, p->rfinv, si);
       } else {
-        launch_gemm(OP_NN, rf, s);
+        launch_gemm(OP_NN, rf, si);
       }
-      if (p->f32) launch_to_float(p->rfinv, p->rfinv_f, mm, s);
+      if (p->f32) launch_to_float(p->rfinv, p->rfinv_f, mm, si);
     }
+    if (side) GPR_HIP(hipEventRecord(p->ev_rf, si));
+    triu_xxt(p, p->rinv, p->binv, si);  // B~^-1 (upper tiles)
+    if (side) GPR_HIP(hipEventRecord(p->ev_binv, si));
     tstop(p);
     bool derive_inducing = false;
     for (int c = 0; c < p->nchunks; ++c) {
@@ -754,6 +768,7 @@ void do_pass2(gprhip_problem* p, const double* ar1, double* ar2) {
         // X = diag(is) Q' R^-T - diag(v) V U^-T - w t^T  (S, U_mat and the ger of lib/fitc_gp.ml:931-939, :1204-1206) as
         // one launch of two-phase items: acc = V U^-T, rows scaled by -v/is, acc += Q' R^-T, epilogue is*acc - w t^T --
         // one epilogue per tile instead of two, no X~ round trip, no operand read in the epilogue
+        if (side && c == 0) GPR_HIP(hipStreamWaitEvent(s, p->ev_rf, 0));
         tstart(p, "p2_trmm_SX");
         GemmArgsT<TS> xg;
         xg.A = bufA; xg.lda = mp; xg.B = inv_rfull<TS>(p); xg.ldb = mp; xg.C = bufB; xg.ldc = mp;
@@ -835,6 +850,7 @@ void do_pass2(gprhip_problem* p, const double* ar1, double* ar2) {
     if (derive_inducing) launch_proj_inducing_grad(ar2_col, mp, p->d, p->D, p->tproj, s);
     // G~_part = V^T diag(v) V over all rows (the two dsyrk of lib/fitc_gp.ml:1198-1203, whitened, in one)
     const int64_t ktot = p->rows_total_padded();
+    if (side) GPR_HIP(hipStreamWaitEvent(s, p->ev_binv, 0));  // B~^-1 done: the split-K scratch is free again
     tstart(p, "p2_syrk_W");
     GemmArgsT<TS> wg;
     wg.A = Vstore; wg.lda = mp; wg.B = Vstore; wg.ldb = mp; wg.C = slices; wg.ldc = mp;
@@ -1531,6 +1547,8 @@ int gprhip_problem_create_ex(int device, int cov_kind, int precision, int64_t n,
     GPR_HIP(hipStreamCreate(&p->stream2));
     GPR_HIP(hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming));
     GPR_HIP(hipEventCreateWithFlags(&p->ev_join, hipEventDisableTiming));
+    GPR_HIP(hipEventCreateWithFlags(&p->ev_rf, hipEventDisableTiming));
+    GPR_HIP(hipEventCreateWithFlags(&p->ev_binv, hipEventDisableTiming));
     const int mp = p->mp;
     const int64_t mm = (int64_t)mp * mp;
     const int64_t npad = (int64_t)p->nchunks * chunk;
@@ -1620,6 +1638,8 @@ void gprhip_problem_destroy(gprhip_problem* p) {
   if (p->ex_host) hipHostFree(p->ex_host);
   if (p->ev_fork) hipEventDestroy(p->ev_fork);
   if (p->ev_join) hipEventDestroy(p->ev_join);
+  if (p->ev_rf) hipEventDestroy(p->ev_rf);
+  if (p->ev_binv) hipEventDestroy(p->ev_binv);
   if (p->timer.k0) {
     hipEventDestroy(p->timer.k0);
     hipEventDestroy(p->timer.k1);
