@@ -563,7 +563,10 @@ void do_pass1(gprhip_problem* p, const gprhip_hypers* h, int want_grad, int64_t 
     p->kstore_tried = true;
     size_t free_b = 0, total_b = 0;
     const size_t need = (size_t)p->nchunks * p->chunk * mp * sizeof(TS);
-    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b > need + (size_t(4) << 30)) {
+    // taken only while it leaves 4 GB free AND stays below 40 % of the device's memory: the copy is held for the life of
+    // the problem, and other problems (fitc_gp caches several per functor; other shards may share the device) must still
+    // find room.  GPRHIP_K_RESIDENT=0 never keeps it.
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b > need + (size_t(4) << 30) && need <= total_b / 5 * 2) {
       void* ptr = nullptr;
       if (hipMalloc(&ptr, need) == hipSuccess) {
         p->allocs.push_back(ptr);
@@ -1617,6 +1620,8 @@ int gprhip_problem_create_ex(int device, int cov_kind, int precision, int64_t n,
     p->ar1 = p->alloc<double>(gprhip_ar1_len(p));
     p->ar2 = p->alloc<double>(gprhip_ar2_len(p));
     GPR_HIP(hipMemsetAsync(p->y, 0, (size_t)npad * sizeof(double), p->stream));
+    // R^-1 is written on its upper tiles only; the fp32 conversion reads the whole square
+    GPR_HIP(hipMemsetAsync(p->rfinv, 0, (size_t)mm * sizeof(double), p->stream));
     GPR_HIP(hipStreamSynchronize(p->stream));
   });
 }

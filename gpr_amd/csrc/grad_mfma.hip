@@ -50,9 +50,9 @@ __global__ __launch_bounds__(256, (DT + BT <= 4 && KS4 <= 8) ? 2 : 1) void grad_
   // that and keep one staging buffer.
   constexpr bool PF = (DT <= 2 && BT <= 2);
   constexpr int NBUF = PF ? 2 : 1;
-  __shared__ double ps[NBUF * G_RC * LDP];
+  __shared__ double ps[KR ? 1 : NBUF * G_RC * LDP];
   __shared__ double bs[BT > 0 ? NBUF * G_RC * LDB : 1];
-  __shared__ double pn[NBUF * G_RC];
+  __shared__ double pn[KR ? 1 : NBUF * G_RC];
   __shared__ double red[4][2];
   __shared__ double sh[DP];  // the expansion offset, zero-padded
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -116,8 +116,8 @@ __global__ __launch_bounds__(256, (DT + BT <= 4 && KS4 <= 8) ? 2 : 1) void grad_
     for (int jt = 0; jt < 2; ++jt) {
       if constexpr (KR) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {  // padded rows and columns of X and K are zero
-          const double e = xv[jt][r];
+        for (int r = 0; r < 4; ++r) {  // (padded rows load zero; padded columns are masked, whatever K holds there)
+          const double e = live_c[jt] ? xv[jt][r] : 0.0;
           ev[jt][r] = e;
           cs[jt] += e;
           sE += e;
@@ -170,10 +170,12 @@ __global__ __launch_bounds__(256, (DT + BT <= 4 && KS4 <= 8) ? 2 : 1) void grad_
     const int br_ = tid / BP, bk = tid % BP;
     double pv[NPV], bv[NBV];
     auto fetch_pts = [&](int rb) {
+      if constexpr (!KR) {  // (K resident: neither distances nor the P^T E products need the points)
 #pragma unroll
-      for (int j = 0; j < NPV; ++j) {
-        const int row = rb + sr + RPP * j;
-        pv[j] = (sk < a.d && row < r1) ? a.pts[(int64_t)row * a.d + sk] - sh[sk] : 0.0;
+        for (int j = 0; j < NPV; ++j) {
+          const int row = rb + sr + RPP * j;
+          pv[j] = (sk < a.d && row < r1) ? a.pts[(int64_t)row * a.d + sk] - sh[sk] : 0.0;
+        }
       }
       if constexpr (BT > 0) {
 #pragma unroll
@@ -184,17 +186,19 @@ __global__ __launch_bounds__(256, (DT + BT <= 4 && KS4 <= 8) ? 2 : 1) void grad_
       }
     };
     auto store_pts = [&](int buf) {
+      if constexpr (!KR) {
 #pragma unroll
-      for (int j = 0; j < NPV; ++j) {
-        const int r = sr + RPP * j;
-        ps[buf * G_RC * LDP + r * LDP + sk] = pv[j];
-        double s2 = pv[j] * pv[j];
-        s2 += __shfl_xor(s2, 1);
-        s2 += __shfl_xor(s2, 2);
-        s2 += __shfl_xor(s2, 4);
-        s2 += __shfl_xor(s2, 8);
-        if constexpr (DP == 32) s2 += __shfl_xor(s2, 16);
-        if (sk == 0) pn[buf * G_RC + r] = s2;
+        for (int j = 0; j < NPV; ++j) {
+          const int r = sr + RPP * j;
+          ps[buf * G_RC * LDP + r * LDP + sk] = pv[j];
+          double s2 = pv[j] * pv[j];
+          s2 += __shfl_xor(s2, 1);
+          s2 += __shfl_xor(s2, 2);
+          s2 += __shfl_xor(s2, 4);
+          s2 += __shfl_xor(s2, 8);
+          if constexpr (DP == 32) s2 += __shfl_xor(s2, 16);
+          if (sk == 0) pn[buf * G_RC + r] = s2;
+        }
       }
       if constexpr (BT > 0) {
 #pragma unroll
@@ -226,9 +230,11 @@ __global__ __launch_bounds__(256, (DT + BT <= 4 && KS4 <= 8) ? 2 : 1) void grad_
   } else {
     for (int rb = r0; rb < r1; rb += G_RC) {
       __syncthreads();
-      for (int idx = tid; idx < G_RC * DP; idx += 256) {
-        const int r = idx / DP, k = idx % DP;
-        ps[r * LDP + k] = (k < a.d && rb + r < r1) ? a.pts[(int64_t)(rb + r) * a.d + k] - sh[k] : 0.0;
+      if constexpr (!KR) {
+        for (int idx = tid; idx < G_RC * DP; idx += 256) {
+          const int r = idx / DP, k = idx % DP;
+          ps[r * LDP + k] = (k < a.d && rb + r < r1) ? a.pts[(int64_t)(rb + r) * a.d + k] - sh[k] : 0.0;
+        }
       }
       if (BT > 0) {
         for (int idx = tid; idx < G_RC * BP; idx += 256) {
@@ -237,12 +243,14 @@ __global__ __launch_bounds__(256, (DT + BT <= 4 && KS4 <= 8) ? 2 : 1) void grad_
         }
       }
       __syncthreads();
-      if (tid < G_RC) {
-        double s2 = 0.0;
-        for (int k = 0; k < DP; ++k) s2 += ps[tid * LDP + k] * ps[tid * LDP + k];
-        pn[tid] = s2;
+      if constexpr (!KR) {
+        if (tid < G_RC) {
+          double s2 = 0.0;
+          for (int k = 0; k < DP; ++k) s2 += ps[tid * LDP + k] * ps[tid * LDP + k];
+          pn[tid] = s2;
+        }
+        __syncthreads();
       }
-      __syncthreads();
 #pragma unroll 1  // one row tile's worth of registers: two wavefronts per SIMD stay resident
       for (int rt = 0; rt < G_RC / 16; ++rt) {
         if (rb + rt * 16 >= r1) break;

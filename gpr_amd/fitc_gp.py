@@ -217,9 +217,10 @@ def _make_variant(spec, variational, functor, cov_kind="FITC"):
                              % (n_inducing, n_inputs))
 
     def choose(kernel, inputs, indexes):
-        """Inducing.choose (lib/fitc_gp.ml:62-64): Utils.choose_cols, then the spec's create_inducing."""
+        """Inducing.choose (lib/fitc_gp.ml:62-64): Utils.choose_cols, then the spec's create_inducing.  Returns the
+        inducing POINTS (Spec.Inducing.t, lib/interfaces.ml:382-395), which the caller hands to Inducing.calc."""
         chosen = np.asfortranarray(np.asarray(inputs, dtype=np.float64)[:, indexes])
-        return inducing_calc(kernel, spec.create_inducing(kernel, chosen))
+        return spec.create_inducing(kernel, chosen)
 
     def choose_n_first_inputs(kernel, inputs, n_inducing):
         check_n_inducing(n_inducing, inputs)                                            # :66-72

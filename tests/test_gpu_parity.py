@@ -622,8 +622,9 @@ def test_calc_model_inputs_family_and_inducing_choice():
     GP = fitc_gp.Make_deriv(cov_se_iso)
     for F, fic, variational in ((GP.FITC, False, False), (GP.FIC, True, False), (GP.Variational_FITC, False, True)):
         E = F.Eval
-        inducing = E.Inducing.choose_n_random_inputs(kernel, X, n_inducing=m, rnd_state=5)
-        Z = E.Inducing.get_points(inducing)
+        Z = E.Inducing.choose_n_random_inputs(kernel, X, n_inducing=m, rnd_state=5)  # Spec.Inducing.t: the points
+        inducing = E.Inducing.calc(kernel, Z)
+        assert E.Inducing.get_points(inducing) is Z
         assert Z.shape == (d, m) and len({tuple(c) for c in Z.T}) == m
         assert all(any(np.array_equal(c, x) for x in X.T) for c in Z.T[:5])
         model = E.Model.calc(E.Inputs.calc(X, inducing), sigma2=s2)
@@ -640,7 +641,7 @@ def test_calc_model_inputs_family_and_inducing_choice():
         assert np.max(np.abs(np.triu(got) - cref)) <= 1e-8 * np.max(np.abs(cref))
         assert np.allclose(np.diag(E.Covariances.get(c)), np.diag(cref) + s2, rtol=0, atol=1e-8)
     first = GP.FITC.Eval.Inducing.choose_n_first_inputs(kernel, X, n_inducing=m)
-    assert np.array_equal(GP.FITC.Eval.Inducing.get_points(first), X[:, :m])
+    assert np.array_equal(first, X[:, :m])
     GP.close()
     # Cov_se_fat: the chosen inputs are projected into the kernel's space (create_inducing = project, lib/cov_se_fat.ml:220)
     D, dd = 5, 2
@@ -648,8 +649,8 @@ def test_calc_model_inputs_family_and_inducing_choice():
     Xb = np.asfortranarray(rng.normal(size=(D, 300)) + 2.0)
     fk = cov_se_fat.Kernel.create(cov_se_fat.Params.create(dd, 0.1, tproj=rng.normal(size=(D, dd)) / np.sqrt(D)))
     GPf = fitc_gp.Make_deriv(cov_se_fat)
-    ind = GPf.FITC.Eval.Inducing.choose_n_first_inputs(fk, Xb, n_inducing=20)
-    Zf = GPf.FITC.Eval.Inducing.get_points(ind)
+    Zf = GPf.FITC.Eval.Inducing.choose_n_first_inputs(fk, Xb, n_inducing=20)
+    ind = GPf.FITC.Eval.Inducing.calc(fk, Zf)
     assert Zf.shape == (dd, 20) and np.allclose(Zf, fk.params.tproj.T @ Xb[:, :20], rtol=0, atol=1e-15)
     yb = np.sin(Xb.sum(0))
     tr = GPf.FITC.Eval.Trained.calc(GPf.FITC.Eval.Model.calc(GPf.FITC.Eval.Inputs.calc(Xb, ind), sigma2=0.1), targets=yb)

@@ -239,16 +239,17 @@ def test_inducing_choice_and_default_kernels_follow_the_reference():
     E = GP.FITC.Eval
     k = E.Inputs.create_default_kernel(X, n_inducing=7)
     assert k.get_params().log_ell == 0.0 and k.get_params().log_sf2 == 0.0
-    ind = E.Inducing.choose_n_first_inputs(k, X, n_inducing=7)
-    assert np.array_equal(E.Inducing.get_points(ind), X[:, :7])
+    pts = E.Inducing.choose_n_first_inputs(k, X, n_inducing=7)  # Spec.Inducing.t (the points), as in the reference
+    assert np.array_equal(pts, X[:, :7])
+    assert E.Inducing.get_points(E.Inducing.calc(k, pts)) is pts
     # the same partial shuffle, restated: step i swaps position i with a draw below n - i
     g = np.random.default_rng(11)
     idx = list(range(50))
     for i in range(9):
         j = int(g.integers(50 - i))
         idx[j], idx[i] = idx[i], idx[j]
-    ind = E.Inducing.choose_n_random_inputs(k, X, n_inducing=9, rnd_state=11)
-    assert np.array_equal(E.Inducing.get_points(ind), X[:, idx[:9]])
+    pts = E.Inducing.choose_n_random_inputs(k, X, n_inducing=9, rnd_state=11)
+    assert np.array_equal(pts, X[:, idx[:9]])
     assert len(set(idx[:9])) == 9
     with pytest.raises(ValueError, match=r"check_n_inducing: violating 1 <= n_inducing \(51\) <= n_inputs \(50\)"):
         E.Inducing.choose_n_random_inputs(k, X, n_inducing=51)
@@ -264,5 +265,5 @@ def test_inducing_choice_and_default_kernels_follow_the_reference():
     assert np.all(np.abs(pf.tproj) <= bound[:, None] * (1 + 1e-15))
     assert np.array_equal(pf.log_hetero_skedasticity, np.full(6, -5.0)) and pf.log_multiscales_m05.shape == (10, 6)
     assert not np.any(pf.log_multiscales_m05)
-    indf = GPf.FITC.Eval.Inducing.choose_n_first_inputs(kf, Xb, n_inducing=6)
-    assert np.allclose(GPf.FITC.Eval.Inducing.get_points(indf), pf.tproj.T @ Xb[:, :6], rtol=0, atol=1e-14)
+    ptsf = GPf.FITC.Eval.Inducing.choose_n_first_inputs(kf, Xb, n_inducing=6)
+    assert np.allclose(ptsf, pf.tproj.T @ Xb[:, :6], rtol=0, atol=1e-14)
