@@ -169,6 +169,29 @@ def other_configs(gpr_amd, steps=2):
     return out
 
 
+def context_entry(gpr_amd, n, m, d, seed, steps=2):
+    """The same evaluation through the C ABI's single-process multi-device entry (gprhip_ctx_create /
+    gprhip_sharded_eval -- what the reference's one-process host binds) on the one device this run has: outside the
+    headline's timed region; shows the entry adds nothing to the evaluation it wraps."""
+    X, y, Z = synth(seed, n, m, d)
+    ctx = gpr_amd.Context([0])
+    sp = gpr_amd.ShardedDeviceProblem(ctx, gpr_amd.COV_SE_ISO, n, d, d, m)
+    sp.set_inputs(X)
+    sp.set_targets(y)
+    kw = dict(log_ell=0.5 * np.log(d), log_sf2=0.0, sigma2=0.1, inducing=Z)
+    sp.eval(**kw)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        ev = sp.eval(**kw)
+    dt = (time.perf_counter() - t0) / steps
+    out = {"devices": [0], "comm_mode": {0: "none", 1: "rccl", 2: "same-device sum"}[ctx.comm_mode],
+           "ms_per_eval": dt * 1e3, "points_per_s": n / dt, "collectives_per_eval": sp.comm_stats()["collectives"],
+           "l": float(ev.l)}
+    sp.close()
+    ctx.close()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -352,6 +375,7 @@ def main():
         if comm:
             line["multi_gpu"] = comm
         if world == 1 and not args.no_configs:
+            line["single_process_context"] = context_entry(gpr_amd, n, m, d, seed)
             line["configs"] = other_configs(gpr_amd)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(m, d, seed)

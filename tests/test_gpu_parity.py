@@ -1469,6 +1469,15 @@ def test_random_shapes_against_oracle(seed):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(8))
+def test_random_shapes_through_the_context(seed):
+    """The same random-shape cases evaluated by the single-process multi-device entry (gprhip_sharded_eval) over 2..5
+    shards of the one device a test box has: ragged shards, every kernel option, standard and variational, with and
+    without row chunks inside a shard -- against the oracle at the unsharded tolerances."""
+    _random_shape_case(seed, shards=2 + seed % 4)
+
+
+@pytest.mark.gpu
 def test_random_shapes_long_sweep():
     """The same sweep over a seed range given in GPR_FUZZ_SEEDS="lo:hi" (skipped without it): the long runs whose logs
     are kept under profiles/ (r03_fuzz.txt: seeds 24..423)."""
@@ -1477,16 +1486,31 @@ def test_random_shapes_long_sweep():
         pytest.skip("GPR_FUZZ_SEEDS not set")
     lo, hi = (int(v) for v in spec.split(":"))
     bad = []
+    shards = int(os.environ.get("GPR_FUZZ_SHARDS", "0"))  # > 0: through the context, seed-dependent shard counts up to it
     for seed in range(lo, hi):
         try:
-            _random_shape_case(seed)
+            _random_shape_case(seed, shards=(2 + seed % (shards - 1)) if shards > 1 else 0)
         except AssertionError as e:  # keep going: the log should name every failing seed
             bad.append((seed, str(e)[:200]))
     print("random-shape sweep: seeds %d..%d, %d cases, %d failures %s" % (lo, hi - 1, hi - lo, len(bad), bad))
     assert not bad, bad
 
 
-def _random_shape_case(seed):
+class _ShardedAsProblem:
+    """A gpr_amd.ShardedDeviceProblem over `shards` shards of cuda:0 (the context's validation mode) with the small part
+    of gpr_amd.Problem's surface the random-shape cases use."""
+
+    def __init__(self, kind, n, D, d, m, shards, chunk_rows=0):
+        self.ctx = gpr_amd.Context([0] * shards)
+        self.sp = gpr_amd.ShardedDeviceProblem(self.ctx, kind, n, D, d, m, chunk_rows=chunk_rows)
+        self.set_inputs, self.set_targets, self.eval = self.sp.set_inputs, self.sp.set_targets, self.sp.eval
+
+    def close(self):
+        self.sp.close()
+        self.ctx.close()
+
+
+def _random_shape_case(seed, shards=0):
     rng = np.random.default_rng(1000 + seed)
     iso = seed % 2 == 0   # (the oracle forms one dense n x m derivative matrix per Proj hyper: smaller fat cases)
     n = int(rng.integers(300, 6000 if iso else 3000))
@@ -1503,7 +1527,8 @@ def _random_shape_case(seed):
             Z = np.asfortranarray(np.hstack([Z, rng.normal(size=(d, m - n))]))
         log_ell = 0.5 * np.log(d) + rng.uniform(-0.3, 0.3)
         k = O.SeIsoKernel(log_ell, rng.uniform(-0.5, 0.5))
-        p = gpr_amd.Problem(gpr_amd.COV_SE_ISO, n, d, d, m, chunk_rows=chunk_rows)
+        p = (gpr_amd.Problem(gpr_amd.COV_SE_ISO, n, d, d, m, chunk_rows=chunk_rows) if not shards
+             else _ShardedAsProblem(gpr_amd.COV_SE_ISO, n, d, d, m, shards, chunk_rows))
         args = dict(log_ell=k.log_ell, log_sf2=k.log_sf2)
     else:
         D = d + int(rng.integers(0, 4))
@@ -1515,7 +1540,8 @@ def _random_shape_case(seed):
         het = rng.uniform(-6, -3, size=m) if rng.integers(0, 2) else None
         ms = rng.uniform(-0.5, 0.5, size=(d, m)) if (rng.integers(0, 3) == 0 and D <= 32) else None
         k = O.SeFatKernel(d, rng.uniform(-0.5, 0.5), P, het, ms)
-        p = gpr_amd.Problem(gpr_amd.COV_SE_FAT, n, D, d, m, chunk_rows=chunk_rows)
+        p = (gpr_amd.Problem(gpr_amd.COV_SE_FAT, n, D, d, m, chunk_rows=chunk_rows) if not shards
+             else _ShardedAsProblem(gpr_amd.COV_SE_FAT, n, D, d, m, shards, chunk_rows))
         args = dict(log_sf2=k.log_sf2)
         if P is not None:
             args["tproj"] = P
@@ -1793,6 +1819,39 @@ def test_context_eight_way_partition_at_4096_inducing_points():
     assert abs(ev.dl_dsigma2 - ref.dl_dsigma2) <= 10 * TOL_SHARD * abs(ref.dl_dsigma2)
     assert relinf(ev.grad, ref.grad) <= 100 * TOL_SHARD
     assert relinf(ev.coeffs, ref.coeffs) <= 1e-6  # cond(K_m) at m = 4096, d = 16 amplifies the summation-order difference
+
+
+def test_context_posterior_paths_from_any_shard():
+    """After a sharded evaluation the m x m model state is replicated: prediction, covariances and the export of the
+    factors work on every shard's problem and agree with the unsharded problem; training statistics are per shard and
+    combine with sum / sum / max / sum."""
+    g = load_golden("posterior_iso")
+    X, y, Z, Xt = g["X"], g["y"], g["Z"], g["Xt"]
+    hyp = dict(log_ell=float(g["log_ell"]), log_sf2=float(g["log_sf2"]), sigma2=float(g["sigma2"]), inducing=Z)
+    p = _problem_for(g)
+    p.eval(**hyp)
+    mean, var = p.predict(Xt)
+    sums, _ = p.train_stats()
+    u, r = p.co_variance_coeffs()
+    p.close()
+    ctx = gpr_amd.Context([0, 0, 0])
+    sp = gpr_amd.ShardedDeviceProblem(ctx, gpr_amd.COV_SE_ISO, X.shape[1], X.shape[0], Z.shape[0], Z.shape[1])
+    sp.set_inputs(X)
+    sp.set_targets(y)
+    sp.eval(**hyp)
+    acc = np.zeros(4)
+    for i in range(3):
+        q = sp.problem(i)
+        mi, vi = q.predict(Xt)
+        assert relinf(mi, mean) <= 100 * TOL_SHARD and relinf(vi, var) <= 100 * TOL_SHARD
+        si, _ = q.train_stats()
+        acc[[0, 1, 3]] += si[[0, 1, 3]]
+        acc[2] = max(acc[2], si[2])
+    assert relinf(acc, sums) <= 100 * TOL_SHARD
+    ui, ri = sp.problem(2).co_variance_coeffs()
+    assert relinf(ui, u) <= 100 * TOL_SHARD and relinf(ri, r) <= 100 * TOL_SHARD
+    sp.close()
+    ctx.close()
 
 
 def test_context_argument_checks():
