@@ -28,7 +28,12 @@ LDS map (bytes; one workgroup = 73728): A image of stage buffer b at b*18432, B 
       4q+e and 4q+e+2 (512 B each) to chunk 2q+e at (2q+e)*1088, so k and k+1 differ by 64 B mod 128 B in bank space;
   per-k weights of the stage (128 B) at +18304 of the A image (w) and of the B image (w2, column-sum weights).
 """
+import os
 import sys
+
+# engine lab (timing only, results wrong): GEN_NOBARRIER=1 leaves the per-stage s_barrier out of the generated loops --
+# what the workgroup barrier itself costs (tools/lab16.sh)
+NOBARRIER = os.environ.get("GEN_NOBARRIER") == "1"
 
 OPSZ = 18432           # bytes per operand image
 BUFSZ = OPSZ           # stage buffer b of an operand sits at b*OPSZ from the operand's base
@@ -174,7 +179,8 @@ def gen(c):
             mfmas(kk & 1, lv(kk))
         # last k-step: everything this wave read from buffer b has arrived; its DMA into the other buffer has landed
         emit("s_waitcnt vmcnt(0) lgkmcnt(0)")
-        emit("s_barrier")
+        if not NOBARRIER:
+            emit("s_barrier")
         emit("s_cmp_lt_u32 %[rem], 3")          # a stage after the next one? -> refill this buffer
         emit("s_cbranch_scc1 5f")
         dma(b)
