@@ -88,6 +88,8 @@ external sharded_set_inputs : sharded -> mat -> unit = "gprhip_ml_sharded_set_in
 external sharded_set_targets : sharded -> vec -> unit = "gprhip_ml_sharded_set_targets"
 external sharded_eval : sharded -> hypers -> bool -> vec -> vec -> float * float * float * float * int
   = "gprhip_ml_sharded_eval"
+external sharded_predict : sharded -> mat -> bool -> vec -> vec option -> unit = "gprhip_ml_sharded_predict"
+external sharded_train_stats : sharded -> vec option -> vec -> unit = "gprhip_ml_sharded_train_stats"
 external sharded_comm_stats : sharded -> int * (int * int) * (float * float) = "gprhip_ml_sharded_comm_stats"
 external sharded_set_timing : sharded -> int -> unit = "gprhip_ml_sharded_set_timing"
 
@@ -420,14 +422,8 @@ module Make_variant
       let sums (trained : Trained.t) =
         Trained.ensure_state trained;
         let dev = Lazy.force trained.Trained.model.Model.inputs.Inputs.dev in
-        let acc = Vec.make0 4 and part = Vec.create 4 in
-        for i = 0 to ctx_ndev (Lazy.force context) - 1 do
-          train_stats (sharded_problem dev.sp i) None part;
-          acc.{1} <- acc.{1} +. part.{1};
-          acc.{2} <- acc.{2} +. part.{2};
-          acc.{3} <- max acc.{3} part.{3};
-          acc.{4} <- acc.{4} +. part.{4}
-        done;
+        let acc = Vec.create 4 in
+        sharded_train_stats dev.sp None acc;
         acc
 
       let calc_n_samples (trained : Trained.t) = Vec.dim trained.Trained.targets
@@ -511,14 +507,12 @@ module Make_variant
       let calc mean_predictor (inputs : Inputs.t) =
         same_inducing (Mean_predictor.get_inducing mean_predictor) inputs.Inputs.inducing.Inducing.points "Means.calc";
         let means = Vec.create (Spec.Inputs.get_n_points inputs.Inputs.points) in
-        let p =
-          match mean_predictor with
-          | Mean_predictor.Of_trained trained ->
-              Trained.ensure_state trained;
-              Trained.problem trained
-          | Mean_predictor.Stored s -> load_stored inputs ~sigma2:0. ~coeffs:s.coeffs ()
-        in
-        predict p inputs.Inputs.points false means None;
+        (match mean_predictor with
+        | Mean_predictor.Of_trained trained ->
+            (* the trained model's state is replicated on every device: the test points are split over all of them *)
+            Trained.ensure_state trained;
+            sharded_predict (Lazy.force trained.Trained.model.Model.inputs.Inputs.dev).sp inputs.Inputs.points false means None
+        | Mean_predictor.Stored s -> predict (load_stored inputs ~sigma2:0. ~coeffs:s.coeffs ()) inputs.Inputs.points false means None);
         { points = inputs.Inputs.points; means }
 
       let get t = t.means

@@ -411,6 +411,29 @@ CAMLprim value gprhip_ml_sharded_eval(value sp, value h, value want_grad, value 
   CAMLreturn(res);
 }
 
+/* external sharded_predict : sharded -> mat -> predictive:bool -> means:vec -> variances:vec option -> unit */
+CAMLprim value gprhip_ml_sharded_predict(value sp, value points, value predictive, value means, value variances) {
+  CAMLparam5(sp, points, predictive, means, variances);
+  struct caml_ba_array* ba = Caml_ba_array_val(points);
+  gprhip_sharded* s = Sharded_val(sp);
+  const double* x = (const double*)ba->data;
+  int64_t ld = ba->dim[0], nt = ba->dim[1];
+  double* mu = (double*)Caml_ba_data_val(means);
+  double* var = (double*)opt_data(variances);
+  int pr = Bool_val(predictive), status;
+  caml_release_runtime_system();
+  status = gprhip_sharded_predict(s, x, ld, nt, pr, mu, var);
+  caml_acquire_runtime_system();
+  check(status);
+  CAMLreturn(Val_unit);
+}
+/* external sharded_train_stats : sharded -> means:vec option -> sums:vec -> unit */
+CAMLprim value gprhip_ml_sharded_train_stats(value sp, value means, value sums) {
+  CAMLparam3(sp, means, sums);
+  check(gprhip_sharded_train_stats(Sharded_val(sp), (double*)opt_data(means), (double*)Caml_ba_data_val(sums)));
+  CAMLreturn(Val_unit);
+}
+
 /* external sharded_comm_stats : sharded -> int * (int * int) * (float * float)   collectives, bytes, milliseconds */
 CAMLprim value gprhip_ml_sharded_comm_stats(value sp) {
   CAMLparam1(sp);

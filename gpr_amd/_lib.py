@@ -105,6 +105,8 @@ SIGNATURES = {
     "gprhip_sharded_set_inputs": (C.c_int, [_vp, _dp, C.c_int64]),
     "gprhip_sharded_set_targets": (C.c_int, [_vp, _dp]),
     "gprhip_sharded_eval": (C.c_int, [_vp, C.POINTER(Hypers), C.c_int, C.POINTER(Result), _dp, _dp]),
+    "gprhip_sharded_predict": (C.c_int, [_vp, _dp, C.c_int64, C.c_int64, C.c_int, _dp, _dp]),
+    "gprhip_sharded_train_stats": (C.c_int, [_vp, _dp, _dp]),
     "gprhip_sharded_comm_stats": (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int64), C.POINTER(C.c_float)]),
     "gprhip_sharded_set_timing": (C.c_int, [_vp, C.c_int]),
     "gprhip_last_error": (C.c_char_p, []),

@@ -130,6 +130,25 @@ class ShardedDeviceProblem:
         return Evaluation(res.l1, res.l2, res.l, res.dl_dsigma2 if want_grad else None,
                           grad[:res.n_hypers] if want_grad else None, coeffs)
 
+    def predict(self, test_inputs, predictive=True, want_variances=True):
+        """Means.calc / Variances.calc at test points (D x nt), the test points split over the devices."""
+        xt = np.asfortranarray(test_inputs, dtype=np.float64)
+        if xt.ndim != 2 or xt.shape[0] != self.D:
+            raise ValueError("predict: expected test inputs of shape (%d, nt)" % self.D)
+        nt = xt.shape[1]
+        means = np.empty(nt, dtype=np.float64)
+        var = np.empty(nt, dtype=np.float64) if want_variances else None
+        _lib.check(self._lib.gprhip_sharded_predict(self._h, _f64_ptr(xt), self.D, nt, int(predictive), _f64_ptr(means),
+                                                    _f64_ptr(var) if want_variances else None))
+        return means, var
+
+    def train_stats(self, want_means=False):
+        """Residual sums of the whole training set (all shards): ([sse, sum|y-mean|, max|y-mean|, sum y^2], means or None)."""
+        sums = np.empty(4, dtype=np.float64)
+        means = np.empty(self.n, dtype=np.float64) if want_means else None
+        _lib.check(self._lib.gprhip_sharded_train_stats(self._h, _f64_ptr(means) if want_means else None, _f64_ptr(sums)))
+        return sums, means
+
     def set_timing(self, level):
         _lib.check(self._lib.gprhip_sharded_set_timing(self._h, int(level)))
 

@@ -476,6 +476,44 @@ int gprhip_sharded_eval(gprhip_sharded* sp, const gprhip_hypers* h, int want_gra
   });
 }
 
+int gprhip_sharded_predict(gprhip_sharded* sp, const double* test_inputs, int64_t ld, int64_t nt, int predictive,
+                           double* means, double* variances) {
+  return guarded([&] {
+    if (!sp || !test_inputs || nt < 1) fail(GPRHIP_EBADARG, "gprhip_sharded_predict: invalid arguments");
+    const int nd = (int)sp->parts.size();
+    if (nt < nd) {  // fewer points than devices: the first shard serves them
+      const int st = gprhip_predict(sp->parts[0], test_inputs, ld, nt, predictive, means, variances);
+      if (st != GPRHIP_OK) throw HipFail{st};
+      return;
+    }
+    for_all(sp, [&](int i) {
+      int64_t lo = 0, hi = 0;
+      int st = gprhip_shard_rows(nt, nd, i, &lo, &hi);
+      if (st != GPRHIP_OK) return st;
+      return gprhip_predict(sp->parts[i], test_inputs + lo * ld, ld, hi - lo, predictive, means ? means + lo : nullptr,
+                            variances ? variances + lo : nullptr);
+    });
+  });
+}
+
+int gprhip_sharded_train_stats(gprhip_sharded* sp, double* means, double* sums) {
+  return guarded([&] {
+    if (!sp || !sums) fail(GPRHIP_EBADARG, "gprhip_sharded_train_stats: invalid arguments");
+    const int nd = (int)sp->parts.size();
+    std::vector<double> part((size_t)nd * 4, 0.0);
+    for_all(sp, [&](int i) {
+      return gprhip_train_stats(sp->parts[i], means ? means + sp->lo[i] : nullptr, part.data() + (size_t)i * 4);
+    });
+    sums[0] = sums[1] = sums[2] = sums[3] = 0.0;
+    for (int i = 0; i < nd; ++i) {  // fixed order: reproducible
+      sums[0] += part[(size_t)i * 4 + 0];
+      sums[1] += part[(size_t)i * 4 + 1];
+      sums[2] = std::max(sums[2], part[(size_t)i * 4 + 2]);
+      sums[3] += part[(size_t)i * 4 + 3];
+    }
+  });
+}
+
 int gprhip_sharded_comm_stats(const gprhip_sharded* sp, int* collectives, int64_t bytes[2], float ms[2]) {
   return guarded([&] {
     if (!sp) fail(GPRHIP_EBADARG, "gprhip_sharded_comm_stats: NULL argument");

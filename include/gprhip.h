@@ -202,6 +202,13 @@ int gprhip_sharded_set_targets(gprhip_sharded* sp, const double* targets);      
 /* As gprhip_eval. */
 int gprhip_sharded_eval(gprhip_sharded* sp, const gprhip_hypers* h, int want_grad, gprhip_result* res, double* grad,
                         double* coeffs);
+/* Posterior prediction with all devices (gprhip_predict on every shard's problem for its share of the test points --
+ * the model state is replicated, the test points are split like the training rows): means / variances as there. */
+int gprhip_sharded_predict(gprhip_sharded* sp, const double* test_inputs, int64_t ld, int64_t nt, int predictive,
+                           double* means, double* variances);
+/* Training-set statistics over all shards (gprhip_train_stats per shard, combined sum / sum / max / sum): means (n,
+ * whole problem, may be NULL) and sums[4]. */
+int gprhip_sharded_train_stats(gprhip_sharded* sp, double* means, double* sums);
 /* Exchange steps of the last evaluation: their count (1 evidence-only, 2 gradient; 0 with one device and no forced
  * RCCL), bytes per device of each, and -- after gprhip_sharded_set_timing(sp, 1) -- their milliseconds on the first
  * shard's stream (HIP events; includes waiting for the slowest shard). */

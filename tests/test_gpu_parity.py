@@ -1850,6 +1850,13 @@ def test_context_posterior_paths_from_any_shard():
     assert relinf(acc, sums) <= 100 * TOL_SHARD
     ui, ri = sp.problem(2).co_variance_coeffs()
     assert relinf(ui, u) <= 100 * TOL_SHARD and relinf(ri, r) <= 100 * TOL_SHARD
+    # the sharded entry points: test points split over the devices, statistics combined by the library
+    ms, vs = sp.predict(Xt)
+    assert relinf(ms, mean) <= 100 * TOL_SHARD and relinf(vs, var) <= 100 * TOL_SHARD
+    m1, v1 = sp.predict(Xt[:, :2], want_variances=False)  # fewer points than shards
+    assert v1 is None and relinf(m1, mean[:2]) <= 100 * TOL_SHARD
+    ss, tm = sp.train_stats(want_means=True)
+    assert relinf(ss, sums) <= 100 * TOL_SHARD and relinf(tm, g["train_means"]) <= 1e-7
     sp.close()
     ctx.close()
 
