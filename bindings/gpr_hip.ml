@@ -531,18 +531,15 @@ module Make_variant
       let calc co_variance_predictor ~sigma2 (inputs : Inputs.t) =
         let nt = Spec.Inputs.get_n_points inputs.Inputs.points in
         let means = Vec.create nt and variances = Vec.create nt in
-        let p =
-          match co_variance_predictor with
-          | Co_variance_predictor.Of_model model ->
-              same_inducing model.Model.inputs.Inputs.inducing.Inducing.points inputs.Inputs.inducing.Inducing.points
-                "Variances.calc";
-              Model.ensure_state model;
-              (Lazy.force model.Model.inputs.Inputs.dev).first
-          | Co_variance_predictor.Stored s ->
-              same_inducing s.inducing inputs.Inputs.inducing.Inducing.points "Variances.calc";
-              load_stored inputs ~sigma2 ~factors:s.coeffs ()
-        in
-        predict p inputs.Inputs.points false means (Some variances);
+        (match co_variance_predictor with
+        | Co_variance_predictor.Of_model model ->
+            same_inducing model.Model.inputs.Inputs.inducing.Inducing.points inputs.Inputs.inducing.Inducing.points
+              "Variances.calc";
+            Model.ensure_state model;
+            sharded_predict (Lazy.force model.Model.inputs.Inputs.dev).sp inputs.Inputs.points false means (Some variances)
+        | Co_variance_predictor.Stored s ->
+            same_inducing s.inducing inputs.Inputs.inducing.Inducing.points "Variances.calc";
+            predict (load_stored inputs ~sigma2 ~factors:s.coeffs ()) inputs.Inputs.points false means (Some variances));
         { points = inputs.Inputs.points; variances; sigma2 }
 
       (* lib/fitc_gp.ml:487-496: at the model's own inputs the same numbers Variances.calc gives there *)

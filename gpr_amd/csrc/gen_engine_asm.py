@@ -41,9 +41,14 @@ WOFF = 18304           # weights of the stage inside an operand image
 
 
 class Cfg:
-    def __init__(self, f64, op, var, diag=None, cont=False):
+    def __init__(self, f64, op, var, diag=None, cont=False, desc=False):
         self.f64, self.op, self.var, self.diag = f64, op, var, diag
         self.cont = cont                    # second phase of a two-phase item: the accumulators are kept, not zeroed
+        # the k-range is walked from its last stage down to its first (the operand bases step backwards): the second,
+        # short item of a column-tile pair of a triangular NN product then reads the A blocks its seven neighbours on
+        # the XCD read at the same time (mfma_gemm.hip: tile_of_block).  diag "khid": the diagonal block of B, which
+        # ends the k-range, is visited first, its stages in reverse order.
+        self.desc = desc or diag == "khid"
         self.nkk = 4 if f64 else 8          # k-steps (of 4) per stage
         self.fw = 2 if f64 else 1           # dwords per fragment element
         self.aw = 8 if f64 else 4           # accumulator registers per 16x16 sub-tile
@@ -55,8 +60,8 @@ class Cfg:
     def name(self):
         return "ENGINE_LOOP_%s_%s%s%s%s" % ("F64" if self.f64 else "F32", self.op.upper(),
                                             {0: "", 1: "_W", 2: "_WS"}[self.var],
-                                            {None: "", "khi": "_KHI", "klo": "_KLO", "sy": "_SY"}[self.diag],
-                                            "_CONT" if self.cont else "")
+                                            {None: "", "khi": "_KHI", "klo": "_KLO", "sy": "_SY", "khid": "_KHID"}[self.diag],
+                                            ("_CONT" if self.cont else "") + ("_DESC" if self.desc and self.diag != "khid" else ""))
 
 
 def reg(base, width):
@@ -164,11 +169,17 @@ def gen(c):
             emit("4:")
             emit("s_add_u32 s90, s90, 128")
             emit("s_addc_u32 s91, s91, 0")
-        # advance the operand bases to the next stage
-        emit("s_add_u32 s84, s84, %[stepA]")
-        emit("s_addc_u32 s85, s85, 0")
-        emit("s_add_u32 s86, s86, %[stepB]")
-        emit("s_addc_u32 s87, s87, 0")
+        # advance the operand bases to the next stage (descending walks: the previous one)
+        if c.desc:
+            emit("s_sub_u32 s84, s84, %[stepA]")
+            emit("s_subb_u32 s85, s85, 0")
+            emit("s_sub_u32 s86, s86, %[stepB]")
+            emit("s_subb_u32 s87, s87, 0")
+        else:
+            emit("s_add_u32 s84, s84, %[stepA]")
+            emit("s_addc_u32 s85, s85, 0")
+            emit("s_add_u32 s86, s86, %[stepB]")
+            emit("s_addc_u32 s87, s87, 0")
 
     # ---- one k-stage out of buffer b
     def stage(b, exit_label, live=None, tail=None):
@@ -206,7 +217,7 @@ def gen(c):
     def diag_live(u, wc):
         def f(kk):
             kpos = 4 * (u * nkk + kk)
-            if c.diag == "khi":
+            if c.diag in ("khi", "khid"):
                 return tuple(j for j in range(4) if kpos <= 16 * (wc + 2 * j) + 15)
             return tuple(j for j in range(4) if kpos + 3 >= 16 * (wc + 2 * j))
         return f
@@ -214,7 +225,9 @@ def gen(c):
     def diag_section(b0, wc, end_label):
         for u in range(DSTAGES):
             last = u == DSTAGES - 1
-            stage((b0 + u) & 1, end_label if (last or c.diag == "klo") else None, live=diag_live(u, wc))
+            # "khid": the v-th stage visited is stage DSTAGES-1-v of the block
+            ub = DSTAGES - 1 - u if c.diag == "khid" else u
+            stage((b0 + u) & 1, end_label if (last or c.diag in ("klo", "khid")) else None, live=diag_live(ub, wc))
 
     # ================= program: two asm statements per output tile =================
     # PRO : fetch of the tile's first k-stage (issued by the HIP code before the previous tile's epilogue, so the
@@ -316,14 +329,17 @@ def gen(c):
 def main():
     out = ["// Generated by gen_engine_asm.py -- do not edit.", ""]
     for f64 in (True, False):
-        for op, var, diag, cont in (("nn", 0, None, False), ("nt", 0, None, False), ("tn", 0, None, False),
-                                    ("tn", 1, None, False), ("tn", 2, None, False), ("nn", 0, "khi", False),
-                                    ("nt", 0, "klo", False), ("tn", 1, "sy", False), ("tn", 2, "sy", False),
-                                    ("nt", 0, None, True), ("nt", 0, "klo", True)):
-            c = Cfg(f64, op, var, diag, cont)
+        for op, var, diag, cont, desc in (("nn", 0, None, False, False), ("nt", 0, None, False, False),
+                                          ("tn", 0, None, False, False), ("tn", 1, None, False, False),
+                                          ("tn", 2, None, False, False), ("nn", 0, "khi", False, False),
+                                          ("nt", 0, "klo", False, False), ("tn", 1, "sy", False, False),
+                                          ("tn", 2, "sy", False, False), ("nt", 0, None, True, False),
+                                          ("nt", 0, "klo", True, False), ("nn", 0, None, False, True),
+                                          ("nn", 0, "khid", False, False)):
+            c = Cfg(f64, op, var, diag, cont, desc)
             for part, lines in zip(("PRO", "MAIN"), gen(c)):
                 if (diag or cont) and part == "PRO":
-                    continue   # same fetch as the plain variant
+                    continue   # same fetch as the plain variant (khid: as the plain descending one)
                 out.append("#define %s \\" % c.name().replace("LOOP", part))
                 for ln in lines:
                     out.append('  "%s\\n\\t" \\' % ln)

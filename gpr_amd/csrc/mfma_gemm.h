@@ -45,6 +45,9 @@ struct GemmArgsT {
   int upper_only = 0;    // compute only tiles with row tile <= column tile
   int order = 0;         // block -> tile order of full grids (see tile_of_block)
   int ipw = 1;           // items per workgroup (set by launch_gemm: 2 for the paired order 3)
+  int desc2 = 0;         // set by launch_gemm (paired NN products with a triangular B): the second, short item of a pair walks
+                         // its k-range downwards, so that the eight short items of a row panel read the same A block at the
+                         // same time (GPRHIP_NN_DESC=0 switches it off)
   int syrk = 0;          // set by launch_gemm: weighted TN launch with A == B and upper_only (diagonal tiles skip their lower sub-tiles)
   int sgroup = 16;       // set by launch_gemm: slices per group of the SYRK item order (tile_of_block); 1 = slice by slice
   int dslices = 0;       // set by launch_gemm: k-slices of the diagonal tiles of such a launch (gemm_syrk_diag_slices), 0 = as kslices
