@@ -142,6 +142,7 @@ struct gprhip_problem {
   const void* x_last = nullptr;  // single-chunk gradient evaluations: the chunk buffer that holds X (debug fetch "x_rows")
   bool have_k = false;        // Kstore holds K_nm of the current kernel and inducing points for every chunk
   int k_resident = 1;         // GPRHIP_K_RESIDENT=0 (read at creation): never keep K_nm (ablation)
+  int w_as_ws = 1;            // GPRHIP_W_AS_WS=0 (read at creation): pass-2 SYRK through the plain weighted kernel (do_pass2)
   // GPRHIP_MERGED_X (read at creation): 0 = X~ and X = X~ U^-T as two launches, as in rounds 1-2 (A/B runs); 1 (default) =
   // the two-phase product for shards large enough to pay for R^-1; 2 = always (parity tests at small sizes)
   int merged_x_mode = 1;
@@ -859,9 +860,19 @@ void do_pass2(gprhip_problem* p, const double* ar1, double* ar2) {
     wg.A = Vstore; wg.lda = mp; wg.B = Vstore; wg.ldb = mp; wg.C = slices; wg.ldc = mp;
     wg.M = mp; wg.N = mp; wg.K = (int)ktot; wg.beta = 0.0; wg.scale_k = row_weights<TS>(p, p->v, p->v_f); wg.upper_only = 1;
     wg.kslices = p->ks_used; wg.slice_stride = mm;
+    // The pass-2 launch goes through the kernel of the pass-1 one (its diagonal tiles then also form column sums nobody
+    // reads): measured in round 4, the plain weighted kernel (gemm_*_tn_w) runs this very launch with 172 GB instead of
+    // 67 GB through the fabric and 1-2 ms slower on most boxes of the pool -- its workgroups fall out of step from the
+    // first residency round on -- while the column-sum kernel does not (tools/lab19.sh, lab20.sh; GPRHIP_W_AS_WS=0 restores
+    // the plain kernel).
+    const bool as_ws = p->w_as_ws != 0;
+    if (as_ws) {
+      wg.cs_w = wg.scale_k;
+      wg.cs_out = p->gemvpart;
+    }
     launch_gemm(OP_TN, wg, s);
     tstop(p);
-    launch_sum_slices<TS>(nullptr, slices, p->ks_used, mm, mp, ar2, s, 1, gemm_syrk_diag_slices(p->ks_used, !p->f32, false));
+    launch_sum_slices<TS>(nullptr, slices, p->ks_used, mm, mp, ar2, s, 1, gemm_syrk_diag_slices(p->ks_used, !p->f32, as_ws));
   }
   p->stage = 2;
 }
@@ -1543,6 +1554,7 @@ int gprhip_problem_create_ex(int device, int cov_kind, int precision, int64_t n,
     if (const char* e = getenv("GPRHIP_TILE_ORDER")) p->tile_order = atoi(e);
     if (const char* e = getenv("GPRHIP_GRAD_SCALAR")) p->grad_scalar = atoi(e);
     if (const char* e = getenv("GPRHIP_K_RESIDENT")) p->k_resident = atoi(e);
+    if (const char* e = getenv("GPRHIP_W_AS_WS")) p->w_as_ws = atoi(e);
     if (const char* e = getenv("GPRHIP_F32_COEFF_TOL")) p->f32_coeff_tol = atof(e);
     if (const char* e = getenv("GPRHIP_MERGED_X")) p->merged_x_mode = atoi(e);
     if (const char* e = getenv("GPRHIP_POTRF_ENGINE")) p->engine_steps = atoi(e) != 0;
