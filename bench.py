@@ -321,10 +321,12 @@ def main():
         ms_per_step = dt / args.steps * 1e3
         value = n * args.steps / dt
         F = algorithmic_flops(n, m, d)
-        # dominant kernel by time per launch: gprhip::gemm_f64_tn_ws -- the pass-1 SYRK-shaped accumulation
-        # B~ = V^T diag(1/s) V over the shard's training points (one launch per evaluation; launched nowhere else, so the
-        # rocprofv3 --stats average of that kernel name is directly comparable).  Algorithmic flops per launch =
-        # n_local * m^2 ("SYRK B nm^2"); time: HIP events on the library's stream inside the timed region.
+        # dominant kernel by time per launch: gprhip::gemm_f64_tn_ws -- the SYRK-shaped accumulations over the shard's
+        # training points: B~ = V^T diag(1/s) V in pass 1 and G~ = V^T diag(v) V in pass 2 (two launches of the same shape
+        # per gradient evaluation since round 4, each n_local * m^2 algorithmic flops -- SURVEY 8(d): "SYRK B nm^2",
+        # "weighted-SYRK W nm^2"; the kernel is launched nowhere else, so the rocprofv3 --stats average of that kernel
+        # name is directly comparable).  Time: HIP events on the library's stream around the pass-1 launch, inside the
+        # timed region.
         syrk_ms = float(np.mean(kernel_ms)) if kernel_ms else 0.0
         flops_per_launch = float(n_local) * m * m
         achieved = flops_per_launch / (syrk_ms * 1e-3) * 1e-12 if syrk_ms > 0 else None
@@ -346,8 +348,8 @@ def main():
             "config": {"workload": "cov_se_iso FITC nLML + full hyper-gradient, n=%d m=%d d=%d fp64 "
                                    "(BASELINE.json configs[1]); n row-sharded over %d GPU(s)" % (n, m, d, world),
                        "n": n, "m": m, "d": d, "n_hypers": int(ev.grad.shape[0]) + 1},
-            "roofline": {"bound": "mfma", "kernel": DOMINANT["f64"] + "  (OP_TN: weighted SYRK over training points + c~ column sums)",
-                         "launches_per_step": 1,
+            "roofline": {"bound": "mfma", "kernel": DOMINANT["f64"] + "  (OP_TN: weighted SYRK over training points + column sums on the diagonal tiles)",
+                         "launches_per_step": 2,
                          "achieved": achieved, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": (achieved / PEAK_FP64_MFMA_TFLOPS) if achieved else None,
                          "traffic": (first["fetch_bytes"] + first["write_bytes"]) if first else None,
