@@ -1,10 +1,12 @@
 #!/bin/bash
-# Round 4: fabric traffic and time of the two SYRK launches, as is and with the device drained (host synchronisation)
-# right before the pass-2 launch.
+# Round 4: fabric traffic and time of the two SYRK launches per launch, with the pass-2 one through the plain weighted
+# kernel (GPRHIP_W_AS_WS=0: gemm_f64_tn_w, 172 GB) and through the column-sum kernel (=1, default: gemm_f64_tn_ws, 67 GB).
+# (The run logged in profiles/r04_lab_syrk_w_traffic.txt compared the plain kernel as is and with the device drained by a
+# host synchronisation right before the launch -- no difference.)
 root=$(pwd); out=$root/gpurun_out/lab19; mkdir -p $out
 for v in 0 1; do
-  if [ $v = 1 ]; then export GPRHIP_LAB_SYNC_W=1; else unset GPRHIP_LAB_SYNC_W; fi
-  echo "SYNC_W=$v"
+  export GPRHIP_W_AS_WS=$v
+  echo "W_AS_WS=$v"
   python3 $root/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-configs 2>/dev/null | python3 $root/tools/stage_times.py gt 56 | cut -c1-160
   (cd /tmp && export TMPDIR=/tmp && rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $out/f_$v -- python3 $root/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-configs > /dev/null 2>&1)
   db=$(ls $out/f_$v/*/*.db | head -1)
