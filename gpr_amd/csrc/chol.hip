@@ -42,9 +42,12 @@ __device__ __forceinline__ double* dblk(double* T, int b) {
   return (b < 7) ? T + ((b + 1) * MB) * LDT + b * MB : T + (7 * MB) * LDT;
 }
 
+// m_real (0 = mp): rows / columns at and beyond it are identity padding (K_m + jitter and B~ are 1 on the padded
+// diagonal, 0 off it): the 16-column micro-panels that lie wholly in the padding are skipped in both phases -- their
+// factor and their inverse are the identity that is already there.  (m = 50: four of eight micro-panels, 47 -> 27 us.)
 __global__ __launch_bounds__(PT) void potrf_diag_kernel(double* __restrict__ A, int mp, int j,
                                                         double* __restrict__ dinv,
-                                                        int* __restrict__ info, int flags) {
+                                                        int* __restrict__ info, int flags, int m_real) {
   extern __shared__ __attribute__((aligned(16))) double T[];  // [NB][LDT]
   double* T1 = T + NB * LDT;                                   // [NB][MB]
   double* rdiag = T1 + NB * MB;                                // [NB] reciprocal pivots
@@ -53,6 +56,8 @@ __global__ __launch_bounds__(PT) void potrf_diag_kernel(double* __restrict__ A, 
   const int lane = tid & 63, wid = tid >> 6;
   j += blockIdx.x;  // a launch over several blocks handles block j + blockIdx.x (inverse-only pass over all blocks)
   dinv += (int64_t)blockIdx.x * NB * NB;
+  const int live = (m_real > 0) ? min(NB, max(1, m_real - j * NB)) : NB;  // real rows of this block
+  const int k_end = (live + MB - 1) / MB * MB;                              // micro-panels that hold any of them
   double* Ab = A + (int64_t)j * NB * mp + (int64_t)j * NB;
   for (int idx = tid; idx < NB * NB / 2; idx += PT) {
     const int r = idx / (NB / 2), c2 = (idx % (NB / 2)) * 2;
@@ -63,6 +68,7 @@ __global__ __launch_bounds__(PT) void potrf_diag_kernel(double* __restrict__ A, 
     }
   }
   if (tid == 0) bad = 0;
+  if (tid < NB && tid >= k_end) rdiag[tid] = 1.0;  // padding: unit pivots
   __syncthreads();
   if (flags & 1) {  // block already holds a factor (model import): only its inverse is wanted
     if (tid < NB) rdiag[tid] = 1.0 / T[tid * LDT + tid];
@@ -70,7 +76,7 @@ __global__ __launch_bounds__(PT) void potrf_diag_kernel(double* __restrict__ A, 
   }
 
   // ---------------- factor
-  for (int k0 = 0; k0 < ((flags & 1) ? 0 : NB); k0 += MB) {
+  for (int k0 = 0; k0 < ((flags & 1) ? 0 : k_end); k0 += MB) {
     if (wid == 0 && !(flags & 4)) {
       const int cc = lane & 15;   // lanes 16..63 mirror lanes 0..15
       double a[MB];
@@ -201,7 +207,8 @@ __global__ __launch_bounds__(PT) void potrf_diag_kernel(double* __restrict__ A, 
     //   X(ri,b) = -T1 D_b                           (T1 re-laid out as an A operand through the wave's LDS scratch)
     // wavefront b copies D_b onto the diagonal tile.  All reads of U(.,b) finish before the first write.
     const int l15 = lane & 15, lq = lane >> 4;
-    for (int b = 0; b < NB / MB; ++b) {
+    // (block columns wholly in the padding are already their own inverse: zero above a unit diagonal block)
+    for (int b = 0; b < k_end / MB; ++b) {
       const double* D = dblk(T, b);
       const int cb = b * MB;
       pd4 t1 = {0.0, 0.0, 0.0, 0.0};
@@ -476,7 +483,6 @@ __global__ __launch_bounds__(256) void triu_matvec_kernel(const double* __restri
   if (lane == 0) y[i] = s;
 }
 
-void launch_potrf_diag_flags(double* A, int mp, int j, double* dinv, int* info, int flags, hipStream_t s);
 // dynamic-LDS opt-in of the two step kernels, once per device
 static void potrf_attrs() {
   static uint64_t done = 0;
@@ -488,19 +494,20 @@ static void potrf_attrs() {
   });
 }
 void launch_potrf_diag(double* A, int mp, int j, double* dinv, int* info, hipStream_t s) {
-  launch_potrf_diag_flags(A, mp, j, dinv, info, 0, s);
+  launch_potrf_diag_flags(A, mp, j, dinv, info, 0, s, 0);
 }
 // flags: ablation switches of tools/potrf_check (bit0 skip factor, bit1 skip invert); 0 in the library
-void launch_potrf_diag_flags(double* A, int mp, int j, double* dinv, int* info, int flags, hipStream_t s) {
+void launch_potrf_diag_flags(double* A, int mp, int j, double* dinv, int* info, int flags, hipStream_t s, int m_real) {
   potrf_attrs();
-  hipLaunchKernelGGL(potrf_diag_kernel, dim3(1), dim3(PT), POTRF_LDS, s, A, mp, j, dinv, info, flags);
+  hipLaunchKernelGGL(potrf_diag_kernel, dim3(1), dim3(PT), POTRF_LDS, s, A, mp, j, dinv, info, flags, m_real);
   GPR_HIP(hipGetLastError());
 }
 
 // Blocked upper Cholesky A = U^T U in place (dpotrf `U; lib/fitc_gp.ml:56) with inv(U_jj) of every diagonal block in
 // dinv: per step a factor-only diagonal kernel, the substitution panel and the small-tile trailing update; the block
 // inverses (which nothing on the chain needs any more) are formed by one launch over all blocks at the end.
-void potrf_upper_blocked(hipStream_t s, double* A, int mp, double* dinv, int* info, double* Yscratch, double* Xinv) {
+void potrf_upper_blocked(hipStream_t s, double* A, int mp, double* dinv, int* info, double* Yscratch, double* Xinv,
+                         int m_real) {
   potrf_attrs();
   static const int all_tiles = [] {  // largest step (in 64 x 64 sub-tiles) that runs the all-loads-first update kernel
     const char* e = getenv("GPRHIP_POTRF_ALL_TILES");
@@ -508,7 +515,7 @@ void potrf_upper_blocked(hipStream_t s, double* A, int mp, double* dinv, int* in
   }();
   const int nb = mp / NB;
   if (nb == 1) {  // a single block: factor and inverse in one launch
-    hipLaunchKernelGGL(potrf_diag_kernel, dim3(1), dim3(PT), POTRF_LDS, s, A, mp, 0, dinv, info, 0);
+    hipLaunchKernelGGL(potrf_diag_kernel, dim3(1), dim3(PT), POTRF_LDS, s, A, mp, 0, dinv, info, 0, m_real);
     if (Xinv) launch_scatter_diag_blocks(dinv, mp, Xinv, s);
     GPR_HIP(hipGetLastError());
     return;
@@ -525,7 +532,7 @@ void potrf_upper_blocked(hipStream_t s, double* A, int mp, double* dinv, int* in
   if (Y) hipLaunchKernelGGL(set_identity_kernel, dim3((mp + 255) / 256, mp), dim3(256), 0, s, Y, mp);
   for (int j = 0; j < nb; ++j) {
     double* dj = dinv + (int64_t)j * NB * NB;
-    hipLaunchKernelGGL(potrf_diag_kernel, dim3(1), dim3(PT), POTRF_LDS, s, A, mp, j, dj, info, 2 + 32);
+    hipLaunchKernelGGL(potrf_diag_kernel, dim3(1), dim3(PT), POTRF_LDS, s, A, mp, j, dj, info, 2 + 32, m_real);
     const int rest = nb - 1 - j, ns = 2 * rest;
     const int nrhs = Y ? 2 * (j + 1) : 0;  // 64-column groups of the right-hand side that are non-zero in block row j
     if (rest + nrhs > 0)
@@ -537,7 +544,7 @@ void potrf_upper_blocked(hipStream_t s, double* A, int mp, double* dinv, int* in
     }
   }
   if (Y) hipLaunchKernelGGL(transpose_kernel, dim3(mp / 32, mp / 32), dim3(256), 0, s, Y, mp, Xinv);
-  else hipLaunchKernelGGL(potrf_diag_kernel, dim3(nb), dim3(PT), POTRF_LDS, s, A, mp, 0, dinv, info, 1);
+  else hipLaunchKernelGGL(potrf_diag_kernel, dim3(nb), dim3(PT), POTRF_LDS, s, A, mp, 0, dinv, info, 1, m_real);
   GPR_HIP(hipGetLastError());
 }
 

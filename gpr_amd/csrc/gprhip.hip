@@ -283,12 +283,12 @@ void tcollect(gprhip_problem* p) {
 
 // Blocked upper Cholesky A = U^T U in place (dpotrf `U; lib/fitc_gp.ml:56) -- diagonal blocks in
 // LDS, panel solve and trailing update on the MFMA engine.  dinv receives inv(U_jj) per block.
-void potrf_upper_n(hipStream_t s, double* A, int mp, double* dinv, int* info, bool engine_steps) {
+void potrf_upper_n(hipStream_t s, double* A, int mp, double* dinv, int* info, bool engine_steps, int m_real = 0) {
   // default: the engine-free step kernels of chol.hip (potrf_upper_blocked); engine_steps (GPRHIP_POTRF_ENGINE=1 at
   // problem creation) keeps the round-2 sequence below for A/B timing -- diagonal block with its full inverse, panel
   // and trailing update as engine launches
   if (!engine_steps) {
-    potrf_upper_blocked(s, A, mp, dinv, info);
+    potrf_upper_blocked(s, A, mp, dinv, info, nullptr, nullptr, m_real);
     return;
   }
   const int nb = mp / TILE;
@@ -311,7 +311,7 @@ void potrf_upper_n(hipStream_t s, double* A, int mp, double* dinv, int* info, bo
   }
 }
 void potrf_upper(gprhip_problem* p, double* A, int* info) {
-  potrf_upper_n(p->stream, A, p->mp, p->dinv, info, p->engine_steps);
+  potrf_upper_n(p->stream, A, p->mp, p->dinv, info, p->engine_steps, p->m);
 }
 
 // A non-batched m x m product with few output tiles and a long k-range, split over `ks` k-slices so that the
@@ -397,7 +397,7 @@ void potrf_trtri(gprhip_problem* p, double* A, double* X, double* tmp, int* info
     trtri_upper(p, A, X, tmp);
     return;
   }
-  potrf_upper_blocked(p->stream, A, p->mp, p->dinv, info, tmp, X);
+  potrf_upper_blocked(p->stream, A, p->mp, p->dinv, info, tmp, X, p->m);
 }
 
 // C (upper tiles) = X X^T for upper-triangular X: (U^T U)^-1 = U^-1 U^-T   (Utils.ichol, lib/utils.ml:110-113)
@@ -1342,7 +1342,7 @@ void do_cov_samples(gprhip_problem* p, const double* cov, int64_t ld, int64_t nt
                            (size_t)nt * sizeof(double), (size_t)nt, hipMemcpyHostToDevice, s));
   GPR_HIP(hipMemsetAsync(info, 0, sizeof(int), s));
   launch_sym_from_upper(raw, nt, (int)nt, A, np, add_diag + jitter, s);
-  potrf_upper_n(s, A, np, dinv, info, p->engine_steps);
+  potrf_upper_n(s, A, np, dinv, info, p->engine_steps, (int)nt);
   int hinfo = 0;
   GPR_HIP(hipMemcpyAsync(&hinfo, info, sizeof(int), hipMemcpyDeviceToHost, s));
   // z: Fortran nt x ns == row-major [ns][nt]
@@ -1405,7 +1405,7 @@ void do_co_variance_coeffs(gprhip_problem* p, double* chol_km, double* r_mat) {
 // inv of an upper factor that is already on the device: per-block inverses, then the recursive-doubling joins
 void trtri_of_factor(gprhip_problem* p, double* U, double* X) {
   for (int j = 0; j < p->mp / TILE; ++j)
-    launch_potrf_diag_flags(U, p->mp, j, p->dinv + (int64_t)j * TILE * TILE, p->info, 1, p->stream);
+    launch_potrf_diag_flags(U, p->mp, j, p->dinv + (int64_t)j * TILE * TILE, p->info, 1, p->stream, p->m);
   trtri_upper(p, U, X, p->wmat);
 }
 

@@ -46,7 +46,8 @@ void launch_project(const double* X, int64_t n, int D, int d, const double* tpro
 // On a non-positive pivot, *info (if still 0) is set to the 1-based global index.
 void launch_potrf_diag(double* A, int mp, int j, double* dinv, int* info, hipStream_t s);
 // flags bit0: the block already holds an upper factor -- skip the factorisation, only write inv(U_jj) to dinv
-void launch_potrf_diag_flags(double* A, int mp, int j, double* dinv, int* info, int flags, hipStream_t s);
+// m_real (0 = mp): rows and columns from m_real on are identity padding; micro-panels wholly inside it are skipped
+void launch_potrf_diag_flags(double* A, int mp, int j, double* dinv, int* info, int flags, hipStream_t s, int m_real = 0);
 // Whole blocked factorisation A = U^T U (upper, in place; the strict lower parts of the diagonal blocks are zeroed, the
 // tiles below the diagonal untouched) + inv(U_jj) of every diagonal block in dinv [mp/128][128][128], without the
 // contraction engine: factor-only diagonal kernel, substitution panel, small-tile trailing update per 128-row step.
@@ -54,7 +55,7 @@ void launch_potrf_diag_flags(double* A, int mp, int j, double* dinv, int* info, 
 // right-hand side in the mp x mp scratch Yscratch rides along) and dinv only serves as scratch; with Xinv == null dinv
 // receives the block inverses as before.
 void potrf_upper_blocked(hipStream_t s, double* A, int mp, double* dinv, int* info, double* Yscratch = nullptr,
-                         double* Xinv = nullptr);
+                         double* Xinv = nullptr, int m_real = 0);
 void launch_zero_strict_lower(double* A, int mp, hipStream_t s);
 void launch_copy_block(const double* src, int64_t lds, double* dst, int64_t ldd, int rows, int cols,
                        hipStream_t s);

@@ -4,7 +4,6 @@
 #include <cstdlib>
 #include "../gpr_amd/csrc/kernels.h"
 using namespace gprhip;
-namespace gprhip { void launch_potrf_diag_flags(double* A, int mp, int j, double* dinv, int* info, int flags, hipStream_t s); }
 int main() {
   const int n = 128;
   std::vector<double> G(n * n), A(n * n);
