@@ -515,8 +515,8 @@ void potrf_upper_blocked(hipStream_t s, double* A, int mp, double* dinv, int* in
   }();
   const int nb = mp / NB;
   if (nb == 1) {  // a single block: factor and inverse in one launch
-    hipLaunchKernelGGL(potrf_diag_kernel, dim3(1), dim3(PT), POTRF_LDS, s, A, mp, 0, dinv, info, 0, m_real);
-    if (Xinv) launch_scatter_diag_blocks(dinv, mp, Xinv, s);
+    // (a single block's inverse, [128][128], IS the mp x mp inverse: written straight to Xinv)
+    hipLaunchKernelGGL(potrf_diag_kernel, dim3(1), dim3(PT), POTRF_LDS, s, A, mp, 0, Xinv ? Xinv : dinv, info, 0, m_real);
     GPR_HIP(hipGetLastError());
     return;
   }
