@@ -1496,7 +1496,7 @@ int problem_finish_collect(gprhip_problem* p, gprhip_result* res, double* grad, 
 extern "C" {
 
 const char* gprhip_last_error(void) { return last_error().c_str(); }
-const char* gprhip_version(void) { return "gprhip 0.1 (gfx950)"; }
+const char* gprhip_version(void) { return "gprhip 0.4 (gfx950)"; }
 
 int gprhip_device_count(int* count) {
   return guarded([&] {
