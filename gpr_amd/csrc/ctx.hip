@@ -235,13 +235,16 @@ void exchange(gprhip_sharded* sp, int which, int64_t len, const std::function<do
   }
   if (c->mode == GPRHIP_COMM_RCCL) {
     int rc = c->rccl.GroupStart();
-    for (int i = 0; i < nd && rc == 0; ++i) {
-      GPR_HIP(hipSetDevice(c->devices[i]));
+    bool dev_ok = true;
+    for (int i = 0; i < nd && rc == 0 && dev_ok; ++i) {
+      dev_ok = hipSetDevice(c->devices[i]) == hipSuccess;  // (no exception between GroupStart and GroupEnd)
+      if (!dev_ok) break;
       double* b = buf(sp->parts[i]);
       rc = c->rccl.AllReduce(b, b, (size_t)len, RCCL_DOUBLE, RCCL_SUM, c->comms[i], problem_hip_stream(sp->parts[i]));
     }
     const int rc2 = c->rccl.GroupEnd();
     if (rc == 0) rc = rc2;
+    if (!dev_ok) fail(GPRHIP_EHIP, "gprhip_sharded_eval: hipSetDevice failed inside the exchange step");
     if (rc != 0) fail(GPRHIP_ECOMM, std::string("gprhip_sharded_eval: ncclAllReduce failed: ") + c->rccl.GetErrorString(rc));
   } else {  // all shards on one device: a fixed-order sum on the first shard's stream, fenced by events
     GPR_HIP(hipSetDevice(c->devices[0]));
