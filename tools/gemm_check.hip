@@ -383,26 +383,31 @@ void timestamps(GemmOp op, int M, int N, int K, int tri, const char* path) {
 // TS_SYRK=1 [WS=1]: per-workgroup time stamps of the 1M-row weighted SYRK launch of the headline shape, through the plain
 // weighted kernel (gemm_f64_tn_w) or, with WS=1, the column-sum kernel (gemm_f64_tn_ws): how far apart the workgroups of
 // an XCD's residency rounds start, and how long their k-loops last (the pass-2 SYRK finding)
-__global__ void fill_kernel(double* x, size_t n, unsigned seed) {
+template <typename T>
+__global__ void fill_kernel(T* x, size_t n, unsigned seed) {
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
     unsigned h = (unsigned)(i * 2654435761u) ^ seed;
     h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
-    x[i] = (double)(h & 0xffffff) / 16777216.0 - 0.5;
+    x[i] = (T)((double)(h & 0xffffff) / 16777216.0 - 0.5);
   }
 }
+template <typename T>
 void timestamps_syrk(bool ws) {
-  const int N = 2048, KS = getenv("KS") ? atoi(getenv("KS")) : 112;
+  const bool f64 = sizeof(T) == 8;
+  const int N = getenv("NCOLS") ? atoi(getenv("NCOLS")) : 2048, KS = getenv("KS") ? atoi(getenv("KS")) : 112;
   const int64_t K = 1000064;
-  double *dV, *dW, *dC, *dCS;
-  hipMalloc(&dV, K * N * 8); hipMalloc(&dW, K * 8); hipMalloc(&dC, (int64_t)KS * N * N * 8); hipMalloc(&dCS, (int64_t)KS * N * 8);
-  hipLaunchKernelGGL(fill_kernel, dim3(4096), dim3(256), 0, 0, dV, (size_t)(K * N), 1u);
-  hipLaunchKernelGGL(fill_kernel, dim3(256), dim3(256), 0, 0, dW, (size_t)K, 7u);
-  GemmArgs g;
+  T *dV, *dW, *dC;
+  double* dCS;
+  hipMalloc(&dV, K * N * sizeof(T)); hipMalloc(&dW, K * sizeof(T)); hipMalloc(&dC, (int64_t)KS * N * N * sizeof(T));
+  hipMalloc(&dCS, (int64_t)KS * N * 8);
+  hipLaunchKernelGGL(fill_kernel<T>, dim3(4096), dim3(256), 0, 0, dV, (size_t)(K * N), 1u);
+  hipLaunchKernelGGL(fill_kernel<T>, dim3(256), dim3(256), 0, 0, dW, (size_t)K, 7u);
+  GemmArgsT<T> g;
   g.A = dV; g.lda = N; g.B = dV; g.ldb = N; g.C = dC; g.ldc = N; g.M = N; g.N = N; g.K = (int)K;
   g.scale_k = dW; g.upper_only = 1; g.kslices = KS; g.slice_stride = (int64_t)N * N;
   if (ws) { g.cs_w = dW; g.cs_out = dCS; }
   const int nbn = N / 128, tiles = nbn * (nbn + 1) / 2;
-  const int dsl = gemm_syrk_diag_slices(KS, true, ws);
+  const int dsl = gemm_syrk_diag_slices(KS, f64, ws);
   const int nwg = 8 * ((tiles - nbn) * (KS / 8) + nbn * ((dsl + 7) / 8));
   unsigned long long* dts; hipMalloc(&dts, (size_t)nwg * 128); hipMemset(dts, 0, (size_t)nwg * 128);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
@@ -414,14 +419,15 @@ void timestamps_syrk(bool ws) {
   hipDeviceSynchronize();
   std::vector<unsigned long long> h((size_t)nwg * 16);
   hipMemcpy(h.data(), dts, h.size() * 8, hipMemcpyDeviceToHost);
-  printf("%s: %d workgroups, %d + %d slices, launch %.3f ms (without stamps)\n", ws ? "tn_ws" : "tn_w", nwg, KS, dsl, ms);
+  printf("%s %s N=%d: %d workgroups, %d + %d slices, launch %.3f ms (without stamps)\n", f64 ? "f64" : "f32", ws ? "tn_ws" : "tn_w", N,
+         nwg, KS, dsl, ms);
   // per XCD, in dispatch order (blockIdx = 8 q + x): k-loop start of position q, in groups of 64 positions
   unsigned long long t0 = ~0ull;
   for (int w = 0; w < nwg; ++w) if (h[(size_t)w * 16 + 1]) t0 = std::min(t0, h[(size_t)w * 16 + 10]);
+  const int nq = nwg / 8, nrounds = (nq + 63) / 64;
   for (int x = 0; x < 8; x += 7) {  // first and last XCD
-    const int nq = nwg / 8;
     printf("XCD %d: round (64 positions): first loop start [us], spread of loop starts [us], mean / min / max loop length [us]\n", x);
-    for (int r = 0; r * 64 < nq && r < 40; ++r) {
+    for (int r = 0; r < nrounds; r += std::max(1, nrounds / 24)) {
       double lo = 1e30, hi = 0, sum = 0, dmin = 1e30, dmax = 0; int cnt = 0;
       for (int q = r * 64; q < std::min(nq, r * 64 + 64); ++q) {
         const unsigned long long* rec = &h[(size_t)(8 * q + x) * 16];
@@ -429,7 +435,19 @@ void timestamps_syrk(bool ws) {
         const double st = (rec[1] - t0) / 100.0, len = (rec[2] - rec[1]) / 100.0;
         lo = std::min(lo, st); hi = std::max(hi, st); sum += len; dmin = std::min(dmin, len); dmax = std::max(dmax, len); ++cnt;
       }
-      if (cnt) printf("  round %2d: start %9.1f  spread %7.1f   loop %7.1f / %7.1f / %7.1f  (%d items)\n", r, lo, hi - lo, sum / cnt, dmin, dmax, cnt);
+      if (cnt) {
+        printf("  round %3d: start %9.1f  spread %7.1f   loop %7.1f / %7.1f / %7.1f  (%d items)", r, lo, hi - lo, sum / cnt, dmin, dmax, cnt);
+        // sorted loop starts relative to the earliest, every eighth: two tight groups or a continuum?
+        std::vector<double> st;
+        for (int q = r * 64; q < std::min(nq, r * 64 + 64); ++q) {
+          const unsigned long long* rec = &h[(size_t)(8 * q + x) * 16];
+          if (rec[1]) st.push_back((rec[1] - t0) / 100.0 - lo);
+        }
+        std::sort(st.begin(), st.end());
+        printf("   starts:");
+        for (size_t i = 0; i < st.size(); i += 7) printf(" %.0f", st[i]);
+        printf("\n");
+      }
     }
   }
   hipFree(dV); hipFree(dW); hipFree(dC); hipFree(dCS); hipFree(dts);
@@ -439,7 +457,8 @@ int main() {
   setvbuf(stdout, nullptr, _IOLBF, 0);
   gemm_init();
   if (getenv("TS_SYRK")) {
-    timestamps_syrk(getenv("WS") != nullptr);
+    if (getenv("F32")) timestamps_syrk<float>(getenv("WS") != nullptr);
+    else timestamps_syrk<double>(getenv("WS") != nullptr);
     return 0;
   }
   if (getenv("TS")) {
