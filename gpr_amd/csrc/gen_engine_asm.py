@@ -48,7 +48,9 @@ class Cfg:
         # short item of a column-tile pair of a triangular NN product then reads the A blocks its seven neighbours on
         # the XCD read at the same time (mfma_gemm.hip: tile_of_block).  diag "khid": the diagonal block of B, which
         # ends the k-range, is visited first, its stages in reverse order.
-        self.desc = desc or diag == "khid"
+        # diag "klod" (NT): the diagonal block of B, which starts the k-range, is visited last (first phase of the long
+        # item of a two-phase pair: the eight long items of a row panel then start together at the top of k)
+        self.desc = desc or diag in ("khid", "klod")
         self.nkk = 4 if f64 else 8          # k-steps (of 4) per stage
         self.fw = 2 if f64 else 1           # dwords per fragment element
         self.aw = 8 if f64 else 4           # accumulator registers per 16x16 sub-tile
@@ -60,8 +62,8 @@ class Cfg:
     def name(self):
         return "ENGINE_LOOP_%s_%s%s%s%s" % ("F64" if self.f64 else "F32", self.op.upper(),
                                             {0: "", 1: "_W", 2: "_WS"}[self.var],
-                                            {None: "", "khi": "_KHI", "klo": "_KLO", "sy": "_SY", "khid": "_KHID"}[self.diag],
-                                            ("_CONT" if self.cont else "") + ("_DESC" if self.desc and self.diag != "khid" else ""))
+                                            {None: "", "khi": "_KHI", "klo": "_KLO", "sy": "_SY", "khid": "_KHID", "klod": "_KLOD"}[self.diag],
+                                            ("_CONT" if self.cont else "") + ("_DESC" if self.desc and self.diag not in ("khid", "klod") else ""))
 
 
 def reg(base, width):
@@ -219,14 +221,15 @@ def gen(c):
             kpos = 4 * (u * nkk + kk)
             if c.diag in ("khi", "khid"):
                 return tuple(j for j in range(4) if kpos <= 16 * (wc + 2 * j) + 15)
+            # ("klo", "klod")
             return tuple(j for j in range(4) if kpos + 3 >= 16 * (wc + 2 * j))
         return f
 
     def diag_section(b0, wc, end_label):
         for u in range(DSTAGES):
             last = u == DSTAGES - 1
-            # "khid": the v-th stage visited is stage DSTAGES-1-v of the block
-            ub = DSTAGES - 1 - u if c.diag == "khid" else u
+            # "khid" / "klod": the v-th stage visited is stage DSTAGES-1-v of the block
+            ub = DSTAGES - 1 - u if c.diag in ("khid", "klod") else u
             stage((b0 + u) & 1, end_label if (last or c.diag in ("klo", "khid")) else None, live=diag_live(ub, wc))
 
     # ================= program: two asm statements per output tile =================
@@ -283,7 +286,7 @@ def gen(c):
         for b in (0, 1):
             stage(b, "2f", live=lambda kk: tuple((i, j) for i in range(4) for j in range(4) if i < j))
         emit("s_branch 20b")
-    elif c.diag == "khi":
+    elif c.diag in ("khi", "klod"):
         # plain stages until DSTAGES remain, then the diagonal block (a copy per starting buffer and wave column)
         def to_diag(label):
             def f():
@@ -335,7 +338,8 @@ def main():
                                           ("nt", 0, "klo", False, False), ("tn", 1, "sy", False, False),
                                           ("tn", 2, "sy", False, False), ("nt", 0, None, True, False),
                                           ("nt", 0, "klo", True, False), ("nn", 0, None, False, True),
-                                          ("nn", 0, "khid", False, False)):
+                                          ("nn", 0, "khid", False, False), ("nt", 0, None, False, True),
+                                          ("nt", 0, "klod", False, False)):
             c = Cfg(f64, op, var, diag, cont, desc)
             for part, lines in zip(("PRO", "MAIN"), gen(c)):
                 if (diag or cont) and part == "PRO":
