@@ -119,22 +119,24 @@ def profile_traffic(n, m):
     return out
 
 
-def other_configs(gpr_amd, steps=2):
+def other_configs(gpr_amd, steps=3):
     """BASELINE.json configs[2] (cov_se_fat ARD, n=1M m=4096 d=32, fp32 bulk and fp64) and the per-GPU shard of
     configs[3] (cov_se_iso, n=1M of 8M, m=4096, d=16, fp64), outside the headline's timed region: one warm-up + `steps`
-    timed evaluations each, the dominant kernel timed with HIP events on the library's stream."""
+    timed evaluations each (median reported), the dominant kernel timed with HIP events on the library's stream."""
     out = []
 
     def measure(label, prob, kwargs, n, m, d, dtype):
         prob.set_timing(1)
         prob.eval(**kwargs)
-        ks, t0 = [], time.perf_counter()
+        ks, ts = [], []
         for _ in range(steps):
+            t0 = time.perf_counter()
             ev = prob.eval(**kwargs)
+            ts.append(time.perf_counter() - t0)
             ks.append(prob.last_timings().get("kernel_p1_syrk_B", 0.0))
-        dt = (time.perf_counter() - t0) / steps
+        dt = float(np.median(ts))
         peak = PEAK_FP64_MFMA_TFLOPS if dtype == "f64" else PEAK_FP32_MFMA_TFLOPS
-        kms = float(np.mean(ks))
+        kms = float(np.median(ks))
         ach = float(n) * m * m / (kms * 1e-3) * 1e-12 if kms > 0 else None
         F = algorithmic_flops(n, m, d)
         out.append({"config": label, "dtype": dtype, "ms_per_eval": dt * 1e3, "points_per_s": n / dt,

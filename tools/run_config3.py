@@ -18,7 +18,7 @@ for prec, name in ((gpr_amd.F32_BULK, "f32"), (gpr_amd.F64, "f64")):
         continue
     p = gpr_amd.Problem(gpr_amd.COV_SE_FAT, n, d, d, m, precision=prec)
     p.set_inputs(X); p.set_targets(y)
-    p.set_timing(0)
+    p.set_timing(int(os.environ.get("TIMING", 0)))
     for it in range(3):
         t0 = time.time()
         ev = p.eval(log_sf2=0.0, sigma2=0.1, inducing=Z, tproj=P)
