@@ -142,6 +142,9 @@ struct gprhip_problem {
   const void* x_last = nullptr;  // single-chunk gradient evaluations: the chunk buffer that holds X (debug fetch "x_rows")
   bool have_k = false;        // Kstore holds K_nm of the current kernel and inducing points for every chunk
   int k_resident = 1;         // GPRHIP_K_RESIDENT=0 (read at creation): never keep K_nm (ablation)
+  // GPRHIP_SMALL_PATH=0 (read at creation): never take the one-kernel row passes of small problems (small.hip)
+  int small_path = 1;
+  double* small_part = nullptr;  // their per-workgroup partial sums (allocated at first use)
   int w_as_ws = 1;            // GPRHIP_W_AS_WS=0 (read at creation): pass-2 SYRK through the plain weighted kernel (do_pass2)
   // GPRHIP_MERGED_X (read at creation): 0 = X~ and X = X~ U^-T as two launches, as in rounds 1-2 (A/B runs); 1 (default) =
   // the two-phase product for shards large enough to pay for R^-1; 2 = always (parity tests at small sizes)
@@ -217,6 +220,9 @@ struct gprhip_problem {
   int64_t km_rows() const { return d + 2 + (kind == GPRHIP_COV_SE_FAT ? d : 0); }
   // exchange-2 column block: sum E, sum p_k E (d), sum x_big E (D), and for Cov_se_fat sum p_k^2 E (d)
   int64_t col_rows() const { return d + 1 + dbig() + (kind == GPRHIP_COV_SE_FAT ? d : 0); }
+  bool use_small() const {
+    return small_path && !f32 && nchunks == 1 && !has_ms() && small_path_fits(m, mp, d, has_proj() ? D : 0, n);
+  }
 };
 
 namespace {
@@ -589,7 +595,9 @@ void do_pass1(gprhip_problem* p, const gprhip_hypers* h, int want_grad, int64_t 
   // K_nm of the first chunk does not depend on U: it is built on the second stream while the (latency-bound, few-CU)
   // factorisation and inversion of K_m run -- 0.4 ms of every evaluation, which is what a chunk's builder takes.
   // (Not under the per-stage timer, whose events sit on the main stream.)
-  const bool cov0_ahead = !reuse && !p->timer.on;
+  const bool small = p->use_small();
+  if (small && !p->small_part) p->small_part = p->alloc<double>(small_part_len(p->d, p->D));
+  const bool cov0_ahead = !reuse && !p->timer.on && !small;
   if (cov0_ahead) {
     GPR_HIP(hipEventRecord(p->ev_fork, s));  // hypers, inducing points and projections are enqueued on s
     GPR_HIP(hipStreamWaitEvent(p->stream2, p->ev_fork, 0));
@@ -605,6 +613,23 @@ void do_pass1(gprhip_problem* p, const gprhip_hypers* h, int want_grad, int64_t 
   if (p->f32) launch_to_float(p->uinv, p->uinv_f, mm, s);
   tstop(p);
 
+  if constexpr (std::is_same<TS, double>::value) {
+    if (small && !reuse) {
+      // small problems: covariance, V, the row quantities and both accumulations in one kernel + one reduction (small.hip)
+      tstart(p, "p1_small");
+      SmallPass1Args a;
+      a.cp = p->cp; a.pts = p->pts(); a.Z = p->Z; a.uinv = p->uinv; a.y = h->model_only ? nullptr : p->y;
+      a.rows = (int)p->n; a.rows_p = (int)round_up(p->n, TILE); a.m = p->m; a.mp = mp; a.d = p->d;
+      a.sigma2 = h->sigma2;
+      a.V = Vstore; a.r = p->r; a.is = p->is; a.yis = p->yis; a.part = p->small_part;
+      launch_small_pass1(a, ar1, ar1_c, ar1_tail, s);
+      tstop(p);
+      p->stage = 1;
+      p->have_v = true;
+      p->have_k = false;
+      return;
+    }
+  }
   for (int c = 0; c < p->nchunks; ++c) {
     const int64_t rows = p->rows_of(c);
     const int rows_p = (int)round_up(rows, TILE);
@@ -722,7 +747,8 @@ void do_pass2(gprhip_problem* p, const double* ar1, double* ar2) {
     // The two-phase X product (below) needs R^-1 = U^-1 R~^-1, one more m x m product (0.14 ms at m = 2048, 0.8 ms at
     // m = 4096), and saves 2.5 us per 1000 training points at m = 2048 (6 us at m = 4096): taken from 48 m training
     // points per shard on.
-    p->merged_x = p->merged_x_mode == 2 || (p->merged_x_mode == 1 && p->n >= 48 * (int64_t)p->m);
+    const bool small = p->use_small();
+    p->merged_x = !small && (p->merged_x_mode == 2 || (p->merged_x_mode == 1 && p->n >= 48 * (int64_t)p->m));
     if (p->merged_x) {
       GemmArgs rf;  // R^-1 = U^-1 R~^-1, both upper triangular
       rf.A = p->uinv; rf.lda = mp; rf.B = p->rinv; rf.ldb = mp; rf.C = p->rfinv; rf.ldc = mp;
@@ -745,6 +771,26 @@ void do_pass2(gprhip_problem* p, const double* ar1, double* ar2) {
     if (side) GPR_HIP(hipEventRecord(p->ev_binv, si));
     tstop(p);
     bool derive_inducing = false;
+    if constexpr (std::is_same<TS, double>::value) {
+      if (small) {
+        // small problems: Q', the row quantities, X~, X, the column sums of E = X .* K and G~ in one kernel (small.hip)
+        tstart(p, "p2_small");
+        if (!p->small_part) p->small_part = p->alloc<double>(small_part_len(p->d, p->D));
+        SmallPass2Args a;
+        a.cp = p->cp; a.pts = p->pts(); a.Z = p->Z; a.uinv = p->uinv; a.rinv = p->rinv; a.bvec = p->bvec; a.ttil = p->ttil;
+        a.V = Vstore; a.y = mo ? nullptr : p->y; a.is = p->is; a.r = p->r;
+        a.big = proj ? p->X : nullptr; a.D = proj ? p->D : 0;
+        a.rows = (int)p->n; a.rows_p = (int)round_up(p->n, TILE); a.m = p->m; a.mp = mp; a.d = p->d;
+        a.variational = p->h.variational;
+        a.w = p->w; a.v = p->v; a.es = proj ? p->es : nullptr; a.X = bufB; a.part = p->small_part;
+        launch_small_pass2(a, ar2, ar2_col, ar2_proj, ar2_tail, s);
+        p->x_last = bufB;
+        tstop(p);
+        if (side) GPR_HIP(hipStreamWaitEvent(s, p->ev_binv, 0));
+        p->stage = 2;
+        return;
+      }
+    }
     for (int c = 0; c < p->nchunks; ++c) {
       const int64_t rows = p->rows_of(c);
       const int rows_p = (int)round_up(rows, TILE);
@@ -1555,6 +1601,7 @@ int gprhip_problem_create_ex(int device, int cov_kind, int precision, int64_t n,
     if (const char* e = getenv("GPRHIP_GRAD_SCALAR")) p->grad_scalar = atoi(e);
     if (const char* e = getenv("GPRHIP_K_RESIDENT")) p->k_resident = atoi(e);
     if (const char* e = getenv("GPRHIP_W_AS_WS")) p->w_as_ws = atoi(e);
+    if (const char* e = getenv("GPRHIP_SMALL_PATH")) p->small_path = atoi(e);
     if (const char* e = getenv("GPRHIP_F32_COEFF_TOL")) p->f32_coeff_tol = atof(e);
     if (const char* e = getenv("GPRHIP_MERGED_X")) p->merged_x_mode = atoi(e);
     if (const char* e = getenv("GPRHIP_POTRF_ENGINE")) p->engine_steps = atoi(e) != 0;

@@ -199,4 +199,28 @@ void launch_km_traces(const double* W, const double* km, const double* Z, int m,
 void launch_km_traces_ms(const double* W, const double* km, const double* Z, const double* ms, int m, int mp,
                          int d, double* part, hipStream_t s);
 
+// ---- row passes of small problems (small.hip): m <= 64, one chunk of at most 65536 rows, d, D <= 16, fp64, no multiscales
+struct SmallPass1Args {
+  CovParams cp;
+  const double *pts, *Z, *uinv, *y;  // points [rows][d], inducing [mp][d], U^-1 [mp][mp], targets (or null)
+  int rows, rows_p, m, mp, d;
+  double sigma2;
+  double *V, *r, *is, *yis;          // out: V [rows_p][mp] (padding zero), r / is / yis [rows_p]
+  double* part;                      // scratch, small_part_len doubles
+};
+struct SmallPass2Args {
+  CovParams cp;
+  const double *pts, *Z, *uinv, *rinv, *bvec, *ttil, *V, *y, *is, *r;
+  const double* big;                 // original inputs [rows][D] (Cov_se_fat with tproj) or null
+  int D, rows, rows_p, m, mp, d, variational;
+  double *w, *v, *es, *X;            // out: w, v [rows_p], es [rows_p] (or null), X [rows_p][mp] (columns < 64)
+  double* part;
+};
+bool small_path_fits(int m, int mp, int d, int D, int64_t rows);
+int64_t small_part_len(int d, int D);
+// pass 1 + its reduction into the exchange-1 buffer: (0,0) tile, c~ [mp], scalar tail [4]
+void launch_small_pass1(const SmallPass1Args& a, double* tile, double* cvec, double* tail, hipStream_t s);
+// pass 2 + its reduction into the (zeroed) exchange-2 buffer: (0,0) tile, column block (ld mp), `Proj term [D*d], tail [8]
+void launch_small_pass2(const SmallPass2Args& a, double* tile, double* colblk, double* proj, double* tail, hipStream_t s);
+
 }  // namespace gprhip

@@ -1,0 +1,502 @@
+// Row passes of small problems (m <= 64 inducing points, one row chunk): the reference's own shapes (n = 1000..2000,
+// m = 10..50, test/save_data.ml, test/gen_data.ml) spend their time in launches, not in arithmetic -- through the engine a
+// gradient evaluation is 9 contraction launches of 16-22 us each plus ~20 small kernels.  Here each pass is ONE kernel
+// per 64-row block that keeps the block's rows of K, V, Q' and X in LDS and the 64 x 64 corners of U^-1 / R~^-1 beside
+// them, plus one fixed-order reduction of the per-workgroup partial sums into the exchange buffers -- same buffers, same
+// layout as the engine path writes (do_pass1 / do_pass2), so everything around the two passes is shared.
+//   pass 1: K (lib/cov_se_iso.ml:128-159, lib/cov_se_fat.ml:224-240), V = K U^-1 (lib/fitc_gp.ml:226-227), r, s, 1/s
+//           (:155-166, :222-223), B~ part = V^T diag(is) V, c~ part = V^T (is y)
+//   pass 2: Q' = V R~^-1, q_diag, w, v (:1048, :1092-1108, :1158-1181), X~ = diag(is) Q' R~^-T - diag(v) V - w t~^T,
+//           X = X~ U^-T (:931-939, :1204-1206), E = X .* K column sums (:975-1003), G~ part = V^T diag(v) V (:1198-1203)
+// All products run as v_mfma_f64_16x16x4_f64 tiles on LDS operands: wavefront w owns rows 16w..16w+15 of the block.
+#include <algorithm>
+#include <type_traits>
+
+#include "kernels.h"
+#include "exp_fast.h"
+
+namespace gprhip {
+
+namespace {
+
+constexpr int SM = 64;    // inducing points (padded) the small path handles
+constexpr int SLD = 66;   // leading dimension of the 64 x 64 LDS matrices
+constexpr int SRB = 64;   // training points per block iteration
+constexpr int P1LEN = SM * SM + SM + 4;  // pass-1 partial of a workgroup: B~ part | c~ part | sum log s, sum y^2/s, sum r/s, -
+__host__ __device__ constexpr int p2len(int d, int D) { return SM * SM + (1 + d + D) * SM + D * d + 8; }
+
+typedef double sd4 __attribute__((ext_vector_type(4)));
+// lane supplies A[lane&15][lane>>4] and B[lane>>4][lane&15]; accumulator element r is D[(lane>>4) + 4r][lane&15]
+__device__ __forceinline__ sd4 mfma_f64(double a, double b, sd4 c) {
+  return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ double sum16(double v) {  // over the 16 lanes that share lane >> 4
+  v += __shfl_xor(v, 1);
+  v += __shfl_xor(v, 2);
+  v += __shfl_xor(v, 4);
+  v += __shfl_xor(v, 8);
+  return v;
+}
+__device__ __forceinline__ double sum64(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+// rows [16 wv, 16 wv + 16) of  A (LDS, [64][SLD]) times  B (LDS, [64][SLD]; TRANS: times B^T)  -> acc[ct], ct = column tile
+template <bool TRANS>
+__device__ __forceinline__ void rows_times(const double* A, const double* B, int wv, int l15, int lq, sd4 (&acc)[4]) {
+#pragma unroll
+  for (int ct = 0; ct < 4; ++ct) acc[ct] = sd4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll 4
+  for (int kk = 0; kk < SM / 4; ++kk) {
+    const double af = A[(16 * wv + l15) * SLD + 4 * kk + lq];
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) {
+      const double bf = TRANS ? B[(16 * ct + l15) * SLD + 4 * kk + lq] : B[(4 * kk + lq) * SLD + 16 * ct + l15];
+      acc[ct] = mfma_f64(af, bf, acc[ct]);
+    }
+  }
+}
+
+// acc[ct] += (T^T diag(wt) T) tile (wv, ct) over the 64 rows of T (LDS)
+__device__ __forceinline__ void gram_update(const double* T, const double* wt, int wv, int l15, int lq, sd4 (&acc)[4]) {
+#pragma unroll 4
+  for (int kk = 0; kk < SRB / 4; ++kk) {
+    const int k = 4 * kk + lq;
+    const double af = T[k * SLD + 16 * wv + l15] * wt[k];
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) acc[ct] = mfma_f64(af, T[k * SLD + 16 * ct + l15], acc[ct]);
+  }
+}
+
+__device__ __forceinline__ void load_corner(const double* __restrict__ M, int mp, double* L, int tid) {
+  for (int idx = tid; idx < SM * SM; idx += 256) {
+    const int r = idx >> 6, c = idx & 63;
+    L[r * SLD + c] = M[(int64_t)r * mp + c];
+  }
+}
+
+}  // namespace
+
+constexpr int SMALL_GROUPS = 128;  // workgroups of a pass at most (each walks blocks b, b + groups, ...)
+int64_t small_part_len(int d, int D) { return (int64_t)SMALL_GROUPS * std::max(P1LEN, p2len(d, D)); }
+static int small_groups(int rows_p) { return std::min(SMALL_GROUPS, rows_p / SRB); }
+
+template <int DT>
+__global__ __launch_bounds__(256) void small_pass1_kernel(SmallPass1Args a) {
+  extern __shared__ __attribute__((aligned(16))) double small_lds[];
+  double* const Ui = small_lds;         // [SM][SLD]  U^-1
+  double* const Kt = Ui + SM * SLD;     // [SRB][SLD] K of the block, then V in place
+  double* const xs = Kt + SRB * SLD;    // [SRB][DT]
+  double* const isr = xs + SRB * DT;    // [SRB] 1/s
+  double* const yisr = isr + SRB;       // [SRB] y/s
+  double* const rs = yisr + SRB;        // [SRB] rowsum(V.^2)
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l15 = lane & 15, lq = lane >> 4;
+  const ExpK ek = exp_consts();
+  load_corner(a.uinv, a.mp, Ui, tid);
+  const int col = lane, rg = wv;  // covariance / column-sum phases: thread = (column, group of 16 rows)
+  const bool live_c = col < a.m;
+  double z[DT];
+#pragma unroll
+  for (int k = 0; k < DT; ++k) z[k] = (k < a.d && live_c) ? a.Z[(int64_t)col * a.d + k] : 0.0;
+  sd4 accB[4];
+#pragma unroll
+  for (int ct = 0; ct < 4; ++ct) accB[ct] = sd4{0.0, 0.0, 0.0, 0.0};
+  double csum = 0.0, p_log = 0.0, p_y2 = 0.0, p_isr = 0.0;
+  const int nblk = a.rows_p / SRB;
+  for (int b = blockIdx.x; b < nblk; b += gridDim.x) {
+    const int r0 = b * SRB;
+    __syncthreads();
+    for (int idx = tid; idx < SRB * DT; idx += 256) {
+      const int r = idx / DT, k = idx % DT;
+      xs[idx] = (k < a.d && r0 + r < a.rows) ? a.pts[(int64_t)(r0 + r) * a.d + k] : 0.0;
+    }
+    __syncthreads();
+    for (int i = 0; i < 16; ++i) {
+      const int r = rg * 16 + i;
+      double acc = 0.0;
+#pragma unroll
+      for (int k = 0; k < DT; ++k) {
+        if (k < a.d) {
+          const double diff = xs[r * DT + k] - z[k];
+          acc = acc + diff * diff;
+        }
+      }
+      Kt[r * SLD + col] = (r0 + r < a.rows && live_c) ? exp_fast(a.cp.log_sf2 + a.cp.inv_ell2_05 * acc, ek) : 0.0;
+    }
+    __syncthreads();
+    sd4 acc[4];
+    rows_times<false>(Kt, Ui, wv, l15, lq, acc);  // V = K U^-1
+    double s2[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      double s = 0.0;
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct) s += acc[ct][r] * acc[ct][r];
+      s2[r] = sum16(s);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = 16 * wv + lq + 4 * r;
+      if (l15 == 0) rs[row] = s2[r];
+      double* vrow = a.V + (int64_t)(r0 + row) * a.mp;
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct) {
+        Kt[row * SLD + 16 * ct + l15] = acc[ct][r];  // rows of this wavefront only: in place
+        vrow[16 * ct + l15] = acc[ct][r];
+        vrow[SM + 16 * ct + l15] = 0.0;  // columns 64..127 of the padded store
+      }
+    }
+    __syncthreads();
+    if (tid < SRB) {  // r, s = r + sigma2, 1/s, sum log s  (as pass1_rows_kernel)
+      const int row = r0 + tid;
+      double rr = 0.0, is = 0.0, yis = 0.0;
+      if (row < a.rows) {
+        rr = a.cp.sf2 - rs[tid];
+        const double s = rr + a.sigma2;
+        is = 1.0 / s;
+        const double y = a.y ? a.y[row] : 0.0;
+        yis = is * y;
+        p_log += log(s);
+        p_y2 += is * y * y;
+        p_isr += is * rr;
+      }
+      a.r[row] = rr;
+      a.is[row] = is;
+      a.yis[row] = yis;
+      isr[tid] = is;
+      yisr[tid] = yis;
+    }
+    __syncthreads();
+    gram_update(Kt, isr, wv, l15, lq, accB);
+    for (int i = 0; i < 16; ++i) {
+      const int k = rg * 16 + i;
+      csum += Kt[k * SLD + col] * yisr[k];
+    }
+  }
+  double* part = a.part + (int64_t)blockIdx.x * P1LEN;
+#pragma unroll
+  for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) part[(16 * wv + lq + 4 * r) * SM + 16 * ct + l15] = accB[ct][r];
+  __syncthreads();
+  Kt[rg * SLD + col] = csum;
+  __syncthreads();
+  if (tid < SM) part[SM * SM + tid] = (Kt[tid] + Kt[SLD + tid]) + (Kt[2 * SLD + tid] + Kt[3 * SLD + tid]);
+  if (wv == 0) {
+    p_log = sum64(p_log);
+    p_y2 = sum64(p_y2);
+    p_isr = sum64(p_isr);
+    if (lane == 0) {
+      part[SM * SM + SM + 0] = p_log;
+      part[SM * SM + SM + 1] = p_y2;
+      part[SM * SM + SM + 2] = p_isr;
+      part[SM * SM + SM + 3] = 0.0;
+    }
+  }
+}
+
+// exchange-1 buffer from the pass-1 partials, workgroups summed in order: the (0,0) upper tile (128 x 128; zero outside
+// the 64 x 64 corner), c~ (mp entries) and the scalar tail
+__global__ __launch_bounds__(256) void small_reduce1_kernel(const double* __restrict__ part, int ng, int mp,
+                                                            double* __restrict__ tile, double* __restrict__ cvec,
+                                                            double* __restrict__ tail) {
+  const int tid = threadIdx.x;
+  if (blockIdx.x < TILE * TILE / 256) {
+    const int idx = blockIdx.x * 256 + tid, r = idx / TILE, c = idx % TILE;
+    double acc = 0.0;
+    if (r < SM && c < SM)
+      for (int g = 0; g < ng; ++g) acc += part[(int64_t)g * P1LEN + r * SM + c];
+    tile[idx] = acc;
+    return;
+  }
+  if (tid < mp) {
+    double acc = 0.0;
+    if (tid < SM)
+      for (int g = 0; g < ng; ++g) acc += part[(int64_t)g * P1LEN + SM * SM + tid];
+    cvec[tid] = acc;
+  } else if (tid >= 192 && tid < 196) {
+    const int k = tid - 192;
+    double acc = 0.0;
+    for (int g = 0; g < ng; ++g) acc += part[(int64_t)g * P1LEN + SM * SM + SM + k];
+    tail[k] = acc;
+  }
+}
+
+template <int DT>
+__global__ __launch_bounds__(256) void small_pass2_kernel(SmallPass2Args a) {
+  extern __shared__ __attribute__((aligned(16))) double small_lds[];
+  double* const Ui = small_lds;          // [SM][SLD]  U^-1
+  double* const Ri = Ui + SM * SLD;      // [SM][SLD]  R~^-1
+  double* const Vt = Ri + SM * SLD;      // [SRB][SLD] V of the block
+  double* const Qt = Vt + SRB * SLD;     // [SRB][SLD] Q', then X~, then X, each in place
+  double* const xs = Qt + SRB * SLD;     // [SRB][DT]
+  double* const isr = xs + SRB * DT;     // [SRB] per-row values of the block
+  double* const vr = isr + SRB;
+  double* const wr = vr + SRB;
+  double* const esr = wr + SRB;
+  double* const q2s = esr + SRB;
+  double* const qbs = q2s + SRB;
+  double* const bv = qbs + SRB;          // [SM] b
+  double* const tt = bv + SM;            // [SM] t~
+  double* const red = tt + SM;           // [4][SM] scratch of the final column reductions
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l15 = lane & 15, lq = lane >> 4;
+  const ExpK ek = exp_consts();
+  const int d = a.d, D = a.D;
+  load_corner(a.uinv, a.mp, Ui, tid);
+  load_corner(a.rinv, a.mp, Ri, tid);
+  if (tid < SM) {
+    bv[tid] = a.bvec[tid];
+    tt[tid] = a.ttil[tid];
+  }
+  const int col = lane, rg = wv;
+  const bool live_c = col < a.m;
+  double z[DT], gx[DT], gb[DT];
+#pragma unroll
+  for (int k = 0; k < DT; ++k) {
+    z[k] = (k < d && live_c) ? a.Z[(int64_t)col * d + k] : 0.0;
+    gx[k] = 0.0;
+    gb[k] = 0.0;
+  }
+  sd4 accG[4];
+#pragma unroll
+  for (int ct = 0; ct < 4; ++ct) accG[ct] = sd4{0.0, 0.0, 0.0, 0.0};
+  double cs = 0.0, sE = 0.0, sED = 0.0, pj = 0.0;
+  double p_v = 0.0, p_is = 0.0, p_res = 0.0, p_v1 = 0.0;
+  const int pj_big = (D > 0 && tid < D * d) ? tid / d : 0, pj_small = (D > 0 && tid < D * d) ? tid % d : 0;
+  const int nblk = a.rows_p / SRB;
+  for (int b = blockIdx.x; b < nblk; b += gridDim.x) {
+    const int r0 = b * SRB;
+    __syncthreads();
+    for (int idx = tid; idx < SRB * DT; idx += 256) {
+      const int r = idx / DT, k = idx % DT;
+      xs[idx] = (k < d && r0 + r < a.rows) ? a.pts[(int64_t)(r0 + r) * d + k] : 0.0;
+    }
+    for (int idx = tid; idx < SRB * SM; idx += 256) {
+      const int r = idx >> 6, c = idx & 63;
+      Vt[r * SLD + c] = a.V[(int64_t)(r0 + r) * a.mp + c];
+    }
+    if (tid < SRB) isr[tid] = a.is[r0 + tid];
+    __syncthreads();
+    sd4 acc[4];
+    rows_times<false>(Vt, Ri, wv, l15, lq, acc);  // Q' = V R~^-1
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      double s2 = 0.0, sb = 0.0;
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct) {
+        s2 += acc[ct][r] * acc[ct][r];
+        sb += acc[ct][r] * bv[16 * ct + l15];
+      }
+      s2 = sum16(s2);
+      sb = sum16(sb);
+      const int row = 16 * wv + lq + 4 * r;
+      if (l15 == 0) {
+        q2s[row] = s2;
+        qbs[row] = sb;
+      }
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct) Qt[row * SLD + 16 * ct + l15] = acc[ct][r];
+    }
+    __syncthreads();
+    if (tid < SRB) {  // q_diag, w, v (as pass2_rows_kernel)
+      const int row = r0 + tid;
+      double w = 0.0, v = 0.0, es = 0.0;
+      if (row < a.rows) {
+        const double is = isr[tid], rr = a.r[row];
+        const double qd = is * q2s[tid], sb = qbs[tid];
+        const double y = a.y ? a.y[row] : 0.0;
+        const double res = a.y ? (y - sb) : 0.0;
+        w = is * res;
+        const double v1 = a.variational ? is * (2.0 - is * rr - qd) : is * (1.0 - qd);
+        v = v1 - w * w;
+        es = qd - v * (a.cp.sf2 - rr) - w * sb;
+        p_v += v;
+        p_is += is;
+        p_res += w * res;
+        p_v1 += v1;
+      }
+      a.w[row] = w;
+      a.v[row] = v;
+      if (a.es) a.es[row] = es;
+      wr[tid] = w;
+      vr[tid] = v;
+      esr[tid] = es;
+    }
+    __syncthreads();
+    rows_times<true>(Qt, Ri, wv, l15, lq, acc);  // Q' R~^-T
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = 16 * wv + lq + 4 * r;
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct) {
+        const int c = 16 * ct + l15;  // X~ = diag(is) Q' R~^-T - diag(v) V - w t~^T
+        Qt[row * SLD + c] = isr[row] * acc[ct][r] - vr[row] * Vt[row * SLD + c] - wr[row] * tt[c];
+      }
+    }
+    rows_times<true>(Qt, Ui, wv, l15, lq, acc);  // X = X~ U^-T
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = 16 * wv + lq + 4 * r;
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct) {
+        Qt[row * SLD + 16 * ct + l15] = acc[ct][r];
+        a.X[(int64_t)(r0 + row) * a.mp + 16 * ct + l15] = acc[ct][r];
+      }
+    }
+    __syncthreads();
+    // E = X .* K of the block: column sums, moments against the points (and the original inputs), sum E, sum E |x - z|^2
+    for (int i = 0; i < 16; ++i) {
+      const int r = rg * 16 + i;
+      double dist = 0.0;
+#pragma unroll
+      for (int k = 0; k < DT; ++k) {
+        if (k < d) {
+          const double diff = xs[r * DT + k] - z[k];
+          dist = dist + diff * diff;
+        }
+      }
+      const bool live = live_c && r0 + r < a.rows;
+      const double e = live ? Qt[r * SLD + col] * exp_fast(a.cp.log_sf2 + a.cp.inv_ell2_05 * dist, ek) : 0.0;
+#pragma unroll
+      for (int k = 0; k < DT; ++k) gx[k] += xs[r * DT + k] * e;
+      if (D > 0 && r0 + r < a.rows) {
+        const double* xb = a.big + (int64_t)(r0 + r) * D;
+#pragma unroll
+        for (int k = 0; k < DT; ++k)
+          if (k < D) gb[k] += xb[k] * e;
+      }
+      cs += e;
+      sE += e;
+      sED += e * dist;
+    }
+    gram_update(Vt, vr, wv, l15, lq, accG);  // G~ part = V^T diag(v) V
+    if (D > 0 && tid < D * d) {  // second term of the `Proj derivative: sum_r x_big,r p_small,r rowsum(E)_r
+      const int nr = min(SRB, a.rows - r0);
+      for (int r = 0; r < nr; ++r) pj += a.big[(int64_t)(r0 + r) * D + pj_big] * xs[r * DT + pj_small] * esr[r];
+    }
+  }
+  double* part = a.part + (int64_t)blockIdx.x * p2len(d, D);
+#pragma unroll
+  for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) part[(16 * wv + lq + 4 * r) * SM + 16 * ct + l15] = accG[ct][r];
+  double* pcol = part + SM * SM;
+  // per-column accumulators: the four row groups of a column are combined in order
+  for (int q = 0; q < 1 + d + D; ++q) {
+    double val = cs;
+    if (q >= 1 && q <= d) {
+#pragma unroll
+      for (int k = 0; k < DT; ++k)
+        if (k == q - 1) val = gx[k];
+    } else if (q > d) {
+#pragma unroll
+      for (int k = 0; k < DT; ++k)
+        if (k == q - 1 - d) val = gb[k];
+    }
+    __syncthreads();
+    red[rg * SM + col] = val;
+    __syncthreads();
+    if (tid < SM) pcol[q * SM + tid] = (red[tid] + red[SM + tid]) + (red[2 * SM + tid] + red[3 * SM + tid]);
+  }
+  double* pproj = pcol + (1 + d + D) * SM;
+  if (D > 0 && tid < D * d) pproj[tid] = pj;
+  double* ptail = pproj + D * d;
+  sE = sum64(sE);
+  sED = sum64(sED);
+  __syncthreads();
+  if (lane == 0) {
+    red[wv] = sE;
+    red[4 + wv] = sED;
+  }
+  __syncthreads();
+  if (wv == 0) {
+    p_v = sum64(p_v);
+    p_is = sum64(p_is);
+    p_res = sum64(p_res);
+    p_v1 = sum64(p_v1);
+    if (lane == 0) {
+      ptail[0] = p_v;
+      ptail[1] = p_is;
+      ptail[2] = p_res;
+      ptail[3] = p_v1;
+      ptail[4] = (red[0] + red[1]) + (red[2] + red[3]);
+      ptail[5] = (red[4] + red[5]) + (red[6] + red[7]);
+      ptail[6] = 0.0;
+      ptail[7] = 0.0;
+    }
+  }
+}
+
+// exchange-2 buffer (already zeroed by the caller) from the pass-2 partials: the 64 x 64 corner of the (0,0) tile, the
+// column block (rows 0..d+D, columns < 64), the `Proj second term and the scalar tail
+__global__ __launch_bounds__(256) void small_reduce2_kernel(const double* __restrict__ part, int ng, int mp, int d, int D,
+                                                            double* __restrict__ tile, double* __restrict__ colblk,
+                                                            double* __restrict__ proj, double* __restrict__ tail) {
+  const int plen = p2len(d, D);
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  const int ncorner = SM * SM, ncol = (1 + d + D) * SM, nproj = D * d;
+  if (idx >= ncorner + ncol + nproj + 8) return;
+  double acc = 0.0;
+  for (int g = 0; g < ng; ++g) acc += part[(int64_t)g * plen + idx];
+  if (idx < ncorner) tile[(idx >> 6) * TILE + (idx & 63)] = acc;
+  else if (idx < ncorner + ncol) colblk[(int64_t)((idx - ncorner) >> 6) * mp + ((idx - ncorner) & 63)] = acc;
+  else if (idx < ncorner + ncol + nproj) proj[idx - ncorner - ncol] = acc;
+  else tail[idx - ncorner - ncol - nproj] = acc;
+}
+
+static size_t small_lds1(int DT) { return (size_t)(2 * SM * SLD + SRB * DT + 3 * SRB) * sizeof(double); }
+static size_t small_lds2(int DT) { return (size_t)(4 * SM * SLD + SRB * DT + 6 * SRB + 2 * SM + 4 * SM) * sizeof(double); }
+
+template <typename F>
+static void small_dispatch(int d, F&& go) {
+  if (d <= 4) go(std::integral_constant<int, 4>{});
+  else if (d <= 8) go(std::integral_constant<int, 8>{});
+  else go(std::integral_constant<int, 16>{});
+}
+
+static void small_attrs() {
+  static uint64_t done = 0;
+  once_per_device(done, [] {
+    auto set = [](const void* f, size_t bytes) {
+      GPR_HIP(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    };
+    set(reinterpret_cast<const void*>(&small_pass1_kernel<4>), small_lds1(4));
+    set(reinterpret_cast<const void*>(&small_pass1_kernel<8>), small_lds1(8));
+    set(reinterpret_cast<const void*>(&small_pass1_kernel<16>), small_lds1(16));
+    set(reinterpret_cast<const void*>(&small_pass2_kernel<4>), small_lds2(4));
+    set(reinterpret_cast<const void*>(&small_pass2_kernel<8>), small_lds2(8));
+    set(reinterpret_cast<const void*>(&small_pass2_kernel<16>), small_lds2(16));
+  });
+}
+
+bool small_path_fits(int m, int mp, int d, int D, int64_t rows) {
+  return m <= SM && mp == TILE && d <= 16 && D <= 16 && rows <= 65536;
+}
+
+void launch_small_pass1(const SmallPass1Args& a, double* tile, double* cvec, double* tail, hipStream_t s) {
+  small_attrs();
+  const int ng = small_groups(a.rows_p);
+  small_dispatch(a.d, [&](auto dt) {
+    constexpr int DT = decltype(dt)::value;
+    hipLaunchKernelGGL((small_pass1_kernel<DT>), dim3(ng), dim3(256), small_lds1(DT), s, a);
+  });
+  hipLaunchKernelGGL(small_reduce1_kernel, dim3(TILE * TILE / 256 + 1), dim3(256), 0, s, a.part, ng, a.mp, tile, cvec, tail);
+  GPR_HIP(hipGetLastError());
+}
+
+void launch_small_pass2(const SmallPass2Args& a, double* tile, double* colblk, double* proj, double* tail, hipStream_t s) {
+  small_attrs();
+  const int ng = small_groups(a.rows_p);
+  small_dispatch(std::max(a.d, a.D), [&](auto dt) {
+    constexpr int DT = decltype(dt)::value;
+    hipLaunchKernelGGL((small_pass2_kernel<DT>), dim3(ng), dim3(256), small_lds2(DT), s, a);
+  });
+  const int nout = SM * SM + (1 + a.d + a.D) * SM + a.D * a.d + 8;
+  hipLaunchKernelGGL(small_reduce2_kernel, dim3((nout + 255) / 256), dim3(256), 0, s, a.part, ng, a.mp, a.d, a.D, tile,
+                     colblk, proj, tail);
+  GPR_HIP(hipGetLastError());
+}
+
+}  // namespace gprhip

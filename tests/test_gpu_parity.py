@@ -52,13 +52,48 @@ def _eval_golden(p, g, **kw):
     return p.eval(**args)
 
 
+def _small_path_applies(g):
+    """gpr_amd/csrc/small.hip: one-kernel row passes for m <= 64, d, D <= 16, no multiscales, one row chunk."""
+    d, m = g["Z"].shape
+    D = g["X"].shape[0]
+    return m <= 64 and d <= 16 and D <= 16 and "log_multiscales" not in g and g["X"].shape[1] <= 65536
+
+
+def _golden_cases(names):
+    """(fixture, row-pass path): fixtures the small path takes also run with GPRHIP_SMALL_PATH=0, through the engine"""
+    out = []
+    for n in names:
+        out.append(pytest.param(n, "default", id=n))
+        if _small_path_applies(load_golden(n)):
+            out.append(pytest.param(n, "engine", id=n + "-engine"))
+    return out
+
+
+def _select_row_path(g, path, monkeypatch):
+    if path == "engine":
+        monkeypatch.setenv("GPRHIP_SMALL_PATH", "0")  # read when the problem is created
+
+
+def _check_row_path(p, g, path):
+    p.set_timing(2)
+    _eval_golden(p, g)
+    stages = set(p.last_timings())
+    p.set_timing(0)
+    if path == "default" and _small_path_applies(g):
+        assert {"p1_small", "p2_small"} <= stages and "p1_trmm_V" not in stages, stages
+    else:
+        assert "p1_trmm_V" in stages and "p1_small" not in stages, stages
+
+
 ISO_GOLDEN = [n for n in golden_names() if n.startswith("iso")]
 
 
-@pytest.mark.parametrize("name", ISO_GOLDEN)
-def test_golden_iso(name):
+@pytest.mark.parametrize("name,path", _golden_cases(ISO_GOLDEN))
+def test_golden_iso(name, path, monkeypatch):
     g = load_golden(name)
+    _select_row_path(g, path, monkeypatch)
     p = _problem_for(g)
+    _check_row_path(p, g, path)
     ev = _eval_golden(p, g)
     assert abs(ev.l1 - g["l1"]) <= TOL_L * abs(g["l1"])
     assert abs(ev.l - g["l"]) <= TOL_L * abs(g["l"])
@@ -84,11 +119,13 @@ def test_golden_iso(name):
 FAT_GOLDEN = [n for n in golden_names() if n.startswith("fat")]
 
 
-@pytest.mark.parametrize("name", FAT_GOLDEN)
-def test_golden_fat(name):
+@pytest.mark.parametrize("name,path", _golden_cases(FAT_GOLDEN))
+def test_golden_fat(name, path, monkeypatch):
     """Cov_se_fat (projection-only): Log_sf2, inducing and Proj hypers in lib/cov_se_fat.ml:290-342 order."""
     g = load_golden(name)
+    _select_row_path(g, path, monkeypatch)
     p = _problem_for(g)
+    _check_row_path(p, g, path)
     ev = _eval_golden(p, g)
     assert abs(ev.l - g["l"]) <= TOL_L * abs(g["l"])
     assert abs(ev.dl_dsigma2 - g["dl_dsigma2"]) <= TOL_DS2 * abs(g["dl_dsigma2"])
@@ -1209,6 +1246,7 @@ def test_scalar_and_mfma_gradient_kernels_agree(name, monkeypatch):
     products as MFMA tiles, |p - z|^2 by expansion) and as the scalar kernel that multiscales still need
     (rowops.hip, direct differences).  Both must meet the oracle tolerance and agree with each other."""
     g = load_golden(name)
+    monkeypatch.setenv("GPRHIP_SMALL_PATH", "0")  # these switches belong to the engine's row passes
     p = _problem_for(g)
     a = _eval_golden(p, g)
     p.close()
@@ -1230,6 +1268,7 @@ def test_resident_and_recomputed_covariance_gradient_passes_agree(name, monkeypa
     g = load_golden(name)
     if "tproj" not in g:
         pytest.skip("no projection hypers in this fixture")
+    monkeypatch.setenv("GPRHIP_SMALL_PATH", "0")  # these switches belong to the engine's row passes
     p = _problem_for(g)
     a = _eval_golden(p, g)
     a2 = _eval_golden(p, g, sigma2=2.0 * float(g["sigma2"]), reuse_v=True)
@@ -1275,6 +1314,7 @@ def test_two_phase_and_two_launch_x_products_agree(name, monkeypatch):
     g = load_golden(name)
     tol = 1e-8 if name.startswith("illcond") else TOL_GRAD
     res = {}
+    monkeypatch.setenv("GPRHIP_SMALL_PATH", "0")  # these switches belong to the engine's row passes
     for mode in ("2", "0"):
         monkeypatch.setenv("GPRHIP_MERGED_X", mode)
         p = _problem_for(g, chunk_rows=512)  # the switch is read when the problem is created
