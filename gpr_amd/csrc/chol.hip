@@ -4,6 +4,7 @@
 // Reference call sites: lib/fitc_gp.ml:53-57 (potrf of K_m + jitter), lib/utils.ml:95-113.
 #include <cstdlib>
 #include "kernels.h"
+#include "exp_fast.h"
 
 namespace gprhip {
 
@@ -12,7 +13,7 @@ constexpr int LDT = NB + 1;     // LDS row stride (bank spread)
 constexpr int MB = 16;          // micro-panel width
 constexpr int PT = 512;         // threads of the diagonal-block kernel
 // LDS: T[NB][LDT] | T1[NB][MB] (product scratch of the inversion) | rdiag[NB] | flag
-constexpr int POTRF_LDS = (NB * LDT + NB * MB + NB) * 8 + 16;
+constexpr int POTRF_LDS = (NB * LDT + NB * MB + NB + 3 * NB) * 8 + 16;  // + c~, b, t~ of the fused B~ phase
 
 // A = U^T U in place on block j (upper); strict lower of the block zeroed; dinv = inv(U_jj).
 //
@@ -45,13 +46,20 @@ __device__ __forceinline__ double* dblk(double* T, int b) {
 // m_real (0 = mp): rows / columns at and beyond it are identity padding (K_m + jitter and B~ are 1 on the padded
 // diagonal, 0 off it): the 16-column micro-panels that lie wholly in the padding are skipped in both phases -- their
 // factor and their inverse are the identity that is already there.  (m = 50: four of eight micro-panels, 47 -> 27 us.)
-__global__ __launch_bounds__(PT) void potrf_diag_kernel(double* __restrict__ A, int mp, int j,
-                                                        double* __restrict__ dinv,
-                                                        int* __restrict__ info, int flags, int m_real) {
+// FUSED (single-block matrices, mp = 128, PotrfFuse in kernels.h): the B~ phase of pass 2 in one kernel -- the block is
+// I + the reduced accumulation of pass 1 instead of a load, and the m-vectors that follow the factorisation (log|B~|, b,
+// t~, t, |b|^2) are formed from the inverse while it is still in LDS: six launches of ~5 us each on the latency chain of
+// every evaluation with m <= 128 become the head and tail of this one.  (Measured and dropped: building K_m + jitter in
+// the same way costs the single workgroup what the cov_upper launch costs; summing the small row pass's per-workgroup
+// partials here instead of in their own launch: 1 MB through one CU, 130 us.)
+template <bool FUSED>
+__device__ __forceinline__ void potrf_diag_body(double* __restrict__ A, int mp, int j, double* __restrict__ dinv,
+                                                int* __restrict__ info, int flags, int m_real, const PotrfFuse& f) {
   extern __shared__ __attribute__((aligned(16))) double T[];  // [NB][LDT]
   double* T1 = T + NB * LDT;                                   // [NB][MB]
   double* rdiag = T1 + NB * MB;                                // [NB] reciprocal pivots
-  int& bad = *reinterpret_cast<int*>(rdiag + NB);              // keep all LDS in the one dynamic array
+  double* cv = rdiag + NB;                                     // [NB] c~, [NB] b, [NB] t~ (FUSED mode 2)
+  int& bad = *reinterpret_cast<int*>(cv + 3 * NB);             // keep all LDS in the one dynamic array
   const int tid = threadIdx.x;
   const int lane = tid & 63, wid = tid >> 6;
   j += blockIdx.x;  // a launch over several blocks handles block j + blockIdx.x (inverse-only pass over all blocks)
@@ -59,12 +67,38 @@ __global__ __launch_bounds__(PT) void potrf_diag_kernel(double* __restrict__ A, 
   const int live = (m_real > 0) ? min(NB, max(1, m_real - j * NB)) : NB;  // real rows of this block
   const int k_end = (live + MB - 1) / MB * MB;                              // micro-panels that hold any of them
   double* Ab = A + (int64_t)j * NB * mp + (int64_t)j * NB;
-  for (int idx = tid; idx < NB * NB / 2; idx += PT) {
-    const int r = idx / (NB / 2), c2 = (idx % (NB / 2)) * 2;
-    if (c2 + 1 >= r) {
-      const double2 v = *reinterpret_cast<const double2*>(Ab + (int64_t)r * mp + c2);
-      T[r * LDT + c2] = v.x;
-      T[r * LDT + c2 + 1] = v.y;
+  // FUSED: thread (i = tid & 127, q = tid >> 7) keeps U^-1[i][32 q .. 32 q + 31] for t = U^-1 t~ at the end
+  double ureg[NB / (PT / NB)];
+  if (FUSED) {
+    // B~ = I + the reduced accumulation of pass 1 ((0,0) tile of the exchange-1 buffer)
+    for (int idx = tid; idx < NB * NB / 2; idx += PT) {
+      const int r = idx / (NB / 2), c2 = (idx % (NB / 2)) * 2;
+      if (c2 + 1 >= r) {
+        const double2 v = *reinterpret_cast<const double2*>(f.src + (int64_t)r * NB + c2);
+        T[r * LDT + c2] = v.x + (c2 == r ? 1.0 : 0.0);
+        T[r * LDT + c2 + 1] = v.y + (c2 + 1 == r ? 1.0 : 0.0);
+      }
+    }
+    if (tid < NB) cv[tid] = f.cvec[tid];
+    else if (tid < NB + 4 && f.tail_out) f.tail_out[tid - NB] = f.tail_in[tid - NB];
+    // issued now, used after the inversion: their latency hides under the factorisation (U^-1 is zero below its diagonal)
+    {
+      const double2* urow = reinterpret_cast<const double2*>(f.uinv + (int64_t)(tid & (NB - 1)) * NB + 32 * (tid / NB));
+#pragma unroll
+      for (int kk = 0; kk < 16; ++kk) {
+        const double2 v = urow[kk];
+        ureg[2 * kk] = v.x;
+        ureg[2 * kk + 1] = v.y;
+      }
+    }
+  } else {
+    for (int idx = tid; idx < NB * NB / 2; idx += PT) {
+      const int r = idx / (NB / 2), c2 = (idx % (NB / 2)) * 2;
+      if (c2 + 1 >= r) {
+        const double2 v = *reinterpret_cast<const double2*>(Ab + (int64_t)r * mp + c2);
+        T[r * LDT + c2] = v.x;
+        T[r * LDT + c2 + 1] = v.y;
+      }
     }
   }
   if (tid == 0) bad = 0;
@@ -252,6 +286,77 @@ __global__ __launch_bounds__(PT) void potrf_diag_kernel(double* __restrict__ A, 
     v.y = (c2 + 1 >= r) ? T[r * LDT + c2 + 1] : 0.0;
     *reinterpret_cast<double2*>(dinv + (int64_t)r * NB + c2) = v;
   }
+  if (FUSED) {
+    // with X = R~^-1 (upper part of T):  b = X^T c~ (= Q_n^T y~, lib/fitc_gp.ml:285-286),  t~ = X b,  t = U^-1 t~ (:291),
+    // log|B~| = -2 sum log(reciprocal pivots) (lib/utils.ml:95-101),  |b|^2
+    double* bv = cv + NB;
+    double* tv = bv + NB;
+    // four threads per entry, a quarter of the summation range each (fixed trip counts, so the LDS reads pipeline;
+    // thread-per-entry loops with data-dependent bounds cost 6 us each, wavefront-wide shuffles reductions 4 us)
+    const int i = tid & (NB - 1), q = tid / NB;
+    {
+      double sum = 0.0;
+#pragma unroll 8
+      for (int kk = 0; kk < 32; ++kk) {
+        const int k = 32 * q + kk;
+        const double x = T[k * LDT + i];
+        sum += (k <= i) ? x * cv[k] : 0.0;
+      }
+      T1[q * NB + i] = sum;
+    }
+    __syncthreads();
+    if (tid < NB) {
+      const double b = (T1[tid] + T1[NB + tid]) + (T1[2 * NB + tid] + T1[3 * NB + tid]);
+      bv[tid] = b;
+      f.bvec[tid] = b;
+    }
+    __syncthreads();
+    {
+      double sum = 0.0;
+#pragma unroll 8
+      for (int kk = 0; kk < 32; ++kk) {
+        const int k = 32 * q + kk;
+        const double x = T[i * LDT + k];
+        sum += (k >= i) ? x * bv[k] : 0.0;
+      }
+      T1[q * NB + i] = sum;
+    }
+    __syncthreads();
+    if (tid < NB) {
+      const double t = (T1[tid] + T1[NB + tid]) + (T1[2 * NB + tid] + T1[3 * NB + tid]);
+      tv[tid] = t;
+      f.ttil[tid] = t;
+    }
+    __syncthreads();
+    {
+      double sum = 0.0;
+#pragma unroll
+      for (int kk = 0; kk < 32; ++kk) sum += ureg[kk] * tv[32 * q + kk];
+      T1[q * NB + i] = sum;
+    }
+    __syncthreads();
+    if (tid < NB) f.tvec[tid] = (T1[tid] + T1[NB + tid]) + (T1[2 * NB + tid] + T1[3 * NB + tid]);
+    if (wid == 0) {
+      double sum = log(rdiag[lane]) + log(rdiag[lane + 64]);
+      for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+      if (lane == 0) f.logdet[0] = -2.0 * sum;
+    } else if (wid == 1) {
+      double sum = bv[lane] * bv[lane] + bv[lane + 64] * bv[lane + 64];
+      for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+      if (lane == 0) f.bb[0] = sum;
+    }
+  }
+}
+
+__global__ __launch_bounds__(PT) void potrf_diag_kernel(double* __restrict__ A, int mp, int j,
+                                                        double* __restrict__ dinv,
+                                                        int* __restrict__ info, int flags, int m_real) {
+  potrf_diag_body<false>(A, mp, j, dinv, info, flags, m_real, PotrfFuse{});
+}
+
+__global__ __launch_bounds__(PT) void potrf_fused_kernel(PotrfFuse f, double* __restrict__ A, double* __restrict__ dinv,
+                                                         int* __restrict__ info, int m_real) {
+  potrf_diag_body<true>(A, NB, 0, dinv, info, 0, m_real, f);
 }
 
 // ---- blocked factorisation without the engine: panel solve and trailing update of one 128-row step
@@ -489,9 +594,16 @@ static void potrf_attrs() {
   once_per_device(done, [] {
     GPR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&potrf_diag_kernel),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, POTRF_LDS));
+    GPR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&potrf_fused_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, POTRF_LDS));
     GPR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&potrf_panel_kernel),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, PANEL_LDS));
   });
+}
+void launch_potrf_fused(const PotrfFuse& f, double* A, double* Xinv, int* info, int m_real, hipStream_t s) {
+  potrf_attrs();
+  hipLaunchKernelGGL(potrf_fused_kernel, dim3(1), dim3(PT), POTRF_LDS, s, f, A, Xinv, info, m_real);
+  GPR_HIP(hipGetLastError());
 }
 void launch_potrf_diag(double* A, int mp, int j, double* dinv, int* info, hipStream_t s) {
   launch_potrf_diag_flags(A, mp, j, dinv, info, 0, s, 0);

@@ -88,6 +88,7 @@ enum {  // device scalar slots
   SC_BB = 1,        // |b|^2 = |Q_n^T y~|^2
   SC_LMAX = 2,      // power-iteration estimates of lambda_max(K_m + jitter) and lambda_max((K_m + jitter)^-1)
   SC_LMAX_INV = 3,
+  SC_A1TAIL = 8,    // 8..11: copy of the reduced exchange-1 tail (single-block problems: written by the fused B~ phase)
 };
 // tail of the exchange-1 buffer
 enum { A1_SUMLOGS = 0, A1_ISY2 = 1, A1_ISR = 2, A1_TAIL = 4 };
@@ -187,7 +188,9 @@ struct gprhip_problem {
   // Results of an evaluation come back as one block as well: [scalars (NSCAL) | potrf flags (2 ints in one double) |
   // t (mp) | K_m traces (km_rows x mp) | diag W (mp)] = res_dev -> res_host (pinned), plus the tails of the two exchange
   // buffers (ex_host: [A1_TAIL | column block .. end of the exchange-2 buffer]).
-  double *res_dev = nullptr, *res_host = nullptr, *ex_host = nullptr;
+  // ex_host / ex_dev lie directly behind the result block (one transfer can bring both)
+  double *res_dev = nullptr, *res_host = nullptr, *ex_host = nullptr, *ex_dev = nullptr;
+  bool a1_in_scal = false;  // this evaluation's exchange-1 tail is in the result block's scalars (SC_A1TAIL)
   int64_t res_len = 0, ex_len = 0;
   double *ms = nullptr, *rowes = nullptr, *es2 = nullptr;  // multiscales [mp][d]; per-row E/ms partials
   double* wdiag = nullptr;  // diag W inside the result block
@@ -221,7 +224,8 @@ struct gprhip_problem {
   // exchange-2 column block: sum E, sum p_k E (d), sum x_big E (D), and for Cov_se_fat sum p_k^2 E (d)
   int64_t col_rows() const { return d + 1 + dbig() + (kind == GPRHIP_COV_SE_FAT ? d : 0); }
   bool use_small() const {
-    return small_path && !f32 && nchunks == 1 && !has_ms() && small_path_fits(m, mp, d, has_proj() ? D : 0, n);
+    return small_path && !f32 && !engine_steps && nchunks == 1 && !has_ms() &&
+           small_path_fits(m, mp, d, has_proj() ? D : 0, n);
   }
 };
 
@@ -711,26 +715,62 @@ void do_pass2(gprhip_problem* p, const double* ar1, double* ar2) {
 
   tstart(p, "b_chol");
   // B~ = I + sum of shard parts; R~ = chol(B~): R = R~ U is the reference's r_mat (lib/fitc_gp.ml:181)
-  hipLaunchKernelGGL(add_identity_upper_kernel, dim3((mp + 255) / 256, mp), dim3(256), 0, s, ar1, mp,
-                     p->bmat);
-  potrf_trtri(p, p->bmat, p->rinv, p->wmat, p->info + 1);
-  launch_logdet(p->bmat, mp, mp, p->scal + SC_LOGDET_B, s);
+  const bool fused_b = mp == TILE && !p->engine_steps;
+  p->a1_in_scal = fused_b;
+  if (fused_b) {
+    // a single block: I + the accumulation, the factorisation, the inverse and the m-vectors below in one kernel
+    PotrfFuse f;
+    f.src = ar1; f.cvec = ar1_c;
+    f.tail_in = ar1_c + mp; f.tail_out = p->scal + SC_A1TAIL;
+    f.uinv = p->uinv; f.bvec = p->bvec; f.ttil = p->ttil; f.tvec = p->tvec;
+    f.logdet = p->scal + SC_LOGDET_B; f.bb = p->scal + SC_BB;
+    launch_potrf_fused(f, p->bmat, p->rinv, p->info + 1, p->m, s);
+  } else {
+    hipLaunchKernelGGL(add_identity_upper_kernel, dim3((mp + 255) / 256, mp), dim3(256), 0, s, ar1, mp,
+                       p->bmat);
+    potrf_trtri(p, p->bmat, p->rinv, p->wmat, p->info + 1);
+    launch_logdet(p->bmat, mp, mp, p->scal + SC_LOGDET_B, s);
+  }
   if (p->f32) launch_to_float(p->rinv, p->rinv_f, mm, s);
   TS* const Vstore = static_cast<TS*>(p->Vstore);
   TS* const bufA = static_cast<TS*>(p->bufA);
   TS* const bufB = static_cast<TS*>(p->bufB);
   TS* const slices = static_cast<TS*>(p->slices);
   // b = R~^-T c~ (= Q_n^T y~, lib/fitc_gp.ml:285-286);  t~ = R~^-1 b;  t = U^-1 t~ (trsv, :291 / :1167)
-  launch_triu_matvec(p->rinv, mp, ar1_c, p->bvec, 1, s);
-  launch_triu_matvec(p->rinv, mp, p->bvec, p->ttil, 0, s);
-  launch_triu_matvec(p->uinv, mp, p->ttil, p->tvec, 0, s);
-  hipLaunchKernelGGL(dot_kernel, dim3(1), dim3(256), 0, s, p->bvec, p->bvec, mp, p->scal + SC_BB);
+  if (!fused_b) {
+    launch_triu_matvec(p->rinv, mp, ar1_c, p->bvec, 1, s);
+    launch_triu_matvec(p->rinv, mp, p->bvec, p->ttil, 0, s);
+    launch_triu_matvec(p->uinv, mp, p->ttil, p->tvec, 0, s);
+    hipLaunchKernelGGL(dot_kernel, dim3(1), dim3(256), 0, s, p->bvec, p->bvec, mp, p->scal + SC_BB);
+  }
   tstop(p);
 
   // evidence-only evaluations (multim_f) carry nothing in the second exchange buffer: only its scalar tail is cleared,
   // and the caller need not reduce it
-  if (p->want_grad) GPR_HIP(hipMemsetAsync(ar2, 0, (size_t)gprhip_ar2_len(p) * sizeof(double), s));
-  else GPR_HIP(hipMemsetAsync(ar2_tail, 0, (size_t)A2_TAIL * sizeof(double), s));
+  const bool small = p->use_small();  // its reduction writes every entry of the exchange-2 buffer
+  if (p->want_grad && !small) GPR_HIP(hipMemsetAsync(ar2, 0, (size_t)gprhip_ar2_len(p) * sizeof(double), s));
+  else if (!p->want_grad) GPR_HIP(hipMemsetAsync(ar2_tail, 0, (size_t)A2_TAIL * sizeof(double), s));
+  if constexpr (std::is_same<TS, double>::value) {
+    if (p->want_grad && small) {
+      // small problems: Q', the row quantities, X~, X, the column sums of E = X .* K and G~ in one kernel (small.hip);
+      // B~^-1 is formed by the finish kernel, R^-1 is not needed
+      tstart(p, "p2_small");
+      if (!p->small_part) p->small_part = p->alloc<double>(small_part_len(p->d, p->D));
+      p->merged_x = false;
+      SmallPass2Args a;
+      a.cp = p->cp; a.pts = p->pts(); a.Z = p->Z; a.uinv = p->uinv; a.rinv = p->rinv; a.bvec = p->bvec; a.ttil = p->ttil;
+      a.V = Vstore; a.y = mo ? nullptr : p->y; a.is = p->is; a.r = p->r;
+      a.big = proj ? p->X : nullptr; a.D = proj ? p->D : 0;
+      a.rows = (int)p->n; a.rows_p = (int)round_up(p->n, TILE); a.m = p->m; a.mp = mp; a.d = p->d;
+      a.variational = p->h.variational;
+      a.w = p->w; a.v = p->v; a.es = proj ? p->es : nullptr; a.X = bufB; a.part = p->small_part;
+      launch_small_pass2(a, (int)p->col_rows(), ar2, ar2_col, ar2_proj, ar2_tail, s);
+      p->x_last = bufB;
+      tstop(p);
+      p->stage = 2;
+      return;
+    }
+  }
   if (p->want_grad) {
     // B~^-1 = R~^-1 R~^-T (needed by the finish stage only) and R^-1 = U^-1 R~^-1 (needed by the first X product) do not
     // belong on the chain between the factorisation and the Q' products: they go to the second stream and run beside
@@ -747,8 +787,7 @@ void do_pass2(gprhip_problem* p, const double* ar1, double* ar2) {
     // The two-phase X product (below) needs R^-1 = U^-1 R~^-1, one more m x m product (0.14 ms at m = 2048, 0.8 ms at
     // m = 4096), and saves 2.5 us per 1000 training points at m = 2048 (6 us at m = 4096): taken from 48 m training
     // points per shard on.
-    const bool small = p->use_small();
-    p->merged_x = !small && (p->merged_x_mode == 2 || (p->merged_x_mode == 1 && p->n >= 48 * (int64_t)p->m));
+    p->merged_x = p->merged_x_mode == 2 || (p->merged_x_mode == 1 && p->n >= 48 * (int64_t)p->m);
     if (p->merged_x) {
       GemmArgs rf;  // R^-1 = U^-1 R~^-1, both upper triangular
       rf.A = p->uinv; rf.lda = mp; rf.B = p->rinv; rf.ldb = mp; rf.C = p->rfinv; rf.ldc = mp;
@@ -771,26 +810,6 @@ void do_pass2(gprhip_problem* p, const double* ar1, double* ar2) {
     if (side) GPR_HIP(hipEventRecord(p->ev_binv, si));
     tstop(p);
     bool derive_inducing = false;
-    if constexpr (std::is_same<TS, double>::value) {
-      if (small) {
-        // small problems: Q', the row quantities, X~, X, the column sums of E = X .* K and G~ in one kernel (small.hip)
-        tstart(p, "p2_small");
-        if (!p->small_part) p->small_part = p->alloc<double>(small_part_len(p->d, p->D));
-        SmallPass2Args a;
-        a.cp = p->cp; a.pts = p->pts(); a.Z = p->Z; a.uinv = p->uinv; a.rinv = p->rinv; a.bvec = p->bvec; a.ttil = p->ttil;
-        a.V = Vstore; a.y = mo ? nullptr : p->y; a.is = p->is; a.r = p->r;
-        a.big = proj ? p->X : nullptr; a.D = proj ? p->D : 0;
-        a.rows = (int)p->n; a.rows_p = (int)round_up(p->n, TILE); a.m = p->m; a.mp = mp; a.d = p->d;
-        a.variational = p->h.variational;
-        a.w = p->w; a.v = p->v; a.es = proj ? p->es : nullptr; a.X = bufB; a.part = p->small_part;
-        launch_small_pass2(a, ar2, ar2_col, ar2_proj, ar2_tail, s);
-        p->x_last = bufB;
-        tstop(p);
-        if (side) GPR_HIP(hipStreamWaitEvent(s, p->ev_binv, 0));
-        p->stage = 2;
-        return;
-      }
-    }
     for (int c = 0; c < p->nchunks; ++c) {
       const int64_t rows = p->rows_of(c);
       const int rows_p = (int)round_up(rows, TILE);
@@ -945,6 +964,21 @@ void do_finish_enqueue(gprhip_problem* p, const double* ar2, bool light = false)
     return;
   }
   const bool wdiag = p->want_grad && (p->has_het() || p->has_ms());
+  const int64_t n_a2 = (ar2_tail + A2_TAIL) - ar2_col;  // the exchange-2 buffer from its column block on
+  if (p->want_grad && p->use_small()) {
+    // small problems: the m x m work in one workgroup, which also gathers the exchange-2 tail behind the result block
+    tstart(p, "finish");
+    SmallFinishArgs a;
+    a.uinv = p->uinv; a.rinv = p->rinv; a.ttil = p->ttil; a.km = p->km; a.Z = p->Z; a.g = ar2;
+    a.m = m; a.mp = mp; a.d = d; a.km_rows = d + 2;
+    a.wmat = p->wmat; a.kmred = p->kmred; a.wdiag = wdiag ? p->wdiag : nullptr;
+    a.gather_from = ar2_col; a.n_gather = n_a2; a.ex = p->ex_dev + A1_TAIL;
+    launch_small_finish(a, s);
+    tstop(p);
+    GPR_HIP(hipMemcpyAsync(p->res_host, p->res_dev, (size_t)(p->res_len + A1_TAIL + n_a2) * sizeof(double),
+                           hipMemcpyDeviceToHost, s));
+    return;
+  }
   if (p->want_grad) {
     tstart(p, "finish");
     launch_build_w(p->binv, p->ttil, ar2, mp, p->wtil, s);
@@ -973,14 +1007,12 @@ void do_finish_enqueue(gprhip_problem* p, const double* ar2, bool light = false)
   // pass 2), and the exchange-2 buffer from its column block on (its scalar tail only after an evidence-only evaluation)
   const int64_t res_used = NSCAL + 2 + mp + (p->want_grad ? p->km_rows() * mp + (wdiag ? mp : 0) : 0);
   GPR_HIP(hipMemcpyAsync(p->res_host, p->res_dev, (size_t)res_used * sizeof(double), hipMemcpyDeviceToHost, s));
-  GPR_HIP(hipMemcpyAsync(p->ex_host, p->ar1 + packed_upper_len(mp) + mp, A1_TAIL * sizeof(double),
-                         hipMemcpyDeviceToHost, s));
+  if (!p->a1_in_scal)
+    GPR_HIP(hipMemcpyAsync(p->ex_host, p->ar1 + packed_upper_len(mp) + mp, A1_TAIL * sizeof(double),
+                           hipMemcpyDeviceToHost, s));
+  // (an evidence-only evaluation reads nothing of the exchange-2 buffer)
   if (p->want_grad)
-    GPR_HIP(hipMemcpyAsync(p->ex_host + A1_TAIL, ar2_col, (size_t)(ar2_tail + A2_TAIL - ar2_col) * sizeof(double),
-                           hipMemcpyDeviceToHost, s));
-  else
-    GPR_HIP(hipMemcpyAsync(p->ex_host + A1_TAIL + (ar2_tail - ar2_col), ar2_tail, A2_TAIL * sizeof(double),
-                           hipMemcpyDeviceToHost, s));
+    GPR_HIP(hipMemcpyAsync(p->ex_host + A1_TAIL, ar2_col, (size_t)n_a2 * sizeof(double), hipMemcpyDeviceToHost, s));
 }
 
 // Finish stage, second half: wait for the stream, check the factorisations, assemble l1, l2, dl/dsigma2 and the gradient
@@ -1001,7 +1033,7 @@ void do_finish_collect(gprhip_problem* p, gprhip_result* res, double* grad, doub
   const double* const ht = p->res_host + NSCAL + 2;
   const double* const hkm = ht + mp;
   const double* const hwdiag = hkm + p->km_rows() * mp;
-  const double* const ha1tail = p->ex_host;
+  const double* const ha1tail = p->a1_in_scal ? hscal + SC_A1TAIL : p->ex_host;
   const double* const hcol = p->ex_host + A1_TAIL;  // column block + Proj second term + scalar tail of exchange 2
   const double* const htail = hcol + p->col_rows() * mp + (int64_t)p->dbig() * d;
   if (hinfo[0] != 0 || hinfo[1] != 0) {
@@ -1643,15 +1675,17 @@ int gprhip_problem_create_ex(int device, int cov_kind, int precision, int64_t n,
     p->bvec = p->alloc<double>(mp); p->ttil = p->alloc<double>(mp);
     {  // the result block and its pinned mirror; the tails of the exchange buffers land in ex_host (do_finish_enqueue)
       p->res_len = NSCAL + 2 + mp + p->km_rows() * mp + mp;
-      p->res_dev = p->alloc<double>(p->res_len);
+      p->ex_len = A1_TAIL + p->col_rows() * mp + (int64_t)p->dbig() * d + A2_TAIL;
+      p->res_dev = p->alloc<double>(p->res_len + p->ex_len);
+      p->ex_dev = p->res_dev + p->res_len;
       p->scal = p->res_dev;
       p->info = reinterpret_cast<int*>(p->res_dev + NSCAL);
       p->tvec = p->res_dev + NSCAL + 2;
       p->kmred = p->tvec + mp;
       p->wdiag = p->kmred + p->km_rows() * mp;
-      p->ex_len = A1_TAIL + p->col_rows() * mp + (int64_t)p->dbig() * d + A2_TAIL;
-      GPR_HIP(hipHostMalloc(reinterpret_cast<void**>(&p->res_host), (size_t)p->res_len * sizeof(double), hipHostMallocDefault));
-      GPR_HIP(hipHostMalloc(reinterpret_cast<void**>(&p->ex_host), (size_t)p->ex_len * sizeof(double), hipHostMallocDefault));
+      GPR_HIP(hipHostMalloc(reinterpret_cast<void**>(&p->res_host), (size_t)(p->res_len + p->ex_len) * sizeof(double),
+                            hipHostMallocDefault));
+      p->ex_host = p->res_host + p->res_len;
     }
     p->r = p->alloc<double>(npad); p->is = p->alloc<double>(npad); p->yis = p->alloc<double>(npad);
     p->w = p->alloc<double>(npad); p->v = p->alloc<double>(npad);
@@ -1699,7 +1733,6 @@ void gprhip_problem_destroy(gprhip_problem* p) {
   if (p->ev_hy) hipEventDestroy(p->ev_hy);
   if (p->hy_host) hipHostFree(p->hy_host);
   if (p->res_host) hipHostFree(p->res_host);
-  if (p->ex_host) hipHostFree(p->ex_host);
   if (p->ev_fork) hipEventDestroy(p->ev_fork);
   if (p->ev_join) hipEventDestroy(p->ev_join);
   if (p->ev_rf) hipEventDestroy(p->ev_rf);

@@ -56,6 +56,18 @@ void launch_potrf_diag_flags(double* A, int mp, int j, double* dinv, int* info, 
 // receives the block inverses as before.
 void potrf_upper_blocked(hipStream_t s, double* A, int mp, double* dinv, int* info, double* Yscratch = nullptr,
                          double* Xinv = nullptr, int m_real = 0);
+// Single-block matrices (mp = 128): A = chol(I + src) (upper, in place of a load: src = the (0,0) tile of an exchange-1
+// buffer), Xinv = A^-1, and the m-vectors that follow in pass 2 (chol.hip, potrf_diag_body<true>):
+//   b = Xinv^T cvec, t~ = Xinv b, t = uinv t~, logdet = log|I + src|, bb = |b|^2
+struct PotrfFuse {
+  const double* src = nullptr;
+  const double* cvec = nullptr;
+  const double* uinv = nullptr;  // U^-1 [128][128]
+  const double* tail_in = nullptr;  // four scalars copied to tail_out (the exchange-1 tail, into the result block)
+  double* tail_out = nullptr;
+  double *bvec = nullptr, *ttil = nullptr, *tvec = nullptr, *logdet = nullptr, *bb = nullptr;  // out
+};
+void launch_potrf_fused(const PotrfFuse& f, double* A, double* Xinv, int* info, int m_real, hipStream_t s);
 void launch_zero_strict_lower(double* A, int mp, hipStream_t s);
 void launch_copy_block(const double* src, int64_t lds, double* dst, int64_t ldd, int rows, int cols,
                        hipStream_t s);
@@ -220,7 +232,20 @@ bool small_path_fits(int m, int mp, int d, int D, int64_t rows);
 int64_t small_part_len(int d, int D);
 // pass 1 + its reduction into the exchange-1 buffer: (0,0) tile, c~ [mp], scalar tail [4]
 void launch_small_pass1(const SmallPass1Args& a, double* tile, double* cvec, double* tail, hipStream_t s);
-// pass 2 + its reduction into the (zeroed) exchange-2 buffer: (0,0) tile, column block (ld mp), `Proj term [D*d], tail [8]
-void launch_small_pass2(const SmallPass2Args& a, double* tile, double* colblk, double* proj, double* tail, hipStream_t s);
+// pass 2 + its reduction into the exchange-2 buffer, every entry of which is written: (0,0) tile, column block
+// (col_rows x mp), `Proj term [D*d], tail [8]
+void launch_small_pass2(const SmallPass2Args& a, int col_rows, double* tile, double* colblk, double* proj, double* tail,
+                        hipStream_t s);
+// the finish stage of a gradient evaluation (m x m work on the 64 x 64 corners) in one workgroup
+struct SmallFinishArgs {
+  const double *uinv, *rinv, *ttil, *km, *Z;
+  const double* g;          // (0,0) tile of the reduced exchange-2 buffer: G~ = V^T diag(v) V
+  int m, mp, d, km_rows;    // km_rows: rows of kmred to write (0: sum W.*K, 1: sum W.*K.*dist, 2+k: per dimension)
+  double *wmat, *kmred, *wdiag;  // out (wdiag may be null)
+  const double* gather_from;     // n_gather doubles copied to ex (the exchange-2 tail behind the result block)
+  int64_t n_gather;
+  double* ex;
+};
+void launch_small_finish(const SmallFinishArgs& a, hipStream_t s);
 
 }  // namespace gprhip

@@ -206,8 +206,10 @@ __global__ __launch_bounds__(256) void small_reduce1_kernel(const double* __rest
   if (blockIdx.x < TILE * TILE / 256) {
     const int idx = blockIdx.x * 256 + tid, r = idx / TILE, c = idx % TILE;
     double acc = 0.0;
-    if (r < SM && c < SM)
+    if (r < SM && c < SM) {
+#pragma unroll 8
       for (int g = 0; g < ng; ++g) acc += part[(int64_t)g * P1LEN + r * SM + c];
+    }
     tile[idx] = acc;
     return;
   }
@@ -429,24 +431,135 @@ __global__ __launch_bounds__(256) void small_pass2_kernel(SmallPass2Args a) {
   }
 }
 
-// exchange-2 buffer (already zeroed by the caller) from the pass-2 partials: the 64 x 64 corner of the (0,0) tile, the
-// column block (rows 0..d+D, columns < 64), the `Proj second term and the scalar tail
+// exchange-2 buffer from the pass-2 partials, every entry written: the (0,0) tile (zero outside its 64 x 64 corner), the
+// column block (col_rows x mp; rows 0..d+D, columns < 64 carry sums), the `Proj second term and the scalar tail
 __global__ __launch_bounds__(256) void small_reduce2_kernel(const double* __restrict__ part, int ng, int mp, int d, int D,
-                                                            double* __restrict__ tile, double* __restrict__ colblk,
-                                                            double* __restrict__ proj, double* __restrict__ tail) {
+                                                            int col_rows, double* __restrict__ tile,
+                                                            double* __restrict__ colblk, double* __restrict__ proj,
+                                                            double* __restrict__ tail) {
   const int plen = p2len(d, D);
-  const int idx = blockIdx.x * 256 + threadIdx.x;
-  const int ncorner = SM * SM, ncol = (1 + d + D) * SM, nproj = D * d;
-  if (idx >= ncorner + ncol + nproj + 8) return;
+  int idx = blockIdx.x * 256 + threadIdx.x;
+  const int ntile = TILE * TILE, ncol = col_rows * mp, nproj = D * d;
+  int src = -1;
+  double* dst;
+  if (idx < ntile) {
+    const int r = idx / TILE, c = idx % TILE;
+    dst = tile + idx;
+    if (r < SM && c < SM) src = r * SM + c;
+  } else if ((idx -= ntile) < ncol) {
+    const int q = idx / mp, c = idx % mp;
+    dst = colblk + idx;
+    if (q < 1 + d + D && c < SM) src = SM * SM + q * SM + c;
+  } else if ((idx -= ncol) < nproj) {
+    dst = proj + idx;
+    src = SM * SM + (1 + d + D) * SM + idx;
+  } else if ((idx -= nproj) < 8) {
+    dst = tail + idx;
+    src = SM * SM + (1 + d + D) * SM + nproj + idx;
+  } else {
+    return;
+  }
   double acc = 0.0;
-  for (int g = 0; g < ng; ++g) acc += part[(int64_t)g * plen + idx];
-  if (idx < ncorner) tile[(idx >> 6) * TILE + (idx & 63)] = acc;
-  else if (idx < ncorner + ncol) colblk[(int64_t)((idx - ncorner) >> 6) * mp + ((idx - ncorner) & 63)] = acc;
-  else if (idx < ncorner + ncol + nproj) proj[idx - ncorner - ncol] = acc;
-  else tail[idx - ncorner - ncol - nproj] = acc;
+  if (src >= 0) {
+#pragma unroll 8
+    for (int g = 0; g < ng; ++g) acc += part[(int64_t)g * plen + src];
+  }
+  *dst = acc;
+}
+
+// Finish stage of a small gradient evaluation in one workgroup (the m x m work of do_finish_enqueue on 64 x 64 corners):
+//   B~^-1 = R~^-1 R~^-T (Utils.ichol, lib/utils.ml:110-113),  W~ = I - B~^-1 - t~ t~^T - G~,  W = U^-1 W~ U^-T
+//   (lib/fitc_gp.ml:1196-1203), the trace terms of W against K_m and its derivatives (km_traces_kernel: :956-973,
+//   lib/utils.ml:196-220), diag W, and the tails of both exchange buffers gathered behind the result block.
+template <int DT>
+__global__ __launch_bounds__(256) void small_finish_kernel(SmallFinishArgs a) {
+  extern __shared__ __attribute__((aligned(16))) double small_lds[];
+  double* const Ui = small_lds;        // [SM][SLD] U^-1
+  double* const Ri = Ui + SM * SLD;    // [SM][SLD] R~^-1
+  double* const Wt = Ri + SM * SLD;    // [SM][SLD] W~, then W
+  double* const Yt = Wt + SM * SLD;    // [SM][SLD] W~ U^-T
+  double* const zs = Yt + SM * SLD;    // [SM][DT]
+  double* const tt = zs + SM * DT;     // [SM]
+  double* const red = tt + SM;         // [4][SM]
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l15 = lane & 15, lq = lane >> 4;
+  const int d = a.d, m = a.m;
+  load_corner(a.uinv, a.mp, Ui, tid);
+  load_corner(a.rinv, a.mp, Ri, tid);
+  if (tid < SM) tt[tid] = a.ttil[tid];
+  for (int idx = tid; idx < SM * DT; idx += 256) {
+    const int c = idx / DT, k = idx % DT;
+    zs[idx] = (k < d && c < m) ? a.Z[(int64_t)c * d + k] : 0.0;
+  }
+  for (int64_t i = tid; i < a.n_gather; i += 256) a.ex[i] = a.gather_from[i];
+  __syncthreads();
+  sd4 acc[4];
+  rows_times<true>(Ri, Ri, wv, l15, lq, acc);  // B~^-1
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int row = 16 * wv + lq + 4 * r;
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) {
+      const int c = 16 * ct + l15;
+      const int rr = min(row, c), cc = max(row, c);  // G~ is valid in the upper triangle: mirrored, as build_w_kernel
+      Wt[row * SLD + c] = (row == c ? 1.0 : 0.0) - acc[ct][r] - tt[row] * tt[c] - a.g[rr * TILE + cc];
+    }
+  }
+  rows_times<true>(Wt, Ui, wv, l15, lq, acc);  // Y = W~ U^-T (rows of this wavefront)
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) Yt[(16 * wv + lq + 4 * r) * SLD + 16 * ct + l15] = acc[ct][r];
+  __syncthreads();
+  rows_times<false>(Ui, Yt, wv, l15, lq, acc);  // W = U^-1 Y
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int row = 16 * wv + lq + 4 * r;
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) {
+      Wt[row * SLD + 16 * ct + l15] = acc[ct][r];
+      a.wmat[(int64_t)row * a.mp + 16 * ct + l15] = acc[ct][r];
+    }
+  }
+  __syncthreads();
+  const int col = lane, rg = wv;
+  double g[DT], s0 = 0.0, s1 = 0.0;
+#pragma unroll
+  for (int k = 0; k < DT; ++k) g[k] = 0.0;
+  if (col < m) {
+    for (int i = 0; i < 16; ++i) {
+      const int r = rg * 16 + i;
+      if (r >= m) break;
+      const double wk = Wt[r * SLD + col] * a.km[(int64_t)r * a.mp + col];
+      double dist = 0.0;
+#pragma unroll
+      for (int k = 0; k < DT; ++k) {
+        const double df = zs[r * DT + k] - zs[col * DT + k];
+        dist += df * df;
+        g[k] += wk * df;
+      }
+      s0 += wk;
+      s1 += wk * dist;
+    }
+  }
+  for (int q = 0; q < a.km_rows; ++q) {
+    double val = 0.0;
+    if (q == 0) val = s0;
+    else if (q == 1) val = s1;
+    else {
+#pragma unroll
+      for (int k = 0; k < DT; ++k)
+        if (k == q - 2) val = g[k];
+    }
+    __syncthreads();
+    red[rg * SM + col] = val;
+    __syncthreads();
+    if (tid < SM) a.kmred[(int64_t)q * a.mp + tid] = (red[tid] + red[SM + tid]) + (red[2 * SM + tid] + red[3 * SM + tid]);
+  }
+  if (a.wdiag && tid < SM) a.wdiag[tid] = Wt[tid * SLD + tid];
 }
 
 static size_t small_lds1(int DT) { return (size_t)(2 * SM * SLD + SRB * DT + 3 * SRB) * sizeof(double); }
+static size_t small_lds3(int DT) { return (size_t)(4 * SM * SLD + SM * DT + SM + 4 * SM) * sizeof(double); }
 static size_t small_lds2(int DT) { return (size_t)(4 * SM * SLD + SRB * DT + 6 * SRB + 2 * SM + 4 * SM) * sizeof(double); }
 
 template <typename F>
@@ -468,6 +581,9 @@ static void small_attrs() {
     set(reinterpret_cast<const void*>(&small_pass2_kernel<4>), small_lds2(4));
     set(reinterpret_cast<const void*>(&small_pass2_kernel<8>), small_lds2(8));
     set(reinterpret_cast<const void*>(&small_pass2_kernel<16>), small_lds2(16));
+    set(reinterpret_cast<const void*>(&small_finish_kernel<4>), small_lds3(4));
+    set(reinterpret_cast<const void*>(&small_finish_kernel<8>), small_lds3(8));
+    set(reinterpret_cast<const void*>(&small_finish_kernel<16>), small_lds3(16));
   });
 }
 
@@ -486,16 +602,26 @@ void launch_small_pass1(const SmallPass1Args& a, double* tile, double* cvec, dou
   GPR_HIP(hipGetLastError());
 }
 
-void launch_small_pass2(const SmallPass2Args& a, double* tile, double* colblk, double* proj, double* tail, hipStream_t s) {
+void launch_small_pass2(const SmallPass2Args& a, int col_rows, double* tile, double* colblk, double* proj, double* tail,
+                        hipStream_t s) {
   small_attrs();
   const int ng = small_groups(a.rows_p);
   small_dispatch(std::max(a.d, a.D), [&](auto dt) {
     constexpr int DT = decltype(dt)::value;
     hipLaunchKernelGGL((small_pass2_kernel<DT>), dim3(ng), dim3(256), small_lds2(DT), s, a);
   });
-  const int nout = SM * SM + (1 + a.d + a.D) * SM + a.D * a.d + 8;
-  hipLaunchKernelGGL(small_reduce2_kernel, dim3((nout + 255) / 256), dim3(256), 0, s, a.part, ng, a.mp, a.d, a.D, tile,
-                     colblk, proj, tail);
+  const int nout = TILE * TILE + col_rows * a.mp + a.D * a.d + 8;
+  hipLaunchKernelGGL(small_reduce2_kernel, dim3((nout + 255) / 256), dim3(256), 0, s, a.part, ng, a.mp, a.d, a.D, col_rows,
+                     tile, colblk, proj, tail);
+  GPR_HIP(hipGetLastError());
+}
+
+void launch_small_finish(const SmallFinishArgs& a, hipStream_t s) {
+  small_attrs();
+  small_dispatch(a.d, [&](auto dt) {
+    constexpr int DT = decltype(dt)::value;
+    hipLaunchKernelGGL((small_finish_kernel<DT>), dim3(1), dim3(256), small_lds3(DT), s, a);
+  });
   GPR_HIP(hipGetLastError());
 }
 

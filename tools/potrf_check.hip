@@ -9,6 +9,12 @@ int main() {
   std::vector<double> G(n * n), A(n * n);
   for (auto& v : G) v = (double)rand() / RAND_MAX - 0.5;
   for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) { double s = 0; for (int k = 0; k < n; ++k) s += G[i*n+k]*G[j*n+k]; A[i*n+j] = s + (i==j ? 1.0 : 0.0); }
+  // M_REAL=<m>: the block as a problem with m < 128 inducing points presents it (identity padding), micro-panels trimmed
+  const int m_real = getenv("M_REAL") ? atoi(getenv("M_REAL")) : 0;
+  if (m_real > 0)
+    for (int i = 0; i < n; ++i)
+      for (int j = 0; j < n; ++j)
+        if (i >= m_real || j >= m_real) A[i*n+j] = (i == j) ? 1.0 : 0.0;
   double *dA, *dD; int* dI;
   hipMalloc(&dA, n*n*8); hipMalloc(&dD, n*n*8); hipMalloc(&dI, 8); hipMemset(dI, 0, 8);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
@@ -17,7 +23,7 @@ int main() {
     for (int rep = 0; rep < 5; ++rep) {
       hipMemcpy(dA, A.data(), n*n*8, hipMemcpyHostToDevice);
       hipEventRecord(e0, 0);
-      launch_potrf_diag_flags(dA, n, 0, dD, dI, flags, 0);
+      launch_potrf_diag_flags(dA, n, 0, dD, dI, flags, 0, m_real);
       hipEventRecord(e1, 0); hipEventSynchronize(e1);
       float ms; hipEventElapsedTime(&ms, e0, e1); best = std::min(best, ms);
     }
@@ -25,7 +31,7 @@ int main() {
   }
   // correctness of the full kernel
   hipMemcpy(dA, A.data(), n*n*8, hipMemcpyHostToDevice);
-  launch_potrf_diag_flags(dA, n, 0, dD, dI, 0, 0);
+  launch_potrf_diag_flags(dA, n, 0, dD, dI, 0, 0, m_real);
   std::vector<double> U(n*n), D(n*n);
   hipMemcpy(U.data(), dA, n*n*8, hipMemcpyDeviceToHost); hipMemcpy(D.data(), dD, n*n*8, hipMemcpyDeviceToHost);
   double e1m = 0, e2m = 0;
