@@ -151,7 +151,7 @@ __device__ __forceinline__ void potrf_diag_body(double* __restrict__ A, int mp, 
     }
     __syncthreads();
     // panel: U12 = U11^-T A12, one thread per column (forward substitution in registers)
-    if (tid < NB && tid >= k0 + MB && !(flags & 8)) {
+    if (tid < k_end && tid >= k0 + MB && !(flags & 8)) {  // (columns in the padding are zero above the unit diagonal)
       double x[MB];
 #pragma unroll
       for (int q = 0; q < MB; ++q) {
@@ -166,7 +166,7 @@ __device__ __forceinline__ void potrf_diag_body(double* __restrict__ A, int mp, 
     __syncthreads();
     // trailing: A22 -= U12^T U12, one 16x16 tile (ti <= tj) per wavefront at a time, 4 MFMAs per tile
     if (!(flags & 16)) {
-      const int b1 = k0 / MB + 1, nt = NB / MB - b1;
+      const int b1 = k0 / MB + 1, nt = k_end / MB - b1;  // (nothing to update in the padding)
       const int ntile = nt * (nt + 1) / 2;
       const int l15 = lane & 15, lq = lane >> 4;
       for (int t = wid; t < ntile; t += PT / 64) {

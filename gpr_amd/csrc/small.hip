@@ -43,37 +43,75 @@ __device__ __forceinline__ double sum64(double v) {
   return v;
 }
 
-// rows [16 wv, 16 wv + 16) of  A (LDS, [64][SLD]) times  B (LDS, [64][SLD]; TRANS: times B^T)  -> acc[ct], ct = column tile
+// rows [16 wv, 16 wv + 16) of  A (LDS, [64][SLD]) times  B (LDS, [64][SLD]; TRANS: times B^T)  -> acc[ct], ct = column tile.
+// Fully unrolled, all fragments of a half of the k-range loaded before its 32 MFMAs: with the loop left rolled every
+// step waits for its own LDS reads and a product takes 2.5-4.5 us instead of ~1.
 template <bool TRANS>
 __device__ __forceinline__ void rows_times(const double* A, const double* B, int wv, int l15, int lq, sd4 (&acc)[4]) {
 #pragma unroll
   for (int ct = 0; ct < 4; ++ct) acc[ct] = sd4{0.0, 0.0, 0.0, 0.0};
-#pragma unroll 4
-  for (int kk = 0; kk < SM / 4; ++kk) {
-    const double af = A[(16 * wv + l15) * SLD + 4 * kk + lq];
 #pragma unroll
-    for (int ct = 0; ct < 4; ++ct) {
-      const double bf = TRANS ? B[(16 * ct + l15) * SLD + 4 * kk + lq] : B[(4 * kk + lq) * SLD + 16 * ct + l15];
-      acc[ct] = mfma_f64(af, bf, acc[ct]);
+  for (int h = 0; h < 2; ++h) {
+    double af[8], bf[8][4];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int kk = 8 * h + j;
+      af[j] = A[(16 * wv + l15) * SLD + 4 * kk + lq];
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct)
+        bf[j][ct] = TRANS ? B[(16 * ct + l15) * SLD + 4 * kk + lq] : B[(4 * kk + lq) * SLD + 16 * ct + l15];
     }
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct) acc[ct] = mfma_f64(af[j], bf[j][ct], acc[ct]);
   }
 }
 
 // acc[ct] += (T^T diag(wt) T) tile (wv, ct) over the 64 rows of T (LDS)
 __device__ __forceinline__ void gram_update(const double* T, const double* wt, int wv, int l15, int lq, sd4 (&acc)[4]) {
-#pragma unroll 4
-  for (int kk = 0; kk < SRB / 4; ++kk) {
-    const int k = 4 * kk + lq;
-    const double af = T[k * SLD + 16 * wv + l15] * wt[k];
 #pragma unroll
-    for (int ct = 0; ct < 4; ++ct) acc[ct] = mfma_f64(af, T[k * SLD + 16 * ct + l15], acc[ct]);
+  for (int h = 0; h < 2; ++h) {
+    double af[8], bf[8][4];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int k = 4 * (8 * h + j) + lq;
+      af[j] = T[k * SLD + 16 * wv + l15] * wt[k];
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct) bf[j][ct] = T[k * SLD + 16 * ct + l15];
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct) acc[ct] = mfma_f64(af[j], bf[j][ct], acc[ct]);
   }
 }
 
+// sum_g part[g * stride] over the workgroups' partials, in order, sixteen loads in flight at a time
+__device__ __forceinline__ double sum_parts(const double* __restrict__ part, int64_t stride, int ng) {
+  double acc = 0.0;
+  for (int g0 = 0; g0 < ng; g0 += 16) {
+    double v[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) v[j] = (g0 + j < ng) ? part[(int64_t)(g0 + j) * stride] : 0.0;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc += v[j];
+  }
+  return acc;
+}
+
+// 64 x 64 corner of a row-major mp x mp matrix -> LDS; eight 16-byte loads per thread, all issued before the first store
 __device__ __forceinline__ void load_corner(const double* __restrict__ M, int mp, double* L, int tid) {
-  for (int idx = tid; idx < SM * SM; idx += 256) {
-    const int r = idx >> 6, c = idx & 63;
-    L[r * SLD + c] = M[(int64_t)r * mp + c];
+  double2 v[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int idx = tid + 256 * j, r = idx >> 5, c2 = (idx & 31) * 2;
+    v[j] = *reinterpret_cast<const double2*>(M + (int64_t)r * mp + c2);
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int idx = tid + 256 * j, r = idx >> 5, c2 = (idx & 31) * 2;
+    *reinterpret_cast<double2*>(L + r * SLD + c2) = v[j];
   }
 }
 
@@ -112,7 +150,9 @@ __global__ __launch_bounds__(256) void small_pass1_kernel(SmallPass1Args a) {
       const int r = idx / DT, k = idx % DT;
       xs[idx] = (k < a.d && r0 + r < a.rows) ? a.pts[(int64_t)(r0 + r) * a.d + k] : 0.0;
     }
+    const double yreg = (tid < SRB && a.y && r0 + tid < a.rows) ? a.y[r0 + tid] : 0.0;  // used by the row phase below
     __syncthreads();
+#pragma unroll 4
     for (int i = 0; i < 16; ++i) {
       const int r = rg * 16 + i;
       double acc = 0.0;
@@ -156,7 +196,7 @@ __global__ __launch_bounds__(256) void small_pass1_kernel(SmallPass1Args a) {
         rr = a.cp.sf2 - rs[tid];
         const double s = rr + a.sigma2;
         is = 1.0 / s;
-        const double y = a.y ? a.y[row] : 0.0;
+        const double y = yreg;
         yis = is * y;
         p_log += log(s);
         p_y2 += is * y * y;
@@ -205,25 +245,11 @@ __global__ __launch_bounds__(256) void small_reduce1_kernel(const double* __rest
   const int tid = threadIdx.x;
   if (blockIdx.x < TILE * TILE / 256) {
     const int idx = blockIdx.x * 256 + tid, r = idx / TILE, c = idx % TILE;
-    double acc = 0.0;
-    if (r < SM && c < SM) {
-#pragma unroll 8
-      for (int g = 0; g < ng; ++g) acc += part[(int64_t)g * P1LEN + r * SM + c];
-    }
-    tile[idx] = acc;
+    tile[idx] = (r < SM && c < SM) ? sum_parts(part + r * SM + c, P1LEN, ng) : 0.0;
     return;
   }
-  if (tid < mp) {
-    double acc = 0.0;
-    if (tid < SM)
-      for (int g = 0; g < ng; ++g) acc += part[(int64_t)g * P1LEN + SM * SM + tid];
-    cvec[tid] = acc;
-  } else if (tid >= 192 && tid < 196) {
-    const int k = tid - 192;
-    double acc = 0.0;
-    for (int g = 0; g < ng; ++g) acc += part[(int64_t)g * P1LEN + SM * SM + SM + k];
-    tail[k] = acc;
-  }
+  if (tid < mp) cvec[tid] = (tid < SM) ? sum_parts(part + SM * SM + tid, P1LEN, ng) : 0.0;
+  else if (tid >= 192 && tid < 196) tail[tid - 192] = sum_parts(part + SM * SM + SM + (tid - 192), P1LEN, ng);
 }
 
 template <int DT>
@@ -275,11 +301,11 @@ __global__ __launch_bounds__(256) void small_pass2_kernel(SmallPass2Args a) {
       const int r = idx / DT, k = idx % DT;
       xs[idx] = (k < d && r0 + r < a.rows) ? a.pts[(int64_t)(r0 + r) * d + k] : 0.0;
     }
-    for (int idx = tid; idx < SRB * SM; idx += 256) {
-      const int r = idx >> 6, c = idx & 63;
-      Vt[r * SLD + c] = a.V[(int64_t)(r0 + r) * a.mp + c];
-    }
+    load_corner(a.V + (int64_t)r0 * a.mp, a.mp, Vt, tid);
     if (tid < SRB) isr[tid] = a.is[r0 + tid];
+    const bool rowlive = tid < SRB && r0 + tid < a.rows;  // the row phase below: one thread per row
+    const double rreg = rowlive ? a.r[r0 + tid] : 0.0;
+    const double yreg = (rowlive && a.y) ? a.y[r0 + tid] : 0.0;
     __syncthreads();
     sd4 acc[4];
     rows_times<false>(Vt, Ri, wv, l15, lq, acc);  // Q' = V R~^-1
@@ -306,9 +332,9 @@ __global__ __launch_bounds__(256) void small_pass2_kernel(SmallPass2Args a) {
       const int row = r0 + tid;
       double w = 0.0, v = 0.0, es = 0.0;
       if (row < a.rows) {
-        const double is = isr[tid], rr = a.r[row];
+        const double is = isr[tid], rr = rreg;
         const double qd = is * q2s[tid], sb = qbs[tid];
-        const double y = a.y ? a.y[row] : 0.0;
+        const double y = yreg;
         const double res = a.y ? (y - sb) : 0.0;
         w = is * res;
         const double v1 = a.variational ? is * (2.0 - is * rr - qd) : is * (1.0 - qd);
@@ -349,6 +375,7 @@ __global__ __launch_bounds__(256) void small_pass2_kernel(SmallPass2Args a) {
     }
     __syncthreads();
     // E = X .* K of the block: column sums, moments against the points (and the original inputs), sum E, sum E |x - z|^2
+#pragma unroll 4
     for (int i = 0; i < 16; ++i) {
       const int r = rg * 16 + i;
       double dist = 0.0;
@@ -459,12 +486,7 @@ __global__ __launch_bounds__(256) void small_reduce2_kernel(const double* __rest
   } else {
     return;
   }
-  double acc = 0.0;
-  if (src >= 0) {
-#pragma unroll 8
-    for (int g = 0; g < ng; ++g) acc += part[(int64_t)g * plen + src];
-  }
-  *dst = acc;
+  *dst = (src >= 0) ? sum_parts(part + src, plen, ng) : 0.0;
 }
 
 // Finish stage of a small gradient evaluation in one workgroup (the m x m work of do_finish_enqueue on 64 x 64 corners):
@@ -491,6 +513,12 @@ __global__ __launch_bounds__(256) void small_finish_kernel(SmallFinishArgs a) {
     zs[idx] = (k < d && c < m) ? a.Z[(int64_t)c * d + k] : 0.0;
   }
   for (int64_t i = tid; i < a.n_gather; i += 256) a.ex[i] = a.gather_from[i];
+  double kreg[16];  // K_m entries of the trace phase below (thread = column, group of 16 rows): loaded now, used at the end
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int r = (tid >> 6) * 16 + i;
+    kreg[i] = (r < m && lane < m) ? a.km[(int64_t)r * a.mp + lane] : 0.0;
+  }
   __syncthreads();
   sd4 acc[4];
   rows_times<true>(Ri, Ri, wv, l15, lq, acc);  // B~^-1
@@ -526,10 +554,10 @@ __global__ __launch_bounds__(256) void small_finish_kernel(SmallFinishArgs a) {
 #pragma unroll
   for (int k = 0; k < DT; ++k) g[k] = 0.0;
   if (col < m) {
+#pragma unroll
     for (int i = 0; i < 16; ++i) {
       const int r = rg * 16 + i;
-      if (r >= m) break;
-      const double wk = Wt[r * SLD + col] * a.km[(int64_t)r * a.mp + col];
+      const double wk = Wt[r * SLD + col] * kreg[i];  // (0 beyond the real rows)
       double dist = 0.0;
 #pragma unroll
       for (int k = 0; k < DT; ++k) {
