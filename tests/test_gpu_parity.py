@@ -1509,6 +1509,23 @@ def test_random_shapes_against_oracle(seed):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(3000, 3024))
+def test_random_small_shapes_against_oracle(seed):
+    """The same sweep over the shapes the one-kernel row passes take (gpr_amd/csrc/small.hip: m <= 64, d, D <= 16, one
+    chunk; multiscale cases fall back to the engine and say so), 1..64 inducing points and 1..4000 training points,
+    followed by a sigma2-only re-evaluation (reuse_v) on the state the small path left."""
+    _random_shape_case(seed, small=True)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(3100, 3106))
+def test_random_small_shapes_through_the_context(seed):
+    """... and through the single-process multi-device entry: the small passes write the same exchange buffers the
+    engine path does, so shards of a small problem reduce and finish like any other."""
+    _random_shape_case(seed, shards=2 + seed % 3, small=True)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("seed", range(8))
 def test_random_shapes_through_the_context(seed):
     """The same random-shape cases evaluated by the single-process multi-device entry (gprhip_sharded_eval) over 2..5
@@ -1527,9 +1544,10 @@ def test_random_shapes_long_sweep():
     lo, hi = (int(v) for v in spec.split(":"))
     bad = []
     shards = int(os.environ.get("GPR_FUZZ_SHARDS", "0"))  # > 0: through the context, seed-dependent shard counts up to it
+    small = os.environ.get("GPR_FUZZ_SMALL", "0") == "1"   # the shapes of the small row passes
     for seed in range(lo, hi):
         try:
-            _random_shape_case(seed, shards=(2 + seed % (shards - 1)) if shards > 1 else 0)
+            _random_shape_case(seed, shards=(2 + seed % (shards - 1)) if shards > 1 else 0, small=small)
         except AssertionError as e:  # keep going: the log should name every failing seed
             bad.append((seed, str(e)[:200]))
     print("random-shape sweep: seeds %d..%d, %d cases, %d failures %s" % (lo, hi - 1, hi - lo, len(bad), bad))
@@ -1550,7 +1568,7 @@ class _ShardedAsProblem:
         self.ctx.close()
 
 
-def _random_shape_case(seed, shards=0):
+def _random_shape_case(seed, shards=0, small=False):
     rng = np.random.default_rng(1000 + seed)
     iso = seed % 2 == 0   # (the oracle forms one dense n x m derivative matrix per Proj hyper: smaller fat cases)
     n = int(rng.integers(300, 6000 if iso else 3000))
@@ -1561,6 +1579,15 @@ def _random_shape_case(seed, shards=0):
     variational = bool(rng.integers(0, 2))
     sigma2 = float(10.0 ** rng.uniform(-2, 0))
     chunk_rows = int(rng.choice([0, 256, 1024, 4096]))
+    if small:  # the shapes of gpr_amd/csrc/small.hip: at most 64 inducing points, 16 dimensions, one row chunk
+        n = int(rng.integers(1, 4000 if iso else 2500))
+        m = int(rng.integers(1, 65))
+        d = int(rng.choice([1, 2, 3, 4, 5, 8, 9, 13, 16] if iso else [1, 2, 3, 5, 8, 11, 13]))
+        chunk_rows = 0
+        if not iso:
+            n = max(n, m)  # (the fat cases draw their inducing points from the projected inputs)
+        if shards:
+            n = max(n, 200)
     if iso:
         X, y, Z = synth(2000 + seed, n, min(m, n), d)
         if m > n:  # more inducing points than training points: legal, and a shape of its own (k-range shorter than m)
@@ -1592,7 +1619,18 @@ def _random_shape_case(seed, shards=0):
     ref = O.evaluate(k, Z, X, y, sigma2, variational=variational)
     p.set_inputs(X)
     p.set_targets(y)
+    if small and not shards:
+        p.set_timing(2)
     ev = p.eval(sigma2=sigma2, inducing=Z, variational=variational, **args)
+    if small and not shards:
+        took_small = "p1_small" in p.last_timings()
+        assert took_small == ("log_multiscales_m05" not in args), (took_small, sorted(args))
+        p.set_timing(0)
+        # Model.update_sigma2 after a small-path evaluation: V and r of the small pass are reused by the engine's pass 1
+        ref2 = O.evaluate(k, Z, X, y, 2.0 * sigma2, variational=variational)
+        ev2 = p.eval(sigma2=2.0 * sigma2, inducing=Z, variational=variational, reuse_v=True, **args)
+        assert abs(ev2.l - ref2["l"]) <= TOL_L * abs(ref2["l"])
+        assert relinf(ev2.grad, ref2["grad"]) <= TOL_GRAD
     ev0 = p.eval(sigma2=sigma2, inducing=Z, variational=variational, want_grad=False, **args)
     p.close()
     assert abs(ev.l - ref["l"]) <= TOL_L * abs(ref["l"])
