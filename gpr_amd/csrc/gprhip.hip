@@ -569,7 +569,9 @@ void do_pass1(gprhip_problem* p, const gprhip_hypers* h, int want_grad, int64_t 
   TS* const bufA = static_cast<TS*>(p->bufA);
   TS* const slices = static_cast<TS*>(p->slices);
   // K resident (see Kstore): decided at the first gradient evaluation that can use it, kept for the problem's life
-  if (!p->Kstore && !p->kstore_tried && want_grad && p->k_resident && p->kind == GPRHIP_COV_SE_FAT && h->tproj &&
+  const bool small = p->use_small();
+  if (small && !p->small_part) p->small_part = p->alloc<double>(small_part_len(p->d, p->D));
+  if (!p->Kstore && !p->kstore_tried && !small && want_grad && p->k_resident && p->kind == GPRHIP_COV_SE_FAT && h->tproj &&
       !h->log_multiscales_m05 && p->d <= 64 && p->D <= 64 && !p->grad_scalar) {
     p->kstore_tried = true;
     size_t free_b = 0, total_b = 0;
@@ -599,8 +601,6 @@ void do_pass1(gprhip_problem* p, const gprhip_hypers* h, int want_grad, int64_t 
   // K_nm of the first chunk does not depend on U: it is built on the second stream while the (latency-bound, few-CU)
   // factorisation and inversion of K_m run -- 0.4 ms of every evaluation, which is what a chunk's builder takes.
   // (Not under the per-stage timer, whose events sit on the main stream.)
-  const bool small = p->use_small();
-  if (small && !p->small_part) p->small_part = p->alloc<double>(small_part_len(p->d, p->D));
   const bool cov0_ahead = !reuse && !p->timer.on && !small;
   if (cov0_ahead) {
     GPR_HIP(hipEventRecord(p->ev_fork, s));  // hypers, inducing points and projections are enqueued on s

@@ -1518,6 +1518,49 @@ def test_random_small_shapes_against_oracle(seed):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("kind,n,m,d", [("iso", 20000, 40, 3), ("iso", 65536, 64, 16), ("fat", 9000, 33, 5), ("iso", 65537, 20, 2)])
+def test_small_path_with_several_blocks_per_workgroup(kind, n, m, d, monkeypatch):
+    """Above 8192 training points a workgroup of the small row passes walks several 64-row blocks (128 workgroups at
+    most) and accumulates its partial sums across them; 65 536 rows is the last size the path takes, 65 537 the first
+    that goes through the engine.  Against the oracle, and against the engine path on the same problem."""
+    rng = np.random.default_rng(n + m)
+    if kind == "iso":
+        X, y, Z = synth(77, n, m, d)
+        k = O.SeIsoKernel(0.5 * np.log(d) + 0.1, 0.2)
+        args = dict(log_ell=k.log_ell, log_sf2=k.log_sf2)
+        D, code = d, gpr_amd.COV_SE_ISO
+    else:
+        D = d + 3
+        X = np.asfortranarray(rng.normal(size=(D, n)))
+        y = np.sin(X.sum(0)) + 0.1 * rng.normal(size=n)
+        P = np.asfortranarray(rng.normal(size=(D, d)) / np.sqrt(D * d))
+        Z = np.asfortranarray((P.T @ X)[:, rng.permutation(n)[:m]] + 0.01 * rng.normal(size=(d, m)))
+        het = rng.uniform(-6, -3, size=m)
+        k = O.SeFatKernel(d, 0.1, P, het, None)
+        args = dict(log_sf2=k.log_sf2, tproj=P, log_hetero_skedasticity=het)
+        code = gpr_amd.COV_SE_FAT
+    ref = O.evaluate(k, Z, X, y, 0.15, variational=True)
+    out = {}
+    for path in ("default", "engine"):
+        if path == "engine":
+            monkeypatch.setenv("GPRHIP_SMALL_PATH", "0")
+        p = gpr_amd.Problem(code, n, D, d, m)
+        p.set_inputs(X)
+        p.set_targets(y)
+        p.set_timing(2)
+        ev = p.eval(sigma2=0.15, inducing=Z, variational=True, **args)
+        assert ("p1_small" in p.last_timings()) == (path == "default" and n <= 65536)
+        p.close()
+        assert abs(ev.l - ref["l"]) <= TOL_L * abs(ref["l"])
+        assert abs(ev.dl_dsigma2 - ref["dl_dsigma2"]) <= TOL_DS2 * abs(ref["dl_dsigma2"])
+        assert relinf(ev.grad, ref["grad"]) <= TOL_GRAD
+        assert relinf(ev.coeffs, ref["coeffs"]) <= TOL_COEFF
+        out[path] = ev
+    assert abs(out["default"].l - out["engine"].l) <= 1e-12 * abs(out["engine"].l)
+    assert relinf(out["default"].grad, out["engine"].grad) <= 1e-9
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("seed", range(3100, 3106))
 def test_random_small_shapes_through_the_context(seed):
     """... and through the single-process multi-device entry: the small passes write the same exchange buffers the
