@@ -103,6 +103,18 @@ __device__ __forceinline__ void potrf_diag_body(double* __restrict__ A, int mp, 
   }
   if (tid == 0) bad = 0;
   if (tid < NB && tid >= k_end) rdiag[tid] = 1.0;  // padding: unit pivots
+  // At most 64 real rows (and no ablation flags): the inverse is not formed by the pass further down but carried through
+  // the factorisation as an identity right-hand side Y, kept in the block's own zero padding -- T[r][64 + c], r, c < 64,
+  // is zero above the padded diagonal and takes no part in the factor.  The panel solve then also turns rows k0..k0+15
+  // of Y into U11^-T Y, the trailing update subtracts U12^T Y from the rows below, and Y ends as U^-T: the steps of
+  // potrf_upper_blocked on 16-column micro-panels.  They run on threads the factor leaves idle, so the inverse costs no
+  // phase of its own (m = 50: 10.5 us of 32).
+  const bool carry = k_end <= 64 && flags == 0;
+  constexpr int YC = 64;  // first column of Y
+  if (carry) {
+    __syncthreads();  // (the loads above wrote zeros where Y goes)
+    for (int idx = tid; idx < 64 * 64; idx += PT) T[(idx >> 6) * LDT + YC + (idx & 63)] = ((idx >> 6) == (idx & 63)) ? 1.0 : 0.0;
+  }
   __syncthreads();
   if (flags & 1) {  // block already holds a factor (model import): only its inverse is wanted
     if (tid < NB) rdiag[tid] = 1.0 / T[tid * LDT + tid];
@@ -151,7 +163,8 @@ __device__ __forceinline__ void potrf_diag_body(double* __restrict__ A, int mp, 
     }
     __syncthreads();
     // panel: U12 = U11^-T A12, one thread per column (forward substitution in registers)
-    if (tid < k_end && tid >= k0 + MB && !(flags & 8)) {  // (columns in the padding are zero above the unit diagonal)
+    // (columns in the padding are zero above the unit diagonal; of Y, columns 0 .. k0+15 are non-zero in these rows)
+    if (((tid < k_end && tid >= k0 + MB) || (carry && tid >= YC && tid < YC + k0 + MB)) && !(flags & 8)) {
       double x[MB];
 #pragma unroll
       for (int q = 0; q < MB; ++q) {
@@ -167,15 +180,24 @@ __device__ __forceinline__ void potrf_diag_body(double* __restrict__ A, int mp, 
     // trailing: A22 -= U12^T U12, one 16x16 tile (ti <= tj) per wavefront at a time, 4 MFMAs per tile
     if (!(flags & 16)) {
       const int b1 = k0 / MB + 1, nt = k_end / MB - b1;  // (nothing to update in the padding)
-      const int ntile = nt * (nt + 1) / 2;
+      const int nsym = nt * (nt + 1) / 2;
+      const int ntile = nsym + (carry ? nt * b1 : 0);  // + rows below the panel x the non-zero column blocks of Y
       const int l15 = lane & 15, lq = lane >> 4;
       for (int t = wid; t < ntile; t += PT / 64) {
-        int ti = 0, rem = t;
-        while (rem >= nt - ti) {
-          rem -= nt - ti;
-          ++ti;
+        int ci, cj;
+        if (t < nsym) {
+          int ti = 0, rem = t;
+          while (rem >= nt - ti) {
+            rem -= nt - ti;
+            ++ti;
+          }
+          ci = (b1 + ti) * MB;
+          cj = (b1 + ti + rem) * MB;
+        } else {
+          const int e = t - nsym;
+          ci = (b1 + e / b1) * MB;
+          cj = YC + (e % b1) * MB;
         }
-        const int ci = (b1 + ti) * MB, cj = (b1 + ti + rem) * MB;
         double* Ct = T + (ci + lq) * LDT + cj + l15;
         pd4 acc;
 #pragma unroll
@@ -198,12 +220,23 @@ __device__ __forceinline__ void potrf_diag_body(double* __restrict__ A, int mp, 
     double2 v;
     v.x = (c2 >= r) ? T[r * LDT + c2] : 0.0;
     v.y = (c2 + 1 >= r) ? T[r * LDT + c2 + 1] : 0.0;
+    if (carry && r < 64 && c2 >= YC) v.x = v.y = 0.0;  // (Y lives there)
     *reinterpret_cast<double2*>(Ab + (int64_t)r * mp + c2) = v;
   }
   __syncthreads();
+  if (carry) {
+    // X = Y^T onto the upper triangle (the factor has gone to memory), then the padding is cleared again
+    for (int idx = tid; idx < 64 * 64; idx += PT) {
+      const int r = idx >> 6, c = idx & 63;
+      if (c >= r) T[r * LDT + c] = T[c * LDT + YC + r];
+    }
+    __syncthreads();
+    for (int idx = tid; idx < 64 * 64; idx += PT) T[(idx >> 6) * LDT + YC + (idx & 63)] = 0.0;
+    __syncthreads();
+  }
 
   // ---------------- invert in place (upper)
-  if (!(flags & 2) || (flags & 32)) {
+  if ((!(flags & 2) || (flags & 32)) && !carry) {
     // all eight diagonal micro-block inverses: wave w handles blocks w (8 waves)
     {
       const int b = wid, j0 = b * MB, cc = lane & 15;
@@ -235,7 +268,7 @@ __device__ __forceinline__ void potrf_diag_body(double* __restrict__ A, int mp, 
       return;
     }
   }
-  if (!(flags & 2)) {
+  if (!(flags & 2) && !carry) {
     // block column b of the inverse, in place (LAPACK dtrtri order): wavefront ri < b owns the 16x16 tile (ri, b):
     //   T1 = sum_{kt=ri}^{b-1} X(ri,kt) U(kt,b)   (X = the already inverted leading block; 4 MFMAs per kt)
     //   X(ri,b) = -T1 D_b                           (T1 re-laid out as an A operand through the wave's LDS scratch)
