@@ -120,7 +120,7 @@ def profile_traffic(n, m):
 
 
 def other_configs(gpr_amd, steps=3):
-    """BASELINE.json configs[2] (cov_se_fat ARD, n=1M m=4096 d=32, fp32 bulk and fp64) and the per-GPU shard of
+    """BASELINE.json configs[0] (n=2000 m=50 d=3: wall time), configs[2] (cov_se_fat ARD, n=1M m=4096 d=32, fp32 bulk and fp64) and the per-GPU shard of
     configs[3] (cov_se_iso, n=1M of 8M, m=4096, d=16, fp64), outside the headline's timed region: one warm-up + `steps`
     timed evaluations each (median reported), the dominant kernel timed with HIP events on the library's stream."""
     out = []
@@ -146,6 +146,25 @@ def other_configs(gpr_amd, steps=3):
                     "l": float(ev.l), "grad_norm": float(np.linalg.norm(ev.grad))})
         prob.close()
 
+    # configs[0], the reference's own shape (n=2000, m=50, d=3): launch-bound, so wall time per evaluation, not a roofline
+    n, m, d = 2000, 50, 3
+    X, y, Z = synth(1, n, m, d)
+    p = gpr_amd.Problem(gpr_amd.COV_SE_ISO, n, d, d, m)
+    p.set_inputs(X)
+    p.set_targets(y)
+    kw = dict(log_ell=0.5 * np.log(d), log_sf2=0.0, sigma2=0.1, inducing=Z)
+    ts = {}
+    for want_grad in (True, False):
+        t = []
+        for _ in range(33):
+            t0 = time.perf_counter()
+            ev = p.eval(want_grad=want_grad, **kw)
+            t.append(time.perf_counter() - t0)
+        ts[want_grad] = float(np.median(t[3:]))
+    p.close()
+    out.append({"config": "C1: cov_se_iso FITC nLML+grad, n=2000 m=50 d=3, fp64 (one kernel per pass, gpr_amd/csrc/small.hip)",
+                "dtype": "f64", "ms_per_eval": ts[True] * 1e3, "ms_per_evidence_only_eval": ts[False] * 1e3,
+                "points_per_s": n / ts[True], "l": float(ev.l)})
     n, m, d = 1_000_000, 4096, 32
     rng = np.random.default_rng(3)
     X = np.asfortranarray(rng.normal(size=(d, n)))
