@@ -109,7 +109,7 @@ __device__ __forceinline__ void potrf_diag_body(double* __restrict__ A, int mp, 
   // of Y into U11^-T Y, the trailing update subtracts U12^T Y from the rows below, and Y ends as U^-T: the steps of
   // potrf_upper_blocked on 16-column micro-panels.  They run on threads the factor leaves idle, so the inverse costs no
   // phase of its own (m = 50: 10.5 us of 32).
-  const bool carry = k_end <= 64 && flags == 0;
+  const bool carry = k_end <= 64 && (flags & ~64) == 0;
   constexpr int YC = 64;  // first column of Y
   if (carry) {
     __syncthreads();  // (the loads above wrote zeros where Y goes)
@@ -213,7 +213,11 @@ __device__ __forceinline__ void potrf_diag_body(double* __restrict__ A, int mp, 
     }
     __syncthreads();
   }
-  if (tid == 0 && bad != 0) atomicCAS(info, 0, j * NB + bad);
+  // flags bit 6 (single-block matrices): the flag is this kernel's alone -- written either way, no memset in front of it
+  if (tid == 0) {
+    if (flags & 64) *info = bad ? j * NB + bad : 0;
+    else if (bad != 0) atomicCAS(info, 0, j * NB + bad);
+  }
   // write U back (zero strict lower of the block)
   for (int idx = tid; idx < NB * NB / 2; idx += PT) {
     const int r = idx / (NB / 2), c2 = (idx % (NB / 2)) * 2;
@@ -389,7 +393,7 @@ __global__ __launch_bounds__(PT) void potrf_diag_kernel(double* __restrict__ A, 
 
 __global__ __launch_bounds__(PT) void potrf_fused_kernel(PotrfFuse f, double* __restrict__ A, double* __restrict__ dinv,
                                                          int* __restrict__ info, int m_real) {
-  potrf_diag_body<true>(A, NB, 0, dinv, info, 0, m_real, f);
+  potrf_diag_body<true>(A, NB, 0, dinv, info, 64, m_real, f);
 }
 
 // ---- blocked factorisation without the engine: panel solve and trailing update of one 128-row step
@@ -661,7 +665,7 @@ void potrf_upper_blocked(hipStream_t s, double* A, int mp, double* dinv, int* in
   const int nb = mp / NB;
   if (nb == 1) {  // a single block: factor and inverse in one launch
     // (a single block's inverse, [128][128], IS the mp x mp inverse: written straight to Xinv)
-    hipLaunchKernelGGL(potrf_diag_kernel, dim3(1), dim3(PT), POTRF_LDS, s, A, mp, 0, Xinv ? Xinv : dinv, info, 0, m_real);
+    hipLaunchKernelGGL(potrf_diag_kernel, dim3(1), dim3(PT), POTRF_LDS, s, A, mp, 0, Xinv ? Xinv : dinv, info, 64, m_real);
     GPR_HIP(hipGetLastError());
     return;
   }

@@ -609,8 +609,11 @@ void do_pass1(gprhip_problem* p, const gprhip_hypers* h, int want_grad, int64_t 
     GPR_HIP(hipEventRecord(p->ev_join, p->stream2));
   }
   tstart(p, "km_chol");
-  GPR_HIP(hipMemsetAsync(p->scal, 0, (NSCAL + 2) * sizeof(double), s));  // the scalars and the two potrf flags behind them
-  GPR_HIP(hipMemsetAsync(ar1_c, 0, (size_t)(mp + A1_TAIL) * sizeof(double), s));
+  // the scalars and the two potrf flags behind them (single-block problems: every slot an evaluation reads is written by
+  // the factorisation kernels themselves, flags included), and the accumulators of the exchange-1 tail (the small row pass
+  // writes them outright)
+  if (mp != TILE || p->engine_steps) GPR_HIP(hipMemsetAsync(p->scal, 0, (NSCAL + 2) * sizeof(double), s));
+  if (!small || reuse) GPR_HIP(hipMemsetAsync(ar1_c, 0, (size_t)(mp + A1_TAIL) * sizeof(double), s));
   // K_m + (hetero) + jitter goes straight into the factor's buffer (kj is scratch of the finish stage only)
   launch_cov_upper(p->cp, p->Z, p->m, mp, p->d, h->jitter, p->has_het() ? p->het : nullptr, p->km, p->umat, s);
   potrf_trtri(p, p->umat, p->uinv, p->wmat, p->info);  // U = chol(K_m + jitter), lib/fitc_gp.ml:53-57, and U^-1
