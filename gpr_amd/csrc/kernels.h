@@ -211,7 +211,7 @@ void launch_km_traces(const double* W, const double* km, const double* Z, int m,
 void launch_km_traces_ms(const double* W, const double* km, const double* Z, const double* ms, int m, int mp,
                          int d, double* part, hipStream_t s);
 
-// ---- row passes of small problems (small.hip): m <= 64, one chunk of at most 65536 rows, d, D <= 16, fp64, no multiscales
+// ---- row passes of small problems (small.hip): m <= 64, one chunk of at most 65536 rows, d <= 16, D <= 64, fp64, no multiscales
 struct SmallPass1Args {
   CovParams cp;
   const double *pts, *Z, *uinv, *y;  // points [rows][d], inducing [mp][d], U^-1 [mp][mp], targets (or null)

@@ -1,4 +1,5 @@
-// Row passes of small problems (m <= 64 inducing points, one row chunk): the reference's own shapes (n = 1000..2000,
+// Row passes of small problems (m <= 64 inducing points, d <= 16 point dimensions -- D <= 64 input dimensions in front of
+// a projection --, one row chunk): the reference's own shapes (n = 1000..2000,
 // m = 10..50, test/save_data.ml, test/gen_data.ml) spend their time in launches, not in arithmetic -- through the engine a
 // gradient evaluation is 9 contraction launches of 16-22 us each plus ~20 small kernels.  Here each pass is ONE kernel
 // per 64-row block that keeps the block's rows of K, V, Q' and X in LDS and the 64 x 64 corners of U^-1 / R~^-1 beside
@@ -252,7 +253,8 @@ __global__ __launch_bounds__(256) void small_reduce1_kernel(const double* __rest
   else if (tid >= 192 && tid < 196) tail[tid - 192] = sum_parts(part + SM * SM + SM + (tid - 192), P1LEN, ng);
 }
 
-template <int DT>
+// DT: padded point dimension (d <= DT); DBT: padded dimension of the original inputs of a projected kernel (D <= DBT)
+template <int DT, int DBT>
 __global__ __launch_bounds__(256) void small_pass2_kernel(SmallPass2Args a) {
   extern __shared__ __attribute__((aligned(16))) double small_lds[];
   double* const Ui = small_lds;          // [SM][SLD]  U^-1
@@ -280,19 +282,37 @@ __global__ __launch_bounds__(256) void small_pass2_kernel(SmallPass2Args a) {
   }
   const int col = lane, rg = wv;
   const bool live_c = col < a.m;
-  double z[DT], gx[DT], gb[DT];
+  // moments of E against the original inputs (`Proj derivative): per-thread sums for D <= 16; above that one more MFMA
+  // product per block, X_big^T E, with the inputs staged where V was (WIDE)
+  constexpr bool WIDE = DBT > 16;
+  constexpr int NGB = WIDE ? 1 : DBT;
+  double z[DT], gx[DT], gb[NGB];
 #pragma unroll
   for (int k = 0; k < DT; ++k) {
     z[k] = (k < d && live_c) ? a.Z[(int64_t)col * d + k] : 0.0;
     gx[k] = 0.0;
-    gb[k] = 0.0;
   }
+#pragma unroll
+  for (int k = 0; k < NGB; ++k) gb[k] = 0.0;
+  sd4 accGB[4];
+#pragma unroll
+  for (int ct = 0; ct < 4; ++ct) accGB[ct] = sd4{0.0, 0.0, 0.0, 0.0};
   sd4 accG[4];
 #pragma unroll
   for (int ct = 0; ct < 4; ++ct) accG[ct] = sd4{0.0, 0.0, 0.0, 0.0};
-  double cs = 0.0, sE = 0.0, sED = 0.0, pj = 0.0;
+  double cs = 0.0, sE = 0.0, sED = 0.0;
   double p_v = 0.0, p_is = 0.0, p_res = 0.0, p_v1 = 0.0;
-  const int pj_big = (D > 0 && tid < D * d) ? tid / d : 0, pj_small = (D > 0 && tid < D * d) ? tid % d : 0;
+  // `Proj second term: thread t accumulates outputs t, t + 256, ... of the D x d matrix
+  constexpr int NPJ = (DBT * DT + 255) / 256;
+  double pj[NPJ];
+  int pj_big[NPJ], pj_small[NPJ];
+#pragma unroll
+  for (int j = 0; j < NPJ; ++j) {
+    const int o = min(tid + 256 * j, max(D * d - 1, 0));
+    pj[j] = 0.0;
+    pj_big[j] = d > 0 ? o / d : 0;
+    pj_small[j] = d > 0 ? o % d : 0;
+  }
   const int nblk = a.rows_p / SRB;
   for (int b = blockIdx.x; b < nblk; b += gridDim.x) {
     const int r0 = b * SRB;
@@ -373,7 +393,14 @@ __global__ __launch_bounds__(256) void small_pass2_kernel(SmallPass2Args a) {
         a.X[(int64_t)(r0 + row) * a.mp + 16 * ct + l15] = acc[ct][r];
       }
     }
+    gram_update(Vt, vr, wv, l15, lq, accG);  // G~ part = V^T diag(v) V
     __syncthreads();
+    if constexpr (WIDE) {  // V is done with: its tile now holds the block's original inputs, zero-padded to 64 columns
+      for (int idx = tid; idx < SRB * DBT; idx += 256) {
+        const int r = idx / DBT, k = idx % DBT;
+        Vt[r * SLD + k] = (k < D && r0 + r < a.rows) ? a.big[(int64_t)(r0 + r) * D + k] : 0.0;
+      }
+    }
     // E = X .* K of the block: column sums, moments against the points (and the original inputs), sum E, sum E |x - z|^2
 #pragma unroll 4
     for (int i = 0; i < 16; ++i) {
@@ -390,20 +417,46 @@ __global__ __launch_bounds__(256) void small_pass2_kernel(SmallPass2Args a) {
       const double e = live ? Qt[r * SLD + col] * exp_fast(a.cp.log_sf2 + a.cp.inv_ell2_05 * dist, ek) : 0.0;
 #pragma unroll
       for (int k = 0; k < DT; ++k) gx[k] += xs[r * DT + k] * e;
-      if (D > 0 && r0 + r < a.rows) {
+      if constexpr (WIDE) {
+        Qt[r * SLD + col] = e;  // (rows of this wavefront)
+      } else if (D > 0 && r0 + r < a.rows) {
         const double* xb = a.big + (int64_t)(r0 + r) * D;
 #pragma unroll
-        for (int k = 0; k < DT; ++k)
+        for (int k = 0; k < NGB; ++k)
           if (k < D) gb[k] += xb[k] * e;
       }
       cs += e;
       sE += e;
       sED += e * dist;
     }
-    gram_update(Vt, vr, wv, l15, lq, accG);  // G~ part = V^T diag(v) V
-    if (D > 0 && tid < D * d) {  // second term of the `Proj derivative: sum_r x_big,r p_small,r rowsum(E)_r
+    if constexpr (WIDE) {
+      __syncthreads();  // the staged inputs and E are complete
+      // accGB[ct] += (X_big^T E) tile (wv, ct): input dimensions 16 wv .. 16 wv + 15 against columns 16 ct ..
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        double af[8], bf[8][4];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int k = 4 * (8 * h + j) + lq;
+          af[j] = Vt[k * SLD + 16 * wv + l15];
+#pragma unroll
+          for (int ct = 0; ct < 4; ++ct) bf[j][ct] = Qt[k * SLD + 16 * ct + l15];
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+#pragma unroll
+          for (int ct = 0; ct < 4; ++ct) accGB[ct] = mfma_f64(af[j], bf[j][ct], accGB[ct]);
+      }
+    }
+    if (D > 0) {  // second term of the `Proj derivative: sum_r x_big,r p_small,r rowsum(E)_r
       const int nr = min(SRB, a.rows - r0);
-      for (int r = 0; r < nr; ++r) pj += a.big[(int64_t)(r0 + r) * D + pj_big] * xs[r * DT + pj_small] * esr[r];
+      for (int r = 0; r < nr; ++r) {
+#pragma unroll
+        for (int j = 0; j < NPJ; ++j) {
+          const double xb = WIDE ? Vt[r * SLD + pj_big[j]] : a.big[(int64_t)(r0 + r) * D + pj_big[j]];
+          pj[j] += xb * xs[r * DT + pj_small[j]] * esr[r];
+        }
+      }
     }
   }
   double* part = a.part + (int64_t)blockIdx.x * p2len(d, D);
@@ -413,7 +466,16 @@ __global__ __launch_bounds__(256) void small_pass2_kernel(SmallPass2Args a) {
     for (int r = 0; r < 4; ++r) part[(16 * wv + lq + 4 * r) * SM + 16 * ct + l15] = accG[ct][r];
   double* pcol = part + SM * SM;
   // per-column accumulators: the four row groups of a column are combined in order
-  for (int q = 0; q < 1 + d + D; ++q) {
+  if constexpr (WIDE) {  // these sums are complete (the MFMA product ran over all 64 rows of every block)
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int k = 16 * wv + lq + 4 * r;
+        if (k < D) pcol[(1 + d + k) * SM + 16 * ct + l15] = accGB[ct][r];
+      }
+  }
+  for (int q = 0; q < (WIDE ? 1 + d : 1 + d + D); ++q) {
     double val = cs;
     if (q >= 1 && q <= d) {
 #pragma unroll
@@ -421,7 +483,7 @@ __global__ __launch_bounds__(256) void small_pass2_kernel(SmallPass2Args a) {
         if (k == q - 1) val = gx[k];
     } else if (q > d) {
 #pragma unroll
-      for (int k = 0; k < DT; ++k)
+      for (int k = 0; k < NGB; ++k)
         if (k == q - 1 - d) val = gb[k];
     }
     __syncthreads();
@@ -430,7 +492,9 @@ __global__ __launch_bounds__(256) void small_pass2_kernel(SmallPass2Args a) {
     if (tid < SM) pcol[q * SM + tid] = (red[tid] + red[SM + tid]) + (red[2 * SM + tid] + red[3 * SM + tid]);
   }
   double* pproj = pcol + (1 + d + D) * SM;
-  if (D > 0 && tid < D * d) pproj[tid] = pj;
+#pragma unroll
+  for (int j = 0; j < NPJ; ++j)
+    if (tid + 256 * j < D * d) pproj[tid + 256 * j] = pj[j];
   double* ptail = pproj + D * d;
   sE = sum64(sE);
   sED = sum64(sED);
@@ -606,9 +670,15 @@ static void small_attrs() {
     set(reinterpret_cast<const void*>(&small_pass1_kernel<4>), small_lds1(4));
     set(reinterpret_cast<const void*>(&small_pass1_kernel<8>), small_lds1(8));
     set(reinterpret_cast<const void*>(&small_pass1_kernel<16>), small_lds1(16));
-    set(reinterpret_cast<const void*>(&small_pass2_kernel<4>), small_lds2(4));
-    set(reinterpret_cast<const void*>(&small_pass2_kernel<8>), small_lds2(8));
-    set(reinterpret_cast<const void*>(&small_pass2_kernel<16>), small_lds2(16));
+    set(reinterpret_cast<const void*>(&small_pass2_kernel<4, 1>), small_lds2(4));
+    set(reinterpret_cast<const void*>(&small_pass2_kernel<8, 1>), small_lds2(8));
+    set(reinterpret_cast<const void*>(&small_pass2_kernel<16, 1>), small_lds2(16));
+    set(reinterpret_cast<const void*>(&small_pass2_kernel<4, 16>), small_lds2(4));
+    set(reinterpret_cast<const void*>(&small_pass2_kernel<8, 16>), small_lds2(8));
+    set(reinterpret_cast<const void*>(&small_pass2_kernel<16, 16>), small_lds2(16));
+    set(reinterpret_cast<const void*>(&small_pass2_kernel<4, 64>), small_lds2(4));
+    set(reinterpret_cast<const void*>(&small_pass2_kernel<8, 64>), small_lds2(8));
+    set(reinterpret_cast<const void*>(&small_pass2_kernel<16, 64>), small_lds2(16));
     set(reinterpret_cast<const void*>(&small_finish_kernel<4>), small_lds3(4));
     set(reinterpret_cast<const void*>(&small_finish_kernel<8>), small_lds3(8));
     set(reinterpret_cast<const void*>(&small_finish_kernel<16>), small_lds3(16));
@@ -616,7 +686,7 @@ static void small_attrs() {
 }
 
 bool small_path_fits(int m, int mp, int d, int D, int64_t rows) {
-  return m <= SM && mp == TILE && d <= 16 && D <= 16 && rows <= 65536;
+  return m <= SM && mp == TILE && d <= 16 && D <= 64 && rows <= 65536;
 }
 
 void launch_small_pass1(const SmallPass1Args& a, double* tile, double* cvec, double* tail, hipStream_t s) {
@@ -634,9 +704,11 @@ void launch_small_pass2(const SmallPass2Args& a, int col_rows, double* tile, dou
                         hipStream_t s) {
   small_attrs();
   const int ng = small_groups(a.rows_p);
-  small_dispatch(std::max(a.d, a.D), [&](auto dt) {
+  small_dispatch(a.d, [&](auto dt) {
     constexpr int DT = decltype(dt)::value;
-    hipLaunchKernelGGL((small_pass2_kernel<DT>), dim3(ng), dim3(256), small_lds2(DT), s, a);
+    if (a.D == 0) hipLaunchKernelGGL((small_pass2_kernel<DT, 1>), dim3(ng), dim3(256), small_lds2(DT), s, a);
+    else if (a.D <= 16) hipLaunchKernelGGL((small_pass2_kernel<DT, 16>), dim3(ng), dim3(256), small_lds2(DT), s, a);
+    else hipLaunchKernelGGL((small_pass2_kernel<DT, 64>), dim3(ng), dim3(256), small_lds2(DT), s, a);
   });
   const int nout = TILE * TILE + col_rows * a.mp + a.D * a.d + 8;
   hipLaunchKernelGGL(small_reduce2_kernel, dim3((nout + 255) / 256), dim3(256), 0, s, a.part, ng, a.mp, a.d, a.D, col_rows,

@@ -53,10 +53,10 @@ def _eval_golden(p, g, **kw):
 
 
 def _small_path_applies(g):
-    """gpr_amd/csrc/small.hip: one-kernel row passes for m <= 64, d, D <= 16, no multiscales, one row chunk."""
+    """gpr_amd/csrc/small.hip: one-kernel row passes for m <= 64, d <= 16, D <= 64, no multiscales, one row chunk."""
     d, m = g["Z"].shape
     D = g["X"].shape[0]
-    return m <= 64 and d <= 16 and D <= 16 and "log_multiscales" not in g and g["X"].shape[1] <= 65536
+    return m <= 64 and d <= 16 and D <= 64 and "log_multiscales" not in g and g["X"].shape[1] <= 65536
 
 
 def _golden_cases(names):
@@ -1518,19 +1518,21 @@ def test_random_small_shapes_against_oracle(seed):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("kind,n,m,d", [("iso", 20000, 40, 3), ("iso", 65536, 64, 16), ("fat", 9000, 33, 5), ("iso", 65537, 20, 2)])
-def test_small_path_with_several_blocks_per_workgroup(kind, n, m, d, monkeypatch):
+@pytest.mark.parametrize("kind,n,m,d,D", [("iso", 20000, 40, 3, 3), ("iso", 65536, 64, 16, 16), ("fat", 9000, 33, 5, 8),
+                                          ("iso", 65537, 20, 2, 2), ("fat", 700, 25, 4, 17), ("fat", 2500, 64, 16, 64),
+                                          ("fat", 1500, 12, 9, 41)])
+def test_small_path_with_several_blocks_per_workgroup(kind, n, m, d, D, monkeypatch):
     """Above 8192 training points a workgroup of the small row passes walks several 64-row blocks (128 workgroups at
     most) and accumulates its partial sums across them; 65 536 rows is the last size the path takes, 65 537 the first
-    that goes through the engine.  Against the oracle, and against the engine path on the same problem."""
+    that goes through the engine.  Projections from more than 16 input dimensions (up to 64) form their input moments
+    as one more matrix-core product per block.  Against the oracle, and against the engine path on the same problem."""
     rng = np.random.default_rng(n + m)
     if kind == "iso":
         X, y, Z = synth(77, n, m, d)
         k = O.SeIsoKernel(0.5 * np.log(d) + 0.1, 0.2)
         args = dict(log_ell=k.log_ell, log_sf2=k.log_sf2)
-        D, code = d, gpr_amd.COV_SE_ISO
+        code = gpr_amd.COV_SE_ISO
     else:
-        D = d + 3
         X = np.asfortranarray(rng.normal(size=(D, n)))
         y = np.sin(X.sum(0)) + 0.1 * rng.normal(size=n)
         P = np.asfortranarray(rng.normal(size=(D, d)) / np.sqrt(D * d))
@@ -1642,6 +1644,8 @@ def _random_shape_case(seed, shards=0, small=False):
         args = dict(log_ell=k.log_ell, log_sf2=k.log_sf2)
     else:
         D = d + int(rng.integers(0, 4))
+        if small and seed % 3 == 0:
+            D = int(rng.integers(17, 65))  # (the small path's wide-input variant; the oracle's n x m matrices stay small)
         X = np.asfortranarray(rng.normal(size=(D, n)))
         y = np.sin(X.sum(0)) + 0.1 * rng.normal(size=n)
         P = np.asfortranarray(rng.normal(size=(D, d)) / np.sqrt(D * d)) if (D != d or rng.integers(0, 2)) else None
