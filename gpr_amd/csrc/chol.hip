@@ -49,12 +49,16 @@ __device__ __forceinline__ double* dblk(double* T, int b) {
 // FUSED (single-block matrices, mp = 128, PotrfFuse in kernels.h): the B~ phase of pass 2 in one kernel -- the block is
 // I + the reduced accumulation of pass 1 instead of a load, and the m-vectors that follow the factorisation (log|B~|, b,
 // t~, t, |b|^2) are formed from the inverse while it is still in LDS: six launches of ~5 us each on the latency chain of
-// every evaluation with m <= 128 become the head and tail of this one.  (Measured and dropped: building K_m + jitter in
-// the same way costs the single workgroup what the cov_upper launch costs; summing the small row pass's per-workgroup
-// partials here instead of in their own launch: 1 MB through one CU, 130 us.)
-template <bool FUSED>
+// every evaluation with m <= 128 become the head and tail of this one.  (Measured and dropped: summing the small row
+// pass's per-workgroup partials here instead of in their own launch: 1 MB through one CU, 130 us.)
+// MODE 0: the block is loaded; 1 (FUSED): the B~ phase; 2: K_m + jitter of at most 64 inducing points built in place of the
+// load (PotrfKm in kernels.h: the values of cov_upper_kernel from the points staged in LDS -- 4096 entries, eight per
+// thread -- and the plain covariance written to km), which takes the cov_upper launch off small evaluations.
+template <int MODE>
 __device__ __forceinline__ void potrf_diag_body(double* __restrict__ A, int mp, int j, double* __restrict__ dinv,
-                                                int* __restrict__ info, int flags, int m_real, const PotrfFuse& f) {
+                                                int* __restrict__ info, int flags, int m_real, const PotrfFuse& f,
+                                                const PotrfKm& g) {
+  constexpr bool FUSED = MODE == 1;
   extern __shared__ __attribute__((aligned(16))) double T[];  // [NB][LDT]
   double* T1 = T + NB * LDT;                                   // [NB][MB]
   double* rdiag = T1 + NB * MB;                                // [NB] reciprocal pivots
@@ -90,6 +94,39 @@ __device__ __forceinline__ void potrf_diag_body(double* __restrict__ A, int mp, 
         ureg[2 * kk] = v.x;
         ureg[2 * kk + 1] = v.y;
       }
+    }
+  } else if (MODE == 2) {
+    // K_m (lib/cov_se_iso.ml:56-87, lib/cov_se_fat.ml:85-100) + heteroskedastic noise + jitter on the real diagonal
+    // (lib/fitc_gp.ml:54-55), 1 on the padded one; g.km = the covariance alone, full and symmetric, padding 0
+    const ExpK ek = exp_consts();
+    double* zs = T1;  // [64][d] (d <= 16: the scratch of the inversion, free until then)
+    for (int idx = tid; idx < g.m * g.d; idx += PT) zs[idx] = g.Z[idx];
+    for (int idx = tid; idx < NB * NB; idx += PT) {  // everything outside the 64 x 64 corner
+      const int r = idx / NB, c = idx % NB;
+      if (r < 64 && c < 64) continue;
+      g.km[idx] = 0.0;
+      if (c >= r) T[r * LDT + c] = (r == c) ? 1.0 : 0.0;
+    }
+    __syncthreads();
+    for (int idx = tid; idx < 64 * 64; idx += PT) {
+      const int r = idx >> 6, c = idx & 63;
+      double val = 0.0, valj = (r == c) ? 1.0 : 0.0;
+      if (r < g.m && c < g.m) {
+        if (r == c) {
+          val = g.cp.sf2;
+          valj = (g.het ? g.cp.sf2 + g.het[c] : g.cp.sf2) + g.jitter;
+        } else {
+          double acc = 0.0;
+          for (int k = 0; k < g.d; ++k) {
+            const double diff = zs[c * g.d + k] - zs[r * g.d + k];
+            acc = acc + diff * diff;
+          }
+          val = exp_fast(g.cp.log_sf2 + g.cp.inv_ell2_05 * acc, ek);
+          valj = val;
+        }
+      }
+      g.km[r * NB + c] = val;
+      if (c >= r) T[r * LDT + c] = valj;
     }
   } else {
     for (int idx = tid; idx < NB * NB / 2; idx += PT) {
@@ -388,12 +425,17 @@ __device__ __forceinline__ void potrf_diag_body(double* __restrict__ A, int mp, 
 __global__ __launch_bounds__(PT) void potrf_diag_kernel(double* __restrict__ A, int mp, int j,
                                                         double* __restrict__ dinv,
                                                         int* __restrict__ info, int flags, int m_real) {
-  potrf_diag_body<false>(A, mp, j, dinv, info, flags, m_real, PotrfFuse{});
+  potrf_diag_body<0>(A, mp, j, dinv, info, flags, m_real, PotrfFuse{}, PotrfKm{});
+}
+
+__global__ __launch_bounds__(PT) void potrf_km_kernel(PotrfKm g, double* __restrict__ A, double* __restrict__ dinv,
+                                                      int* __restrict__ info) {
+  potrf_diag_body<2>(A, NB, 0, dinv, info, 64, g.m, PotrfFuse{}, g);
 }
 
 __global__ __launch_bounds__(PT) void potrf_fused_kernel(PotrfFuse f, double* __restrict__ A, double* __restrict__ dinv,
                                                          int* __restrict__ info, int m_real) {
-  potrf_diag_body<true>(A, NB, 0, dinv, info, 64, m_real, f);
+  potrf_diag_body<1>(A, NB, 0, dinv, info, 64, m_real, f, PotrfKm{});
 }
 
 // ---- blocked factorisation without the engine: panel solve and trailing update of one 128-row step
@@ -633,9 +675,16 @@ static void potrf_attrs() {
                                 hipFuncAttributeMaxDynamicSharedMemorySize, POTRF_LDS));
     GPR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&potrf_fused_kernel),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, POTRF_LDS));
+    GPR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&potrf_km_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, POTRF_LDS));
     GPR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&potrf_panel_kernel),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, PANEL_LDS));
   });
+}
+void launch_potrf_km(const PotrfKm& g, double* A, double* Xinv, int* info, hipStream_t s) {
+  potrf_attrs();
+  hipLaunchKernelGGL(potrf_km_kernel, dim3(1), dim3(PT), POTRF_LDS, s, g, A, Xinv, info);
+  GPR_HIP(hipGetLastError());
 }
 void launch_potrf_fused(const PotrfFuse& f, double* A, double* Xinv, int* info, int m_real, hipStream_t s) {
   potrf_attrs();

@@ -615,8 +615,15 @@ void do_pass1(gprhip_problem* p, const gprhip_hypers* h, int want_grad, int64_t 
   if (mp != TILE || p->engine_steps) GPR_HIP(hipMemsetAsync(p->scal, 0, (NSCAL + 2) * sizeof(double), s));
   if (!small || reuse) GPR_HIP(hipMemsetAsync(ar1_c, 0, (size_t)(mp + A1_TAIL) * sizeof(double), s));
   // K_m + (hetero) + jitter goes straight into the factor's buffer (kj is scratch of the finish stage only)
-  launch_cov_upper(p->cp, p->Z, p->m, mp, p->d, h->jitter, p->has_het() ? p->het : nullptr, p->km, p->umat, s);
-  potrf_trtri(p, p->umat, p->uinv, p->wmat, p->info);  // U = chol(K_m + jitter), lib/fitc_gp.ml:53-57, and U^-1
+  if (mp == TILE && p->m <= 64 && p->d <= 16 && !p->engine_steps && !p->has_ms() && p->small_path) {
+    PotrfKm g;  // few inducing points: the covariance is built inside the factorisation kernel (chol.hip, MODE 2)
+    g.cp = p->cp; g.Z = p->Z; g.m = p->m; g.d = p->d; g.jitter = h->jitter;
+    g.het = p->has_het() ? p->het : nullptr; g.km = p->km;
+    launch_potrf_km(g, p->umat, p->uinv, p->info, s);
+  } else {
+    launch_cov_upper(p->cp, p->Z, p->m, mp, p->d, h->jitter, p->has_het() ? p->het : nullptr, p->km, p->umat, s);
+    potrf_trtri(p, p->umat, p->uinv, p->wmat, p->info);  // U = chol(K_m + jitter), lib/fitc_gp.ml:53-57, and U^-1
+  }
   if (p->f32) launch_to_float(p->uinv, p->uinv_f, mm, s);
   tstop(p);
 

@@ -68,6 +68,17 @@ struct PotrfFuse {
   double *bvec = nullptr, *ttil = nullptr, *tvec = nullptr, *logdet = nullptr, *bb = nullptr;  // out
 };
 void launch_potrf_fused(const PotrfFuse& f, double* A, double* Xinv, int* info, int m_real, hipStream_t s);
+// At most 64 inducing points of at most 16 dimensions, no multiscales: A = chol(K_m + het + jitter) with the matrix built
+// in the kernel (launch_cov_upper's values: km = the covariance alone), Xinv = A^-1; both 128 x 128 with identity padding.
+struct PotrfKm {
+  CovParams cp{};
+  const double* Z = nullptr;
+  int m = 0, d = 0;
+  double jitter = 0.0;
+  const double* het = nullptr;
+  double* km = nullptr;
+};
+void launch_potrf_km(const PotrfKm& g, double* A, double* Xinv, int* info, hipStream_t s);
 void launch_zero_strict_lower(double* A, int mp, hipStream_t s);
 void launch_copy_block(const double* src, int64_t lds, double* dst, int64_t ldd, int rows, int cols,
                        hipStream_t s);
