@@ -224,8 +224,7 @@ struct gprhip_problem {
   // exchange-2 column block: sum E, sum p_k E (d), sum x_big E (D), and for Cov_se_fat sum p_k^2 E (d)
   int64_t col_rows() const { return d + 1 + dbig() + (kind == GPRHIP_COV_SE_FAT ? d : 0); }
   bool use_small() const {
-    return small_path && !f32 && !engine_steps && nchunks == 1 && !has_ms() &&
-           small_path_fits(m, mp, d, has_proj() ? D : 0, n);
+    return small_path && !f32 && !engine_steps && !has_ms() && small_path_fits(m, mp, d, has_proj() ? D : 0, n);
   }
 };
 
@@ -773,9 +772,10 @@ void do_pass2(gprhip_problem* p, const double* ar1, double* ar2) {
       a.big = proj ? p->X : nullptr; a.D = proj ? p->D : 0;
       a.rows = (int)p->n; a.rows_p = (int)round_up(p->n, TILE); a.m = p->m; a.mp = mp; a.d = p->d;
       a.variational = p->h.variational;
-      a.w = p->w; a.v = p->v; a.es = proj ? p->es : nullptr; a.X = bufB; a.part = p->small_part;
+      // (X itself is only kept for the debug fetch "x_rows", which wants all rows in one chunk buffer)
+      a.w = p->w; a.v = p->v; a.es = proj ? p->es : nullptr; a.X = p->nchunks == 1 ? bufB : nullptr; a.part = p->small_part;
       launch_small_pass2(a, (int)p->col_rows(), ar2, ar2_col, ar2_proj, ar2_tail, s);
-      p->x_last = bufB;
+      p->x_last = a.X;
       tstop(p);
       p->stage = 2;
       return;

@@ -222,7 +222,8 @@ void launch_km_traces(const double* W, const double* km, const double* Z, int m,
 void launch_km_traces_ms(const double* W, const double* km, const double* Z, const double* ms, int m, int mp,
                          int d, double* part, hipStream_t s);
 
-// ---- row passes of small problems (small.hip): m <= 64, one chunk of at most 65536 rows, d <= 16, D <= 64, fp64, no multiscales
+// ---- row passes of problems with few inducing points (small.hip): m <= 64, d <= 16, D <= 64, fp64, no multiscales; the rows
+// of all chunks are walked as one range (the resident stores are contiguous)
 struct SmallPass1Args {
   CovParams cp;
   const double *pts, *Z, *uinv, *y;  // points [rows][d], inducing [mp][d], U^-1 [mp][mp], targets (or null)
@@ -236,7 +237,7 @@ struct SmallPass2Args {
   const double *pts, *Z, *uinv, *rinv, *bvec, *ttil, *V, *y, *is, *r;
   const double* big;                 // original inputs [rows][D] (Cov_se_fat with tproj) or null
   int D, rows, rows_p, m, mp, d, variational;
-  double *w, *v, *es, *X;            // out: w, v [rows_p], es [rows_p] (or null), X [rows_p][mp] (columns < 64)
+  double *w, *v, *es, *X;            // out: w, v [rows_p], es [rows_p] (or null), X [rows_p][mp] (columns < 64; or null)
   double* part;
 };
 bool small_path_fits(int m, int mp, int d, int D, int64_t rows);

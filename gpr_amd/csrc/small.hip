@@ -1,5 +1,5 @@
-// Row passes of small problems (m <= 64 inducing points, d <= 16 point dimensions -- D <= 64 input dimensions in front of
-// a projection --, one row chunk): the reference's own shapes (n = 1000..2000,
+// Row passes of problems with few inducing points (m <= 64, d <= 16 point dimensions -- D <= 64 input dimensions in front
+// of a projection --, any number of rows): the reference's own shapes (n = 1000..2000,
 // m = 10..50, test/save_data.ml, test/gen_data.ml) spend their time in launches, not in arithmetic -- through the engine a
 // gradient evaluation is 9 contraction launches of 16-22 us each plus ~20 small kernels.  Here each pass is ONE kernel
 // per 64-row block that keeps the block's rows of K, V, Q' and X in LDS and the 64 x 64 corners of U^-1 / R~^-1 beside
@@ -118,9 +118,13 @@ __device__ __forceinline__ void load_corner(const double* __restrict__ M, int mp
 
 }  // namespace
 
-constexpr int SMALL_GROUPS = 128;  // workgroups of a pass at most (each walks blocks b, b + groups, ...)
-int64_t small_part_len(int d, int D) { return (int64_t)SMALL_GROUPS * std::max(P1LEN, p2len(d, D)); }
-static int small_groups(int rows_p) { return std::min(SMALL_GROUPS, rows_p / SRB); }
+// workgroups of a pass at most (each walks blocks b, b + groups, ...): what the chip holds at once -- two per CU for
+// pass 1 (77 KB of LDS each), one per CU for pass 2 (150 KB)
+constexpr int SMALL_GROUPS1 = 512, SMALL_GROUPS2 = 256;
+int64_t small_part_len(int d, int D) {
+  return std::max((int64_t)SMALL_GROUPS1 * P1LEN, (int64_t)SMALL_GROUPS2 * p2len(d, D));
+}
+static int small_groups(int rows_p, int cap) { return std::min(cap, rows_p / SRB); }
 
 template <int DT>
 __global__ __launch_bounds__(256) void small_pass1_kernel(SmallPass1Args a) {
@@ -390,7 +394,7 @@ __global__ __launch_bounds__(256) void small_pass2_kernel(SmallPass2Args a) {
 #pragma unroll
       for (int ct = 0; ct < 4; ++ct) {
         Qt[row * SLD + 16 * ct + l15] = acc[ct][r];
-        a.X[(int64_t)(r0 + row) * a.mp + 16 * ct + l15] = acc[ct][r];
+        if (a.X) a.X[(int64_t)(r0 + row) * a.mp + 16 * ct + l15] = acc[ct][r];
       }
     }
     gram_update(Vt, vr, wv, l15, lq, accG);  // G~ part = V^T diag(v) V
@@ -686,12 +690,14 @@ static void small_attrs() {
 }
 
 bool small_path_fits(int m, int mp, int d, int D, int64_t rows) {
-  return m <= SM && mp == TILE && d <= 16 && D <= 64 && rows <= 65536;
+  // (rows: no structural limit -- the partial sums are per workgroup, not per block; 4M rows is where int indices of the
+  //  row kernels around it were last checked)
+  return m <= SM && mp == TILE && d <= 16 && D <= 64 && rows <= (int64_t(1) << 22);
 }
 
 void launch_small_pass1(const SmallPass1Args& a, double* tile, double* cvec, double* tail, hipStream_t s) {
   small_attrs();
-  const int ng = small_groups(a.rows_p);
+  const int ng = small_groups(a.rows_p, SMALL_GROUPS1);
   small_dispatch(a.d, [&](auto dt) {
     constexpr int DT = decltype(dt)::value;
     hipLaunchKernelGGL((small_pass1_kernel<DT>), dim3(ng), dim3(256), small_lds1(DT), s, a);
@@ -703,7 +709,7 @@ void launch_small_pass1(const SmallPass1Args& a, double* tile, double* cvec, dou
 void launch_small_pass2(const SmallPass2Args& a, int col_rows, double* tile, double* colblk, double* proj, double* tail,
                         hipStream_t s) {
   small_attrs();
-  const int ng = small_groups(a.rows_p);
+  const int ng = small_groups(a.rows_p, SMALL_GROUPS2);
   small_dispatch(a.d, [&](auto dt) {
     constexpr int DT = decltype(dt)::value;
     if (a.D == 0) hipLaunchKernelGGL((small_pass2_kernel<DT, 1>), dim3(ng), dim3(256), small_lds2(DT), s, a);

@@ -53,10 +53,10 @@ def _eval_golden(p, g, **kw):
 
 
 def _small_path_applies(g):
-    """gpr_amd/csrc/small.hip: one-kernel row passes for m <= 64, d <= 16, D <= 64, no multiscales, one row chunk."""
+    """gpr_amd/csrc/small.hip: one-kernel row passes for m <= 64, d <= 16, D <= 64, no multiscales."""
     d, m = g["Z"].shape
     D = g["X"].shape[0]
-    return m <= 64 and d <= 16 and D <= 64 and "log_multiscales" not in g and g["X"].shape[1] <= 65536
+    return m <= 64 and d <= 16 and D <= 64 and "log_multiscales" not in g
 
 
 def _golden_cases(names):
@@ -1520,11 +1520,11 @@ def test_random_small_shapes_against_oracle(seed):
 @pytest.mark.gpu
 @pytest.mark.parametrize("kind,n,m,d,D", [("iso", 20000, 40, 3, 3), ("iso", 65536, 64, 16, 16), ("fat", 9000, 33, 5, 8),
                                           ("iso", 65537, 20, 2, 2), ("fat", 700, 25, 4, 17), ("fat", 2500, 64, 16, 64),
-                                          ("fat", 1500, 12, 9, 41)])
+                                          ("fat", 1500, 12, 9, 41), ("iso", 300001, 40, 3, 3), ("fat", 140000, 30, 4, 20)])
 def test_small_path_with_several_blocks_per_workgroup(kind, n, m, d, D, monkeypatch):
-    """Above 8192 training points a workgroup of the small row passes walks several 64-row blocks (128 workgroups at
-    most) and accumulates its partial sums across them; 65 536 rows is the last size the path takes, 65 537 the first
-    that goes through the engine.  Projections from more than 16 input dimensions (up to 64) form their input moments
+    """Above 16 384 training points a workgroup of the small row passes walks several 64-row blocks (256 workgroups at
+    most) and accumulates its partial sums across them; the rows of several chunks (131 072 each) are one range to it.
+    Projections from more than 16 input dimensions (up to 64) form their input moments
     as one more matrix-core product per block.  Against the oracle, and against the engine path on the same problem."""
     rng = np.random.default_rng(n + m)
     if kind == "iso":
@@ -1551,7 +1551,7 @@ def test_small_path_with_several_blocks_per_workgroup(kind, n, m, d, D, monkeypa
         p.set_targets(y)
         p.set_timing(2)
         ev = p.eval(sigma2=0.15, inducing=Z, variational=True, **args)
-        assert ("p1_small" in p.last_timings()) == (path == "default" and n <= 65536)
+        assert ("p1_small" in p.last_timings()) == (path == "default")
         p.close()
         assert abs(ev.l - ref["l"]) <= TOL_L * abs(ref["l"])
         assert abs(ev.dl_dsigma2 - ref["dl_dsigma2"]) <= TOL_DS2 * abs(ref["dl_dsigma2"])

@@ -14,7 +14,8 @@ from bench import synth  # noqa: E402
 
 REPS = int(os.environ.get("REPS", 30))
 shapes = [tuple(int(v) for v in a.split(",")) for a in sys.argv[1:]] or [
-    (2000, 50, 3), (2000, 128, 3), (10000, 256, 8), (50000, 512, 8), (100000, 1024, 8), (16384, 2048, 8)]
+    (2000, 50, 3), (1000, 10, 1), (100000, 50, 3), (1000000, 50, 8), (2000, 128, 3), (10000, 256, 8), (50000, 512, 8),
+    (100000, 1024, 8), (16384, 2048, 8)]
 for n, m, d in shapes:
     X, y, Z = synth(1, n, m, d)
     p = gpr_amd.Problem(gpr_amd.COV_SE_ISO, n, d, d, m)
