@@ -143,7 +143,7 @@ struct gprhip_problem {
   const void* x_last = nullptr;  // single-chunk gradient evaluations: the chunk buffer that holds X (debug fetch "x_rows")
   bool have_k = false;        // Kstore holds K_nm of the current kernel and inducing points for every chunk
   int k_resident = 1;         // GPRHIP_K_RESIDENT=0 (read at creation): never keep K_nm (ablation)
-  // GPRHIP_SMALL_PATH=0 (read at creation): never take the one-kernel row passes of small problems (small.hip)
+  // GPRHIP_SMALL_PATH=0 (read at creation): never take the one-kernel passes for at most 64 inducing points (small.hip)
   int small_path = 1;
   double* small_part = nullptr;  // their per-workgroup partial sums (allocated at first use)
   int w_as_ws = 1;            // GPRHIP_W_AS_WS=0 (read at creation): pass-2 SYRK through the plain weighted kernel (do_pass2)
@@ -628,7 +628,8 @@ void do_pass1(gprhip_problem* p, const gprhip_hypers* h, int want_grad, int64_t 
 
   if constexpr (std::is_same<TS, double>::value) {
     if (small && !reuse) {
-      // small problems: covariance, V, the row quantities and both accumulations in one kernel + one reduction (small.hip)
+      // at most 64 inducing points: covariance, V, the row quantities and both accumulations in one kernel + one reduction
+      // (small.hip)
       tstart(p, "p1_small");
       SmallPass1Args a;
       a.cp = p->cp; a.pts = p->pts(); a.Z = p->Z; a.uinv = p->uinv; a.y = h->model_only ? nullptr : p->y;
@@ -761,7 +762,7 @@ void do_pass2(gprhip_problem* p, const double* ar1, double* ar2) {
   else if (!p->want_grad) GPR_HIP(hipMemsetAsync(ar2_tail, 0, (size_t)A2_TAIL * sizeof(double), s));
   if constexpr (std::is_same<TS, double>::value) {
     if (p->want_grad && small) {
-      // small problems: Q', the row quantities, X~, X, the column sums of E = X .* K and G~ in one kernel (small.hip);
+      // at most 64 inducing points: Q', the row quantities, X~, X, the column sums of E = X .* K and G~ in one kernel (small.hip);
       // B~^-1 is formed by the finish kernel, R^-1 is not needed
       tstart(p, "p2_small");
       if (!p->small_part) p->small_part = p->alloc<double>(small_part_len(p->d, p->D));
@@ -976,7 +977,8 @@ void do_finish_enqueue(gprhip_problem* p, const double* ar2, bool light = false)
   const bool wdiag = p->want_grad && (p->has_het() || p->has_ms());
   const int64_t n_a2 = (ar2_tail + A2_TAIL) - ar2_col;  // the exchange-2 buffer from its column block on
   if (p->want_grad && p->use_small()) {
-    // small problems: the m x m work in one workgroup, which also gathers the exchange-2 tail behind the result block
+    // at most 64 inducing points: the m x m work in one workgroup, which also gathers the exchange-2 tail behind the
+    // result block
     tstart(p, "finish");
     SmallFinishArgs a;
     a.uinv = p->uinv; a.rinv = p->rinv; a.ttil = p->ttil; a.km = p->km; a.Z = p->Z; a.g = ar2;

@@ -1626,7 +1626,7 @@ def _random_shape_case(seed, shards=0, small=False):
     variational = bool(rng.integers(0, 2))
     sigma2 = float(10.0 ** rng.uniform(-2, 0))
     chunk_rows = int(rng.choice([0, 256, 1024, 4096]))
-    if small:  # the shapes of gpr_amd/csrc/small.hip: at most 64 inducing points, 16 dimensions, one row chunk
+    if small:  # the shapes of gpr_amd/csrc/small.hip: at most 64 inducing points, 16 point dimensions
         n = int(rng.integers(1, 4000 if iso else 2500))
         m = int(rng.integers(1, 65))
         d = int(rng.choice([1, 2, 3, 4, 5, 8, 9, 13, 16] if iso else [1, 2, 3, 5, 8, 11, 13]))
