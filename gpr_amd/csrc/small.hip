@@ -1,8 +1,8 @@
-// Row passes of problems with few inducing points (m <= 64, d <= 16 point dimensions -- D <= 64 input dimensions in front
-// of a projection --, any number of rows): the reference's own shapes (n = 1000..2000,
-// m = 10..50, test/save_data.ml, test/gen_data.ml) spend their time in launches, not in arithmetic -- through the engine a
-// gradient evaluation is 9 contraction launches of 16-22 us each plus ~20 small kernels.  Here each pass is ONE kernel
-// per 64-row block that keeps the block's rows of K, V, Q' and X in LDS and the 64 x 64 corners of U^-1 / R~^-1 beside
+// Row passes and finish stage of problems with few inducing points (m <= 64, d <= 16 point dimensions -- D <= 64 input
+// dimensions in front of a projection --, any number of rows).  The reference's own shapes (n = 1000..2000, m = 10..50,
+// test/save_data.ml, test/gen_data.ml) spend their time in launches, not in arithmetic -- through the engine a gradient
+// evaluation is 9 contraction launches of 16-22 us each plus ~20 small kernels, 0.40 ms; and with many rows the engine
+// pads m to its 128-wide tile (6.5x the flops of m = 50).  Here each pass is ONE kernel per 64-row block that keeps the block's rows of K, V, Q' and X in LDS and the 64 x 64 corners of U^-1 / R~^-1 beside
 // them, plus one fixed-order reduction of the per-workgroup partial sums into the exchange buffers -- same buffers, same
 // layout as the engine path writes (do_pass1 / do_pass2), so everything around the two passes is shared.
 //   pass 1: K (lib/cov_se_iso.ml:128-159, lib/cov_se_fat.ml:224-240), V = K U^-1 (lib/fitc_gp.ml:226-227), r, s, 1/s
@@ -46,7 +46,7 @@ __device__ __forceinline__ double sum64(double v) {
 
 // rows [16 wv, 16 wv + 16) of  A (LDS, [64][SLD]) times  B (LDS, [64][SLD]; TRANS: times B^T)  -> acc[ct], ct = column tile.
 // Fully unrolled, all fragments of a half of the k-range loaded before its 32 MFMAs: with the loop left rolled every
-// step waits for its own LDS reads and a product takes 2.5-4.5 us instead of ~1.
+// step waits for its own LDS reads and a product takes 2.5-4.5 us instead of ~2.
 template <bool TRANS>
 __device__ __forceinline__ void rows_times(const double* A, const double* B, int wv, int l15, int lq, sd4 (&acc)[4]) {
 #pragma unroll
