@@ -224,7 +224,7 @@ struct gprhip_problem {
   // exchange-2 column block: sum E, sum p_k E (d), sum x_big E (D), and for Cov_se_fat sum p_k^2 E (d)
   int64_t col_rows() const { return d + 1 + dbig() + (kind == GPRHIP_COV_SE_FAT ? d : 0); }
   bool use_small() const {
-    return small_path && !f32 && !engine_steps && !has_ms() && small_path_fits(m, mp, d, has_proj() ? D : 0, n);
+    return small_path && !f32 && !engine_steps && small_path_fits(m, mp, d, has_proj() ? D : 0, n, has_ms());
   }
 };
 
@@ -982,7 +982,8 @@ void do_finish_enqueue(gprhip_problem* p, const double* ar2, bool light = false)
     tstart(p, "finish");
     SmallFinishArgs a;
     a.uinv = p->uinv; a.rinv = p->rinv; a.ttil = p->ttil; a.km = p->km; a.Z = p->Z; a.g = ar2;
-    a.m = m; a.mp = mp; a.d = d; a.km_rows = d + 2;
+    a.ms = p->has_ms() ? p->ms : nullptr;
+    a.m = m; a.mp = mp; a.d = d; a.km_rows = p->has_ms() ? 2 * d + 2 : d + 2;
     a.wmat = p->wmat; a.kmred = p->kmred; a.wdiag = wdiag ? p->wdiag : nullptr;
     a.gather_from = ar2_col; a.n_gather = n_a2; a.ex = p->ex_dev + A1_TAIL;
     launch_small_finish(a, s);

@@ -222,7 +222,7 @@ void launch_km_traces(const double* W, const double* km, const double* Z, int m,
 void launch_km_traces_ms(const double* W, const double* km, const double* Z, const double* ms, int m, int mp,
                          int d, double* part, hipStream_t s);
 
-// ---- row passes of problems with few inducing points (small.hip): m <= 64, d <= 16, D <= 64, fp64, no multiscales; the rows
+// ---- row passes of problems with few inducing points (small.hip): m <= 64, d <= 16 (8 with multiscales), D <= 64, fp64; the rows
 // of all chunks are walked as one range (the resident stores are contiguous)
 struct SmallPass1Args {
   CovParams cp;
@@ -240,7 +240,7 @@ struct SmallPass2Args {
   double *w, *v, *es, *X;            // out: w, v [rows_p], es [rows_p] (or null), X [rows_p][mp] (columns < 64; or null)
   double* part;
 };
-bool small_path_fits(int m, int mp, int d, int D, int64_t rows);
+bool small_path_fits(int m, int mp, int d, int D, int64_t rows, bool ms);
 int64_t small_part_len(int d, int D);
 // pass 1 + its reduction into the exchange-1 buffer: (0,0) tile, c~ [mp], scalar tail [4]
 void launch_small_pass1(const SmallPass1Args& a, double* tile, double* cvec, double* tail, hipStream_t s);
@@ -251,8 +251,10 @@ void launch_small_pass2(const SmallPass2Args& a, int col_rows, double* tile, dou
 // the finish stage of a gradient evaluation (m x m work on the 64 x 64 corners) in one workgroup
 struct SmallFinishArgs {
   const double *uinv, *rinv, *ttil, *km, *Z;
+  const double* ms;         // multiscales [mp][d] or null
   const double* g;          // (0,0) tile of the reduced exchange-2 buffer: G~ = V^T diag(v) V
-  int m, mp, d, km_rows;    // km_rows: rows of kmred to write (0: sum W.*K, 1: sum W.*K.*dist, 2+k: per dimension)
+  int m, mp, d, km_rows;    // km_rows: rows of kmred to write (0: sum W.*K, 1: sum W.*K.*dist, 2+k: per dimension; with
+                            //   multiscales 2+d+k as km_traces_ms_kernel)
   double *wmat, *kmred, *wdiag;  // out (wdiag may be null)
   const double* gather_from;     // n_gather doubles copied to ex (the exchange-2 tail behind the result block)
   int64_t n_gather;

@@ -24,7 +24,10 @@ constexpr int SM = 64;    // inducing points (padded) the small path handles
 constexpr int SLD = 66;   // leading dimension of the 64 x 64 LDS matrices
 constexpr int SRB = 64;   // training points per block iteration
 constexpr int P1LEN = SM * SM + SM + 4;  // pass-1 partial of a workgroup: B~ part | c~ part | sum log s, sum y^2/s, sum r/s, -
-__host__ __device__ constexpr int p2len(int d, int D) { return SM * SM + (1 + d + D) * SM + D * d + 8; }
+// pass-2 partial: G~ part | column sums: E, p_k E (d), x_big E (D), with multiscales p_k^2 E (d) | `Proj term (D d) | 8 scalars
+__host__ __device__ constexpr int p2len(int d, int D, int ms = 0) {
+  return SM * SM + (1 + d + D + (ms ? d : 0)) * SM + D * d + 8;
+}
 
 typedef double sd4 __attribute__((ext_vector_type(4)));
 // lane supplies A[lane&15][lane>>4] and B[lane>>4][lane&15]; accumulator element r is D[(lane>>4) + 4r][lane&15]
@@ -47,23 +50,24 @@ __device__ __forceinline__ double sum64(double v) {
 // rows [16 wv, 16 wv + 16) of  A (LDS, [64][SLD]) times  B (LDS, [64][SLD]; TRANS: times B^T)  -> acc[ct], ct = column tile.
 // Fully unrolled, all fragments of a half of the k-range loaded before its 32 MFMAs: with the loop left rolled every
 // step waits for its own LDS reads and a product takes 2.5-4.5 us instead of ~2.
-template <bool TRANS>
+// (NB = k-steps per batch: 8, or 4 where registers are short)
+template <bool TRANS, int NB = 8>
 __device__ __forceinline__ void rows_times(const double* A, const double* B, int wv, int l15, int lq, sd4 (&acc)[4]) {
 #pragma unroll
   for (int ct = 0; ct < 4; ++ct) acc[ct] = sd4{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-  for (int h = 0; h < 2; ++h) {
-    double af[8], bf[8][4];
+  for (int h = 0; h < 16 / NB; ++h) {
+    double af[NB], bf[NB][4];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int kk = 8 * h + j;
+    for (int j = 0; j < NB; ++j) {
+      const int kk = NB * h + j;
       af[j] = A[(16 * wv + l15) * SLD + 4 * kk + lq];
 #pragma unroll
       for (int ct = 0; ct < 4; ++ct)
         bf[j][ct] = TRANS ? B[(16 * ct + l15) * SLD + 4 * kk + lq] : B[(4 * kk + lq) * SLD + 16 * ct + l15];
     }
 #pragma unroll
-    for (int j = 0; j < 8; ++j)
+    for (int j = 0; j < NB; ++j)
 #pragma unroll
       for (int ct = 0; ct < 4; ++ct) acc[ct] = mfma_f64(af[j], bf[j][ct], acc[ct]);
   }
@@ -122,11 +126,13 @@ __device__ __forceinline__ void load_corner(const double* __restrict__ M, int mp
 // pass 1 (77 KB of LDS each), one per CU for pass 2 (150 KB)
 constexpr int SMALL_GROUPS1 = 512, SMALL_GROUPS2 = 256;
 int64_t small_part_len(int d, int D) {
-  return std::max((int64_t)SMALL_GROUPS1 * P1LEN, (int64_t)SMALL_GROUPS2 * p2len(d, D));
+  return std::max((int64_t)SMALL_GROUPS1 * P1LEN, (int64_t)SMALL_GROUPS2 * p2len(d, D, 1));
 }
 static int small_groups(int rows_p, int cap) { return std::min(cap, rows_p / SRB); }
 
-template <int DT>
+// MS: Cov_se_fat multiscales (lib/cov_se_fat.ml:241-251; a.cp.ms = exp(log_multiscales_m05) + 1/2 as [mp][d]): the exponent
+// accumulates diff * (diff / scale) + log(scale) per dimension, as cov_cross_ms_kernel
+template <int DT, bool MS>
 __global__ __launch_bounds__(256) void small_pass1_kernel(SmallPass1Args a) {
   extern __shared__ __attribute__((aligned(16))) double small_lds[];
   double* const Ui = small_lds;         // [SM][SLD]  U^-1
@@ -140,9 +146,15 @@ __global__ __launch_bounds__(256) void small_pass1_kernel(SmallPass1Args a) {
   load_corner(a.uinv, a.mp, Ui, tid);
   const int col = lane, rg = wv;  // covariance / column-sum phases: thread = (column, group of 16 rows)
   const bool live_c = col < a.m;
-  double z[DT];
+  double z[DT], sc[MS ? DT : 1], lsc[MS ? DT : 1];
 #pragma unroll
-  for (int k = 0; k < DT; ++k) z[k] = (k < a.d && live_c) ? a.Z[(int64_t)col * a.d + k] : 0.0;
+  for (int k = 0; k < DT; ++k) {
+    z[k] = (k < a.d && live_c) ? a.Z[(int64_t)col * a.d + k] : 0.0;
+    if constexpr (MS) {
+      sc[k] = (k < a.d && live_c) ? a.cp.ms[(int64_t)col * a.d + k] : 1.0;
+      lsc[k] = log(sc[k]);
+    }
+  }
   sd4 accB[4];
 #pragma unroll
   for (int ct = 0; ct < 4; ++ct) accB[ct] = sd4{0.0, 0.0, 0.0, 0.0};
@@ -165,7 +177,8 @@ __global__ __launch_bounds__(256) void small_pass1_kernel(SmallPass1Args a) {
       for (int k = 0; k < DT; ++k) {
         if (k < a.d) {
           const double diff = xs[r * DT + k] - z[k];
-          acc = acc + diff * diff;
+          if constexpr (MS) acc = (acc + diff * (diff / sc[k])) + lsc[k];
+          else acc = acc + diff * diff;
         }
       }
       Kt[r * SLD + col] = (r0 + r < a.rows && live_c) ? exp_fast(a.cp.log_sf2 + a.cp.inv_ell2_05 * acc, ek) : 0.0;
@@ -258,7 +271,10 @@ __global__ __launch_bounds__(256) void small_reduce1_kernel(const double* __rest
 }
 
 // DT: padded point dimension (d <= DT); DBT: padded dimension of the original inputs of a projected kernel (D <= DBT)
-template <int DT, int DBT>
+// MS (multiscales, d <= 8): K as grad_fused_ms_kernel forms it, the extra column sums of p_k^2 E (`Log_multiscale_m05,
+// lib/cov_se_fat.ml:598-622), and for the `Proj derivative one weight per (row, dimension), sum_c E_rc / ms_kc (:585-595),
+// formed from the E tile in LDS.  MS instantiations take the staged-inputs (WIDE) route for any D.
+template <int DT, int DBT, bool MS>
 __global__ __launch_bounds__(256) void small_pass2_kernel(SmallPass2Args a) {
   extern __shared__ __attribute__((aligned(16))) double small_lds[];
   double* const Ui = small_lds;          // [SM][SLD]  U^-1
@@ -275,6 +291,8 @@ __global__ __launch_bounds__(256) void small_pass2_kernel(SmallPass2Args a) {
   double* const bv = qbs + SRB;          // [SM] b
   double* const tt = bv + SM;            // [SM] t~
   double* const red = tt + SM;           // [4][SM] scratch of the final column reductions
+  double* const iscL = red + 4 * SM;     // MS: [SM][DT] 1 / ms_kc
+  double* const es2L = iscL + SM * DT;   // MS: [SRB][DT] sum_c E_rc / ms_kc of the block's rows
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l15 = lane & 15, lq = lane >> 4;
   const ExpK ek = exp_consts();
   const int d = a.d, D = a.D;
@@ -284,17 +302,30 @@ __global__ __launch_bounds__(256) void small_pass2_kernel(SmallPass2Args a) {
     bv[tid] = a.bvec[tid];
     tt[tid] = a.ttil[tid];
   }
+  if constexpr (MS) {
+    for (int idx = tid; idx < SM * DT; idx += 256) {
+      const int c = idx / DT, k = idx % DT;
+      iscL[idx] = (k < d && c < a.m) ? 1.0 / a.cp.ms[(int64_t)c * d + k] : 0.0;
+    }
+  }
   const int col = lane, rg = wv;
   const bool live_c = col < a.m;
   // moments of E against the original inputs (`Proj derivative): per-thread sums for D <= 16; above that one more MFMA
   // product per block, X_big^T E, with the inputs staged where V was (WIDE)
-  constexpr bool WIDE = DBT > 16;
+  constexpr bool WIDE = DBT > 16 || MS;
   constexpr int NGB = WIDE ? 1 : DBT;
   double z[DT], gx[DT], gb[NGB];
+  double isc[MS ? DT : 1], gxx[MS ? DT : 1], lsum = 0.0;
 #pragma unroll
   for (int k = 0; k < DT; ++k) {
     z[k] = (k < d && live_c) ? a.Z[(int64_t)col * d + k] : 0.0;
     gx[k] = 0.0;
+    if constexpr (MS) {
+      const double scale = (k < d && live_c) ? a.cp.ms[(int64_t)col * d + k] : 1.0;
+      isc[k] = 1.0 / scale;
+      lsum += log(scale);
+      gxx[k] = 0.0;
+    }
   }
 #pragma unroll
   for (int k = 0; k < NGB; ++k) gb[k] = 0.0;
@@ -332,7 +363,7 @@ __global__ __launch_bounds__(256) void small_pass2_kernel(SmallPass2Args a) {
     const double yreg = (rowlive && a.y) ? a.y[r0 + tid] : 0.0;
     __syncthreads();
     sd4 acc[4];
-    rows_times<false>(Vt, Ri, wv, l15, lq, acc);  // Q' = V R~^-1
+    rows_times<false, MS ? 4 : 8>(Vt, Ri, wv, l15, lq, acc);  // Q' = V R~^-1
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       double s2 = 0.0, sb = 0.0;
@@ -377,7 +408,7 @@ __global__ __launch_bounds__(256) void small_pass2_kernel(SmallPass2Args a) {
       esr[tid] = es;
     }
     __syncthreads();
-    rows_times<true>(Qt, Ri, wv, l15, lq, acc);  // Q' R~^-T
+    rows_times<true, MS ? 4 : 8>(Qt, Ri, wv, l15, lq, acc);  // Q' R~^-T
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int row = 16 * wv + lq + 4 * r;
@@ -387,7 +418,7 @@ __global__ __launch_bounds__(256) void small_pass2_kernel(SmallPass2Args a) {
         Qt[row * SLD + c] = isr[row] * acc[ct][r] - vr[row] * Vt[row * SLD + c] - wr[row] * tt[c];
       }
     }
-    rows_times<true>(Qt, Ui, wv, l15, lq, acc);  // X = X~ U^-T
+    rows_times<true, MS ? 4 : 8>(Qt, Ui, wv, l15, lq, acc);  // X = X~ U^-T
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int row = 16 * wv + lq + 4 * r;
@@ -400,8 +431,9 @@ __global__ __launch_bounds__(256) void small_pass2_kernel(SmallPass2Args a) {
     gram_update(Vt, vr, wv, l15, lq, accG);  // G~ part = V^T diag(v) V
     __syncthreads();
     if constexpr (WIDE) {  // V is done with: its tile now holds the block's original inputs, zero-padded to 64 columns
-      for (int idx = tid; idx < SRB * DBT; idx += 256) {
-        const int r = idx / DBT, k = idx % DBT;
+      constexpr int DW = 64;
+      for (int idx = tid; idx < SRB * DW; idx += 256) {
+        const int r = idx / DW, k = idx % DW;
         Vt[r * SLD + k] = (k < D && r0 + r < a.rows) ? a.big[(int64_t)(r0 + r) * D + k] : 0.0;
       }
     }
@@ -409,18 +441,22 @@ __global__ __launch_bounds__(256) void small_pass2_kernel(SmallPass2Args a) {
 #pragma unroll 4
     for (int i = 0; i < 16; ++i) {
       const int r = rg * 16 + i;
-      double dist = 0.0;
+      double dist = MS ? lsum : 0.0;
 #pragma unroll
       for (int k = 0; k < DT; ++k) {
         if (k < d) {
           const double diff = xs[r * DT + k] - z[k];
-          dist = dist + diff * diff;
+          if constexpr (MS) dist += diff * diff * isc[k];
+          else dist = dist + diff * diff;
         }
       }
       const bool live = live_c && r0 + r < a.rows;
       const double e = live ? Qt[r * SLD + col] * exp_fast(a.cp.log_sf2 + a.cp.inv_ell2_05 * dist, ek) : 0.0;
 #pragma unroll
-      for (int k = 0; k < DT; ++k) gx[k] += xs[r * DT + k] * e;
+      for (int k = 0; k < DT; ++k) {
+        gx[k] += xs[r * DT + k] * e;
+        if constexpr (MS) gxx[k] += xs[r * DT + k] * xs[r * DT + k] * e;
+      }
       if constexpr (WIDE) {
         Qt[r * SLD + col] = e;  // (rows of this wavefront)
       } else if (D > 0 && r0 + r < a.rows) {
@@ -435,6 +471,25 @@ __global__ __launch_bounds__(256) void small_pass2_kernel(SmallPass2Args a) {
     }
     if constexpr (WIDE) {
       __syncthreads();  // the staged inputs and E are complete
+      if constexpr (MS) {  // es2[row][k] = sum_c E_rc / ms_kc: four threads per row, sixteen columns each
+        const int row = tid >> 2, part = tid & 3;
+        double sum[DT];
+#pragma unroll
+        for (int k = 0; k < DT; ++k) sum[k] = 0.0;
+#pragma unroll 2
+        for (int c = 16 * part; c < 16 * part + 16; ++c) {
+          const double e = Qt[row * SLD + c];
+#pragma unroll
+          for (int k = 0; k < DT; ++k) sum[k] += e * iscL[c * DT + k];
+        }
+#pragma unroll
+        for (int k = 0; k < DT; ++k) {
+          double t = sum[k];
+          t += __shfl_xor(t, 1);
+          t += __shfl_xor(t, 2);
+          if (part == 0) es2L[row * DT + k] = t;
+        }
+      }
       // accGB[ct] += (X_big^T E) tile (wv, ct): input dimensions 16 wv .. 16 wv + 15 against columns 16 ct ..
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
@@ -452,18 +507,22 @@ __global__ __launch_bounds__(256) void small_pass2_kernel(SmallPass2Args a) {
           for (int ct = 0; ct < 4; ++ct) accGB[ct] = mfma_f64(af[j], bf[j][ct], accGB[ct]);
       }
     }
-    if (D > 0) {  // second term of the `Proj derivative: sum_r x_big,r p_small,r rowsum(E)_r
+    if (D > 0) {  // second term of the `Proj derivative: sum_r x_big,r p_small,r rowsum(E)_r  (MS: E / ms_small per column)
+      if constexpr (MS) __syncthreads();
       const int nr = min(SRB, a.rows - r0);
       for (int r = 0; r < nr; ++r) {
 #pragma unroll
         for (int j = 0; j < NPJ; ++j) {
           const double xb = WIDE ? Vt[r * SLD + pj_big[j]] : a.big[(int64_t)(r0 + r) * D + pj_big[j]];
-          pj[j] += xb * xs[r * DT + pj_small[j]] * esr[r];
+          const double wgt = MS ? es2L[r * DT + pj_small[j]] : esr[r];
+          pj[j] += xb * xs[r * DT + pj_small[j]] * wgt;
         }
       }
     }
   }
-  double* part = a.part + (int64_t)blockIdx.x * p2len(d, D);
+  constexpr int MSR = MS ? 1 : 0;
+  const int ncq = 1 + d + D + MSR * d;  // rows of the column block
+  double* part = a.part + (int64_t)blockIdx.x * p2len(d, D, MSR);
 #pragma unroll
   for (int ct = 0; ct < 4; ++ct)
 #pragma unroll
@@ -479,12 +538,19 @@ __global__ __launch_bounds__(256) void small_pass2_kernel(SmallPass2Args a) {
         if (k < D) pcol[(1 + d + k) * SM + 16 * ct + l15] = accGB[ct][r];
       }
   }
-  for (int q = 0; q < (WIDE ? 1 + d : 1 + d + D); ++q) {
+  for (int q = 0; q < ncq; ++q) {
+    if (WIDE && q > d && q <= d + D) continue;  // (written above)
     double val = cs;
     if (q >= 1 && q <= d) {
 #pragma unroll
       for (int k = 0; k < DT; ++k)
         if (k == q - 1) val = gx[k];
+    } else if (q > d + D) {
+      if constexpr (MS) {
+#pragma unroll
+        for (int k = 0; k < DT; ++k)
+          if (k == q - 1 - d - D) val = gxx[k];
+      }
     } else if (q > d) {
 #pragma unroll
       for (int k = 0; k < NGB; ++k)
@@ -495,7 +561,7 @@ __global__ __launch_bounds__(256) void small_pass2_kernel(SmallPass2Args a) {
     __syncthreads();
     if (tid < SM) pcol[q * SM + tid] = (red[tid] + red[SM + tid]) + (red[2 * SM + tid] + red[3 * SM + tid]);
   }
-  double* pproj = pcol + (1 + d + D) * SM;
+  double* pproj = pcol + ncq * SM;
 #pragma unroll
   for (int j = 0; j < NPJ; ++j)
     if (tid + 256 * j < D * d) pproj[tid + 256 * j] = pj[j];
@@ -529,10 +595,10 @@ __global__ __launch_bounds__(256) void small_pass2_kernel(SmallPass2Args a) {
 // exchange-2 buffer from the pass-2 partials, every entry written: the (0,0) tile (zero outside its 64 x 64 corner), the
 // column block (col_rows x mp; rows 0..d+D, columns < 64 carry sums), the `Proj second term and the scalar tail
 __global__ __launch_bounds__(256) void small_reduce2_kernel(const double* __restrict__ part, int ng, int mp, int d, int D,
-                                                            int col_rows, double* __restrict__ tile,
+                                                            int ms, int col_rows, double* __restrict__ tile,
                                                             double* __restrict__ colblk, double* __restrict__ proj,
                                                             double* __restrict__ tail) {
-  const int plen = p2len(d, D);
+  const int plen = p2len(d, D, ms), ncq = 1 + d + D + (ms ? d : 0);
   int idx = blockIdx.x * 256 + threadIdx.x;
   const int ntile = TILE * TILE, ncol = col_rows * mp, nproj = D * d;
   int src = -1;
@@ -544,13 +610,13 @@ __global__ __launch_bounds__(256) void small_reduce2_kernel(const double* __rest
   } else if ((idx -= ntile) < ncol) {
     const int q = idx / mp, c = idx % mp;
     dst = colblk + idx;
-    if (q < 1 + d + D && c < SM) src = SM * SM + q * SM + c;
+    if (q < ncq && c < SM) src = SM * SM + q * SM + c;
   } else if ((idx -= ncol) < nproj) {
     dst = proj + idx;
-    src = SM * SM + (1 + d + D) * SM + idx;
+    src = SM * SM + ncq * SM + idx;
   } else if ((idx -= nproj) < 8) {
     dst = tail + idx;
-    src = SM * SM + (1 + d + D) * SM + nproj + idx;
+    src = SM * SM + ncq * SM + nproj + idx;
   } else {
     return;
   }
@@ -561,7 +627,8 @@ __global__ __launch_bounds__(256) void small_reduce2_kernel(const double* __rest
 //   B~^-1 = R~^-1 R~^-T (Utils.ichol, lib/utils.ml:110-113),  W~ = I - B~^-1 - t~ t~^T - G~,  W = U^-1 W~ U^-T
 //   (lib/fitc_gp.ml:1196-1203), the trace terms of W against K_m and its derivatives (km_traces_kernel: :956-973,
 //   lib/utils.ml:196-220), diag W, and the tails of both exchange buffers gathered behind the result block.
-template <int DT>
+// MS: the multiscale trace terms of km_traces_ms_kernel (lib/cov_se_fat.ml:441-516)
+template <int DT, bool MS>
 __global__ __launch_bounds__(256) void small_finish_kernel(SmallFinishArgs a) {
   extern __shared__ __attribute__((aligned(16))) double small_lds[];
   double* const Ui = small_lds;        // [SM][SLD] U^-1
@@ -571,6 +638,7 @@ __global__ __launch_bounds__(256) void small_finish_kernel(SmallFinishArgs a) {
   double* const zs = Yt + SM * SLD;    // [SM][DT]
   double* const tt = zs + SM * DT;     // [SM]
   double* const red = tt + SM;         // [4][SM]
+  double* const msL = red + 4 * SM;    // MS: [SM][DT] multiscales (padding 1)
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l15 = lane & 15, lq = lane >> 4;
   const int d = a.d, m = a.m;
   load_corner(a.uinv, a.mp, Ui, tid);
@@ -579,6 +647,7 @@ __global__ __launch_bounds__(256) void small_finish_kernel(SmallFinishArgs a) {
   for (int idx = tid; idx < SM * DT; idx += 256) {
     const int c = idx / DT, k = idx % DT;
     zs[idx] = (k < d && c < m) ? a.Z[(int64_t)c * d + k] : 0.0;
+    if constexpr (MS) msL[idx] = (k < d && c < m) ? a.ms[(int64_t)c * d + k] : 1.0;
   }
   for (int64_t i = tid; i < a.n_gather; i += 256) a.ex[i] = a.gather_from[i];
   double kreg[16];  // K_m entries of the trace phase below (thread = column, group of 16 rows): loaded now, used at the end
@@ -618,33 +687,55 @@ __global__ __launch_bounds__(256) void small_finish_kernel(SmallFinishArgs a) {
   }
   __syncthreads();
   const int col = lane, rg = wv;
-  double g[DT], s0 = 0.0, s1 = 0.0;
+  double g[DT], gm[MS ? DT : 1], s0 = 0.0, s1 = 0.0;
 #pragma unroll
   for (int k = 0; k < DT; ++k) g[k] = 0.0;
+  if constexpr (MS) {
+#pragma unroll
+    for (int k = 0; k < DT; ++k) gm[k] = 0.0;
+  }
   if (col < m) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       const int r = rg * 16 + i;
       const double wk = Wt[r * SLD + col] * kreg[i];  // (0 beyond the real rows)
-      double dist = 0.0;
-#pragma unroll
-      for (int k = 0; k < DT; ++k) {
-        const double df = zs[r * DT + k] - zs[col * DT + k];
-        dist += df * df;
-        g[k] += wk * df;
-      }
       s0 += wk;
-      s1 += wk * dist;
+      if constexpr (MS) {
+        if (r != col) {
+#pragma unroll
+          for (int k = 0; k < DT; ++k) {
+            if (k < d) {
+              const double iscale = 1.0 / ((msL[r * DT + k] + msL[col * DT + k]) - 1.0);
+              const double sdiff = (zs[r * DT + k] - zs[col * DT + k]) * iscale;
+              g[k] += wk * sdiff;
+              gm[k] += wk * (iscale - sdiff * sdiff);
+            }
+          }
+        }
+      } else {
+        double dist = 0.0;
+#pragma unroll
+        for (int k = 0; k < DT; ++k) {
+          const double df = zs[r * DT + k] - zs[col * DT + k];
+          dist += df * df;
+          g[k] += wk * df;
+        }
+        s1 += wk * dist;
+      }
     }
   }
   for (int q = 0; q < a.km_rows; ++q) {
     double val = 0.0;
     if (q == 0) val = s0;
     else if (q == 1) val = s1;
-    else {
+    else if (q < 2 + d) {
 #pragma unroll
       for (int k = 0; k < DT; ++k)
         if (k == q - 2) val = g[k];
+    } else if constexpr (MS) {
+#pragma unroll
+      for (int k = 0; k < DT; ++k)
+        if (k == q - 2 - d) val = gm[k];
     }
     __syncthreads();
     red[rg * SM + col] = val;
@@ -655,8 +746,12 @@ __global__ __launch_bounds__(256) void small_finish_kernel(SmallFinishArgs a) {
 }
 
 static size_t small_lds1(int DT) { return (size_t)(2 * SM * SLD + SRB * DT + 3 * SRB) * sizeof(double); }
-static size_t small_lds3(int DT) { return (size_t)(4 * SM * SLD + SM * DT + SM + 4 * SM) * sizeof(double); }
-static size_t small_lds2(int DT) { return (size_t)(4 * SM * SLD + SRB * DT + 6 * SRB + 2 * SM + 4 * SM) * sizeof(double); }
+static size_t small_lds3(int DT, bool ms = false) {
+  return (size_t)(4 * SM * SLD + SM * DT + SM + 4 * SM + (ms ? SM * DT : 0)) * sizeof(double);
+}
+static size_t small_lds2(int DT, bool ms = false) {
+  return (size_t)(4 * SM * SLD + SRB * DT + 6 * SRB + 2 * SM + 4 * SM + (ms ? 2 * SM * DT : 0)) * sizeof(double);
+}
 
 template <typename F>
 static void small_dispatch(int d, F&& go) {
@@ -671,36 +766,46 @@ static void small_attrs() {
     auto set = [](const void* f, size_t bytes) {
       GPR_HIP(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
     };
-    set(reinterpret_cast<const void*>(&small_pass1_kernel<4>), small_lds1(4));
-    set(reinterpret_cast<const void*>(&small_pass1_kernel<8>), small_lds1(8));
-    set(reinterpret_cast<const void*>(&small_pass1_kernel<16>), small_lds1(16));
-    set(reinterpret_cast<const void*>(&small_pass2_kernel<4, 1>), small_lds2(4));
-    set(reinterpret_cast<const void*>(&small_pass2_kernel<8, 1>), small_lds2(8));
-    set(reinterpret_cast<const void*>(&small_pass2_kernel<16, 1>), small_lds2(16));
-    set(reinterpret_cast<const void*>(&small_pass2_kernel<4, 16>), small_lds2(4));
-    set(reinterpret_cast<const void*>(&small_pass2_kernel<8, 16>), small_lds2(8));
-    set(reinterpret_cast<const void*>(&small_pass2_kernel<16, 16>), small_lds2(16));
-    set(reinterpret_cast<const void*>(&small_pass2_kernel<4, 64>), small_lds2(4));
-    set(reinterpret_cast<const void*>(&small_pass2_kernel<8, 64>), small_lds2(8));
-    set(reinterpret_cast<const void*>(&small_pass2_kernel<16, 64>), small_lds2(16));
-    set(reinterpret_cast<const void*>(&small_finish_kernel<4>), small_lds3(4));
-    set(reinterpret_cast<const void*>(&small_finish_kernel<8>), small_lds3(8));
-    set(reinterpret_cast<const void*>(&small_finish_kernel<16>), small_lds3(16));
+#define GPRHIP_SMALL_SET(DT)                                                                                   \
+  set(reinterpret_cast<const void*>(&small_pass1_kernel<DT, false>), small_lds1(DT));                          \
+  set(reinterpret_cast<const void*>(&small_pass2_kernel<DT, 1, false>), small_lds2(DT));                       \
+  set(reinterpret_cast<const void*>(&small_pass2_kernel<DT, 16, false>), small_lds2(DT));                      \
+  set(reinterpret_cast<const void*>(&small_pass2_kernel<DT, 64, false>), small_lds2(DT));                      \
+  set(reinterpret_cast<const void*>(&small_finish_kernel<DT, false>), small_lds3(DT));
+    GPRHIP_SMALL_SET(4)
+    GPRHIP_SMALL_SET(8)
+    GPRHIP_SMALL_SET(16)
+#undef GPRHIP_SMALL_SET
+#define GPRHIP_SMALL_SET_MS(DT)                                                                                \
+  set(reinterpret_cast<const void*>(&small_pass1_kernel<DT, true>), small_lds1(DT));                           \
+  set(reinterpret_cast<const void*>(&small_pass2_kernel<DT, 1, true>), small_lds2(DT, true));                  \
+  set(reinterpret_cast<const void*>(&small_pass2_kernel<DT, 64, true>), small_lds2(DT, true));                 \
+  set(reinterpret_cast<const void*>(&small_finish_kernel<DT, true>), small_lds3(DT, true));
+    GPRHIP_SMALL_SET_MS(4)
+    GPRHIP_SMALL_SET_MS(8)
+#undef GPRHIP_SMALL_SET_MS
   });
 }
 
-bool small_path_fits(int m, int mp, int d, int D, int64_t rows) {
+bool small_path_fits(int m, int mp, int d, int D, int64_t rows, bool ms) {
   // (rows: no structural limit -- the partial sums are per workgroup, not per block; 4M rows is where int indices of the
-  //  row kernels around it were last checked)
-  return m <= SM && mp == TILE && d <= 16 && D <= 64 && rows <= (int64_t(1) << 22);
+  //  row kernels around it were last checked.  Multiscales: d <= 8, their extra LDS arrays do not fit beside d = 16.)
+  return m <= SM && mp == TILE && d <= (ms ? 8 : 16) && D <= 64 && rows <= (int64_t(1) << 22);
 }
 
 void launch_small_pass1(const SmallPass1Args& a, double* tile, double* cvec, double* tail, hipStream_t s) {
   small_attrs();
   const int ng = small_groups(a.rows_p, SMALL_GROUPS1);
+  const bool ms = a.cp.ms != nullptr;
   small_dispatch(a.d, [&](auto dt) {
     constexpr int DT = decltype(dt)::value;
-    hipLaunchKernelGGL((small_pass1_kernel<DT>), dim3(ng), dim3(256), small_lds1(DT), s, a);
+    if constexpr (DT <= 8) {
+      if (ms) {
+        hipLaunchKernelGGL((small_pass1_kernel<DT, true>), dim3(ng), dim3(256), small_lds1(DT), s, a);
+        return;
+      }
+    }
+    hipLaunchKernelGGL((small_pass1_kernel<DT, false>), dim3(ng), dim3(256), small_lds1(DT), s, a);
   });
   hipLaunchKernelGGL(small_reduce1_kernel, dim3(TILE * TILE / 256 + 1), dim3(256), 0, s, a.part, ng, a.mp, tile, cvec, tail);
   GPR_HIP(hipGetLastError());
@@ -710,15 +815,23 @@ void launch_small_pass2(const SmallPass2Args& a, int col_rows, double* tile, dou
                         hipStream_t s) {
   small_attrs();
   const int ng = small_groups(a.rows_p, SMALL_GROUPS2);
+  const bool ms = a.cp.ms != nullptr;
   small_dispatch(a.d, [&](auto dt) {
     constexpr int DT = decltype(dt)::value;
-    if (a.D == 0) hipLaunchKernelGGL((small_pass2_kernel<DT, 1>), dim3(ng), dim3(256), small_lds2(DT), s, a);
-    else if (a.D <= 16) hipLaunchKernelGGL((small_pass2_kernel<DT, 16>), dim3(ng), dim3(256), small_lds2(DT), s, a);
-    else hipLaunchKernelGGL((small_pass2_kernel<DT, 64>), dim3(ng), dim3(256), small_lds2(DT), s, a);
+    if constexpr (DT <= 8) {
+      if (ms) {
+        if (a.D == 0) hipLaunchKernelGGL((small_pass2_kernel<DT, 1, true>), dim3(ng), dim3(256), small_lds2(DT, true), s, a);
+        else hipLaunchKernelGGL((small_pass2_kernel<DT, 64, true>), dim3(ng), dim3(256), small_lds2(DT, true), s, a);
+        return;
+      }
+    }
+    if (a.D == 0) hipLaunchKernelGGL((small_pass2_kernel<DT, 1, false>), dim3(ng), dim3(256), small_lds2(DT), s, a);
+    else if (a.D <= 16) hipLaunchKernelGGL((small_pass2_kernel<DT, 16, false>), dim3(ng), dim3(256), small_lds2(DT), s, a);
+    else hipLaunchKernelGGL((small_pass2_kernel<DT, 64, false>), dim3(ng), dim3(256), small_lds2(DT), s, a);
   });
   const int nout = TILE * TILE + col_rows * a.mp + a.D * a.d + 8;
-  hipLaunchKernelGGL(small_reduce2_kernel, dim3((nout + 255) / 256), dim3(256), 0, s, a.part, ng, a.mp, a.d, a.D, col_rows,
-                     tile, colblk, proj, tail);
+  hipLaunchKernelGGL(small_reduce2_kernel, dim3((nout + 255) / 256), dim3(256), 0, s, a.part, ng, a.mp, a.d, a.D, ms ? 1 : 0,
+                     col_rows, tile, colblk, proj, tail);
   GPR_HIP(hipGetLastError());
 }
 
@@ -726,7 +839,13 @@ void launch_small_finish(const SmallFinishArgs& a, hipStream_t s) {
   small_attrs();
   small_dispatch(a.d, [&](auto dt) {
     constexpr int DT = decltype(dt)::value;
-    hipLaunchKernelGGL((small_finish_kernel<DT>), dim3(1), dim3(256), small_lds3(DT), s, a);
+    if constexpr (DT <= 8) {
+      if (a.ms) {
+        hipLaunchKernelGGL((small_finish_kernel<DT, true>), dim3(1), dim3(256), small_lds3(DT, true), s, a);
+        return;
+      }
+    }
+    hipLaunchKernelGGL((small_finish_kernel<DT, false>), dim3(1), dim3(256), small_lds3(DT), s, a);
   });
   GPR_HIP(hipGetLastError());
 }

@@ -53,10 +53,10 @@ def _eval_golden(p, g, **kw):
 
 
 def _small_path_applies(g):
-    """gpr_amd/csrc/small.hip: one-kernel row passes for m <= 64, d <= 16, D <= 64, no multiscales."""
+    """gpr_amd/csrc/small.hip: one-kernel row passes for m <= 64, d <= 16 (8 with multiscales), D <= 64."""
     d, m = g["Z"].shape
     D = g["X"].shape[0]
-    return m <= 64 and d <= 16 and D <= 64 and "log_multiscales" not in g
+    return m <= 64 and d <= (8 if "log_multiscales" in g else 16) and D <= 64
 
 
 def _golden_cases(names):
@@ -1511,9 +1511,10 @@ def test_random_shapes_against_oracle(seed):
 @pytest.mark.gpu
 @pytest.mark.parametrize("seed", range(3000, 3024))
 def test_random_small_shapes_against_oracle(seed):
-    """The same sweep over the shapes the one-kernel row passes take (gpr_amd/csrc/small.hip: m <= 64, d, D <= 16, one
-    chunk; multiscale cases fall back to the engine and say so), 1..64 inducing points and 1..4000 training points,
-    followed by a sigma2-only re-evaluation (reuse_v) on the state the small path left."""
+    """The same sweep over the shapes the one-kernel passes take (gpr_amd/csrc/small.hip: m <= 64, d <= 16, D <= 64;
+    multiscale cases with more than 8 point dimensions fall back to the engine and say so): 1..64 inducing points and
+    1..4000 training points, every kernel option, followed by a sigma2-only re-evaluation (reuse_v) on the state the
+    small path left."""
     _random_shape_case(seed, small=True)
 
 
@@ -1673,7 +1674,7 @@ def _random_shape_case(seed, shards=0, small=False):
     ev = p.eval(sigma2=sigma2, inducing=Z, variational=variational, **args)
     if small and not shards:
         took_small = "p1_small" in p.last_timings()
-        assert took_small == ("log_multiscales_m05" not in args), (took_small, sorted(args))
+        assert took_small == ("log_multiscales_m05" not in args or d <= 8), (took_small, d, sorted(args))
         p.set_timing(0)
         # Model.update_sigma2 after a small-path evaluation: V and r of the small pass are reused by the engine's pass 1
         ref2 = O.evaluate(k, Z, X, y, 2.0 * sigma2, variational=variational)
