@@ -131,6 +131,9 @@ struct gprhip_problem {
   double* zshift = nullptr;  // [64] centroid of the inducing points (gradient kernel's expansion offset)
   double *rp1 = nullptr, *rp2 = nullptr;  // per-row partial sums from the GEMM epilogues [parts*mp/128][chunk]
   double *xt = nullptr, *pt = nullptr, *prow = nullptr;  // prediction: test-point chunk, its projection, 3 row vectors
+  int64_t xt_rows = 0;                                   // rows they hold
+  void *predA = nullptr, *predB = nullptr;               // prediction chunk buffers beyond the training chunk (do_predict)
+  int64_t pred_rows = 0;
   bool have_model = false;
   bool have_factors = false;  // U^-1 / R~^-1 valid (false after a means-only gprhip_load_predictor)
   bool have_v = false;        // Vstore / r hold V = K_nm U^-1 of the current kernel and inducing points (reuse_v)
@@ -1173,14 +1176,29 @@ void do_predict(gprhip_problem* p, const double* test_inputs, int64_t ld, int64_
   GPR_HIP(hipSetDevice(p->device));
   hipStream_t s = p->stream;
   const int mp = p->mp;
-  const int64_t chunk = p->chunk;
-  if (!p->xt) {
+  // Test points go through in chunks of their own: the training chunk (at most the training set, padded) when that is
+  // enough, else up to 131072 rows in buffers kept for later calls -- a model trained on 2000 points predicts 100 000
+  // test points in one pass instead of 49 (5.4 -> 0.7 ms), each of which ends in a stream synchronisation.
+  int64_t chunk = p->chunk;
+  const int64_t want = std::min<int64_t>(131072, round_up(nt, TILE));
+  if (want > chunk) {
+    if (p->pred_rows < want) {
+      const int64_t rows = std::min<int64_t>(131072, std::max(want, 8 * chunk));
+      p->predA = p->alloc<char>(rows * mp * p->esz);
+      p->predB = p->alloc<char>(rows * mp * p->esz);
+      p->xt = nullptr;  // (the row buffers follow)
+      p->pred_rows = rows;
+    }
+    chunk = p->pred_rows;
+  }
+  if (!p->xt || p->xt_rows < chunk) {
     p->xt = p->alloc<double>(chunk * p->D);
     p->pt = p->alloc<double>(chunk * p->d);
     p->prow = p->alloc<double>(3 * chunk);
+    p->xt_rows = chunk;
   }
-  TS* const bufA = static_cast<TS*>(p->bufA);
-  TS* const bufB = static_cast<TS*>(p->bufB);
+  TS* const bufA = static_cast<TS*>(chunk > p->chunk ? p->predA : p->bufA);
+  TS* const bufB = static_cast<TS*>(chunk > p->chunk ? p->predB : p->bufB);
   double* rmean = p->prow;
   double* rk = p->prow + chunk;
   double* rb = p->prow + 2 * chunk;

@@ -330,6 +330,45 @@ def test_prediction_means_and_variances():
     GP.close()
 
 
+@pytest.mark.parametrize("kind,n,m,d,nt", [("iso", 700, 30, 2, 20000), ("fat", 1500, 140, 3, 150000), ("iso", 300, 10, 1, 300000)])
+def test_prediction_of_far_more_test_points_than_training_points(kind, n, m, d, nt):
+    """A model trained on few points predicts many: the test points pass through chunks of their own (up to 131 072 rows,
+    in buffers kept by the problem), not through the training chunk.  Means and variances against the oracle on a sample,
+    against the chunk-by-chunk path (which a small second call still takes) on all of them."""
+    rng = np.random.default_rng(n + nt)
+    D = d + (2 if kind == "fat" else 0)
+    X = np.asfortranarray(rng.normal(size=(D, n)))
+    y = np.sin(X.sum(0)) + 0.1 * rng.normal(size=n)
+    Xt = np.asfortranarray(rng.normal(size=(D, nt)))
+    if kind == "iso":
+        Z = np.asfortranarray(X[:, rng.permutation(n)[:m]] + 0.01 * rng.normal(size=(d, m)))
+        k = O.SeIsoKernel(0.3, 0.1)
+        args = dict(log_ell=0.3, log_sf2=0.1)
+        p = gpr_amd.Problem(gpr_amd.COV_SE_ISO, n, d, d, m)
+    else:
+        P = np.asfortranarray(rng.normal(size=(D, d)) / np.sqrt(D * d))
+        Z = np.asfortranarray((P.T @ X)[:, rng.permutation(n)[:m]] + 0.01 * rng.normal(size=(d, m)))
+        k = O.SeFatKernel(d, 0.1, P, None, None)
+        args = dict(log_sf2=0.1, tproj=P)
+        p = gpr_amd.Problem(gpr_amd.COV_SE_FAT, n, D, d, m)
+    ref = O.evaluate(k, Z, X, y, 0.2, want_grad=False, keep=True)
+    p.set_inputs(X)
+    p.set_targets(y)
+    p.eval(sigma2=0.2, inducing=Z, want_grad=False, **args)
+    mean, var = p.predict(Xt, predictive=False)
+    sample = rng.permutation(nt)[:3000]
+    Xs = np.asfortranarray(Xt[:, sample])
+    assert relinf(mean[sample], O.predict_means(k, Z, ref["coeffs"], Xs)) <= 1e-8
+    vref = O.predict_variances(k, Z, ref["model"], Xs, predictive=False)
+    assert np.max(np.abs(var[sample] - vref)) <= 1e-8 * np.max(np.abs(vref))
+    # the same points in pieces no larger than the training chunk
+    step = 256
+    for lo in range(0, min(nt, 4096), step):
+        mp_, vp_ = p.predict(np.asfortranarray(Xt[:, lo:lo + step]), predictive=False)
+        assert np.array_equal(mp_, mean[lo:lo + step]) and np.array_equal(vp_, var[lo:lo + step])
+    p.close()
+
+
 def test_save_data_recipe_training_improves_evidence_and_fits_noise():
     """test/save_data.ml + test/gen_data.ml:23-44 recipe: 1-D f(x) = sin(3x)/x + |x-3|/(x^2+1), noise
     sigma 0.7, n=1000, m=10, Cov_se_iso FITC; evidence maximisation must raise the log evidence and the
