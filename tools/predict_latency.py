@@ -1,3 +1,6 @@
+"""Wall time of gprhip_predict (means only / means + variances) and of the training statistics for few-inducing-point
+models: few and many test points, from a small and from a large training set.
+    usage (GPU box, repo root): python3 tools/predict_latency.py"""
 import sys, time, numpy as np
 sys.path.insert(0, '.')
 import gpr_amd
