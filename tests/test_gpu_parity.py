@@ -1045,6 +1045,20 @@ def _run_mirror_check(tmp_path, g, Xt, variational):
     return res
 
 
+def test_c_abi_from_a_plain_c_program():
+    """tests/cpp/eval_latency.c (C99, the header included as C) creates a problem, evaluates with and without the
+    gradient and destroys it: both entry forms return the same evidence, and no Python is involved."""
+    import re
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpr_amd", "_build", "eval_latency")
+    if not os.path.exists(exe):
+        pytest.fail("gpr_amd/_build/eval_latency missing: run __graft_entry__.build()")
+    out = subprocess.run([exe, "1500", "40", "2", "6"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    ls = [float(v) for v in re.findall(r"l = (-?[0-9.]+)", out.stdout)]
+    assert len(ls) == 2 and abs(ls[0] - ls[1]) <= 1e-6 * abs(ls[0]), out.stdout
+
+
 @pytest.mark.parametrize("name", ["iso_c1_var", "posterior_fat_all"])
 def test_cpp_host_mirror(tmp_path, name):
     """include/gprhip.hpp -- the C++ mirror of Fitc_gp.Make_deriv(Spec).{FITC, Variational_FITC, FIC,
