@@ -1203,6 +1203,7 @@ void do_predict(gprhip_problem* p, const double* test_inputs, int64_t ld, int64_
   double* rk = p->prow + chunk;
   double* rb = p->prow + 2 * chunk;
   const bool proj = p->has_proj();
+  const bool small = p->small_path && !p->f32 && p->m <= 64 && mp == TILE && p->d <= 16 && !p->has_ms();
   for (int64_t lo = 0; lo < nt; lo += chunk) {
     const int rows = (int)std::min<int64_t>(chunk, nt - lo);
     const int rows_p = (int)round_up(rows, TILE);
@@ -1213,6 +1214,17 @@ void do_predict(gprhip_problem* p, const double* test_inputs, int64_t ld, int64_
     if (proj) {
       launch_project(p->xt, rows, p->D, p->d, p->tproj, p->pt, s);
       pts = p->pt;
+    }
+    if (small) {  // few inducing points: the whole chunk in one kernel (small.hip)
+      SmallPredictArgs a;
+      a.cp = p->cp; a.pts = pts; a.Z = p->Z; a.uinv = p->uinv; a.rinv = p->rinv; a.tvec = p->tvec;
+      a.rows = rows; a.m = p->m; a.mp = mp; a.d = p->d; a.add = predictive ? p->h.sigma2 : 0.0;
+      a.means = means ? rmean : nullptr; a.vars = variances ? rk : nullptr;
+      launch_small_predict(a, s);
+      if (means) GPR_HIP(hipMemcpyAsync(means + lo, rmean, (size_t)rows * sizeof(double), hipMemcpyDeviceToHost, s));
+      if (variances) GPR_HIP(hipMemcpyAsync(variances + lo, rk, (size_t)rows * sizeof(double), hipMemcpyDeviceToHost, s));
+      GPR_HIP(hipStreamSynchronize(s));
+      continue;
     }
     launch_cov_cross<TS>(p->cp, pts, rows, rows_p, p->Z, p->m, mp, p->d, bufA, s);
     if (means) {

@@ -261,5 +261,14 @@ struct SmallFinishArgs {
   double* ex;
 };
 void launch_small_finish(const SmallFinishArgs& a, hipStream_t s);
+// means and / or variances of a chunk of test points in one kernel (same limits, no multiscales)
+struct SmallPredictArgs {
+  CovParams cp;
+  const double *pts, *Z, *uinv, *rinv, *tvec;  // test points [rows][d] (projected), inducing points, U^-1, R~^-1, t
+  int rows, m, mp, d;
+  double add;                                  // sigma2 for predictive variances, else 0
+  double *means, *vars;                        // out [rows]; either may be null
+};
+void launch_small_predict(const SmallPredictArgs& a, hipStream_t s);
 
 }  // namespace gprhip

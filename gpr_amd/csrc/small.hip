@@ -745,6 +745,89 @@ __global__ __launch_bounds__(256) void small_finish_kernel(SmallFinishArgs a) {
   if (a.wdiag && tid < SM) a.wdiag[tid] = Wt[tid * SLD + tid];
 }
 
+// Means.calc / Variances.calc (lib/fitc_gp.ml:418-425, :498-518) for a block of 64 test points in one kernel: K tile,
+// mean = K t, V = K U^-1, Q = V R~^-1, var = (sf2 - (|V_i|^2 - |Q_i|^2)) + add -- what do_predict otherwise does with seven
+// launches per chunk (covariance, two triangular products, three row kernels, the combination).
+template <int DT>
+__global__ __launch_bounds__(256) void small_predict_kernel(SmallPredictArgs a) {
+  extern __shared__ __attribute__((aligned(16))) double small_lds[];
+  double* const Ui = small_lds;         // [SM][SLD]
+  double* const Ri = Ui + SM * SLD;     // [SM][SLD]
+  double* const Kt = Ri + SM * SLD;     // [SRB][SLD] K, then V in place
+  double* const xs = Kt + SRB * SLD;    // [SRB][DT]
+  double* const tv = xs + SRB * DT;     // [SM] mean coefficients
+  double* const rk = tv + SM;           // [SRB] |V_i|^2
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l15 = lane & 15, lq = lane >> 4;
+  const ExpK ek = exp_consts();
+  if (a.vars) {
+    load_corner(a.uinv, a.mp, Ui, tid);
+    load_corner(a.rinv, a.mp, Ri, tid);
+  }
+  if (tid < SM) tv[tid] = tid < a.m ? a.tvec[tid] : 0.0;
+  const int col = lane, rg = wv;
+  const bool live_c = col < a.m;
+  double z[DT];
+#pragma unroll
+  for (int k = 0; k < DT; ++k) z[k] = (k < a.d && live_c) ? a.Z[(int64_t)col * a.d + k] : 0.0;
+  const int r0 = blockIdx.x * SRB;
+  for (int idx = tid; idx < SRB * DT; idx += 256) {
+    const int r = idx / DT, k = idx % DT;
+    xs[idx] = (k < a.d && r0 + r < a.rows) ? a.pts[(int64_t)(r0 + r) * a.d + k] : 0.0;
+  }
+  __syncthreads();
+#pragma unroll 4
+  for (int i = 0; i < 16; ++i) {
+    const int r = rg * 16 + i;
+    double acc = 0.0;
+#pragma unroll
+    for (int k = 0; k < DT; ++k) {
+      if (k < a.d) {
+        const double diff = xs[r * DT + k] - z[k];
+        acc = acc + diff * diff;
+      }
+    }
+    Kt[r * SLD + col] = (r0 + r < a.rows && live_c) ? exp_fast(a.cp.log_sf2 + a.cp.inv_ell2_05 * acc, ek) : 0.0;
+  }
+  __syncthreads();
+  if (a.means) {  // four threads per row, sixteen columns each
+    const int row = tid >> 2, part = tid & 3;
+    double sum = 0.0;
+#pragma unroll
+    for (int c = 16 * part; c < 16 * part + 16; ++c) sum += Kt[row * SLD + c] * tv[c];
+    sum += __shfl_xor(sum, 1);
+    sum += __shfl_xor(sum, 2);
+    if (part == 0 && r0 + row < a.rows) a.means[r0 + row] = sum;
+  }
+  if (!a.vars) return;
+  __syncthreads();  // (the mean phase read rows of other wavefronts)
+  sd4 acc[4];
+  rows_times<false>(Kt, Ui, wv, l15, lq, acc);  // V = K U^-1
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    double s2 = 0.0;
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) s2 += acc[ct][r] * acc[ct][r];
+    s2 = sum16(s2);
+    const int row = 16 * wv + lq + 4 * r;
+    if (l15 == 0) rk[row] = s2;
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) Kt[row * SLD + 16 * ct + l15] = acc[ct][r];  // rows of this wavefront: in place
+  }
+  rows_times<false>(Kt, Ri, wv, l15, lq, acc);  // Q = V R~^-1
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    double s2 = 0.0;
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) s2 += acc[ct][r] * acc[ct][r];
+    s2 = sum16(s2);
+    const int row = 16 * wv + lq + 4 * r;
+    // prior_variance -. (k -. b), lib/fitc_gp.ml:475 (as variance_combine_kernel)
+    if (l15 == 0 && r0 + row < a.rows) a.vars[r0 + row] = (a.cp.sf2 - (rk[row] - s2)) + a.add;
+  }
+}
+
+static size_t small_lds4(int DT) { return (size_t)(3 * SM * SLD + SRB * DT + SM + SRB) * sizeof(double); }
+
 static size_t small_lds1(int DT) { return (size_t)(2 * SM * SLD + SRB * DT + 3 * SRB) * sizeof(double); }
 static size_t small_lds3(int DT, bool ms = false) {
   return (size_t)(4 * SM * SLD + SM * DT + SM + 4 * SM + (ms ? SM * DT : 0)) * sizeof(double);
@@ -776,6 +859,9 @@ static void small_attrs() {
     GPRHIP_SMALL_SET(8)
     GPRHIP_SMALL_SET(16)
 #undef GPRHIP_SMALL_SET
+    set(reinterpret_cast<const void*>(&small_predict_kernel<4>), small_lds4(4));
+    set(reinterpret_cast<const void*>(&small_predict_kernel<8>), small_lds4(8));
+    set(reinterpret_cast<const void*>(&small_predict_kernel<16>), small_lds4(16));
 #define GPRHIP_SMALL_SET_MS(DT)                                                                                \
   set(reinterpret_cast<const void*>(&small_pass1_kernel<DT, true>), small_lds1(DT));                           \
   set(reinterpret_cast<const void*>(&small_pass2_kernel<DT, 1, true>), small_lds2(DT, true));                  \
@@ -832,6 +918,15 @@ void launch_small_pass2(const SmallPass2Args& a, int col_rows, double* tile, dou
   const int nout = TILE * TILE + col_rows * a.mp + a.D * a.d + 8;
   hipLaunchKernelGGL(small_reduce2_kernel, dim3((nout + 255) / 256), dim3(256), 0, s, a.part, ng, a.mp, a.d, a.D, ms ? 1 : 0,
                      col_rows, tile, colblk, proj, tail);
+  GPR_HIP(hipGetLastError());
+}
+
+void launch_small_predict(const SmallPredictArgs& a, hipStream_t s) {
+  small_attrs();
+  small_dispatch(a.d, [&](auto dt) {
+    constexpr int DT = decltype(dt)::value;
+    hipLaunchKernelGGL((small_predict_kernel<DT>), dim3((a.rows + SRB - 1) / SRB), dim3(256), small_lds4(DT), s, a);
+  });
   GPR_HIP(hipGetLastError());
 }
 
