@@ -174,12 +174,10 @@ __global__ __launch_bounds__(256) void small_pass1_kernel(SmallPass1Args a) {
       const int r = rg * 16 + i;
       double acc = 0.0;
 #pragma unroll
-      for (int k = 0; k < DT; ++k) {
-        if (k < a.d) {
-          const double diff = xs[r * DT + k] - z[k];
-          if constexpr (MS) acc = (acc + diff * (diff / sc[k])) + lsc[k];
-          else acc = acc + diff * diff;
-        }
+      for (int k = 0; k < DT; ++k) {  // (dimensions beyond d are zero on both sides, scale 1: they add exactly 0)
+        const double diff = xs[r * DT + k] - z[k];
+        if constexpr (MS) acc = (acc + diff * (diff / sc[k])) + lsc[k];
+        else acc = acc + diff * diff;
       }
       Kt[r * SLD + col] = (r0 + r < a.rows && live_c) ? exp_fast(a.cp.log_sf2 + a.cp.inv_ell2_05 * acc, ek) : 0.0;
     }
@@ -444,11 +442,9 @@ __global__ __launch_bounds__(256) void small_pass2_kernel(SmallPass2Args a) {
       double dist = MS ? lsum : 0.0;
 #pragma unroll
       for (int k = 0; k < DT; ++k) {
-        if (k < d) {
-          const double diff = xs[r * DT + k] - z[k];
-          if constexpr (MS) dist += diff * diff * isc[k];
-          else dist = dist + diff * diff;
-        }
+        const double diff = xs[r * DT + k] - z[k];
+        if constexpr (MS) dist += diff * diff * isc[k];
+        else dist = dist + diff * diff;
       }
       const bool live = live_c && r0 + r < a.rows;
       const double e = live ? Qt[r * SLD + col] * exp_fast(a.cp.log_sf2 + a.cp.inv_ell2_05 * dist, ek) : 0.0;
@@ -781,10 +777,8 @@ __global__ __launch_bounds__(256) void small_predict_kernel(SmallPredictArgs a) 
     double acc = 0.0;
 #pragma unroll
     for (int k = 0; k < DT; ++k) {
-      if (k < a.d) {
-        const double diff = xs[r * DT + k] - z[k];
-        acc = acc + diff * diff;
-      }
+      const double diff = xs[r * DT + k] - z[k];
+      acc = acc + diff * diff;
     }
     Kt[r * SLD + col] = (r0 + r < a.rows && live_c) ? exp_fast(a.cp.log_sf2 + a.cp.inv_ell2_05 * acc, ek) : 0.0;
   }
