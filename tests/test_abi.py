@@ -75,6 +75,18 @@ def test_header_is_plain_c(tmp_path):
     assert out.returncode == 0, out.stderr
 
 
+def test_plain_c_host_program_compiles_and_links(tmp_path):
+    """tests/cpp/eval_latency.c -- a complete host in C99 (create, set inputs / targets, evaluate, destroy) -- compiles
+    with -pedantic -Werror against the header and links against the library (no device call here)."""
+    import subprocess
+    src = os.path.join(ROOT, "tests", "cpp", "eval_latency.c")
+    exe = tmp_path / "eval_latency"
+    out = subprocess.run(["gcc", "-std=c99", "-D_POSIX_C_SOURCE=199309L", "-Wall", "-Werror", "-pedantic", "-I",
+                          os.path.join(ROOT, "include"), src, "-L", os.path.join(ROOT, "gpr_amd"), "-lgprhip", "-lm",
+                          "-Wl,-rpath," + os.path.join(ROOT, "gpr_amd"), "-o", str(exe)], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+
+
 def test_ocaml_stub_sources_cover_the_abi():
     """bindings/gpr_hip_stubs.c (shipped uncompiled: no OCaml toolchain in the image) names only functions the header
     declares, binds every entry point a host needs, and fills every field of gprhip_hypers."""
