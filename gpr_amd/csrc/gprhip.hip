@@ -149,6 +149,8 @@ struct gprhip_problem {
   // GPRHIP_SMALL_PATH=0 (read at creation): never take the one-kernel passes for at most 64 inducing points (small.hip)
   int small_path = 1;
   double* small_part = nullptr;  // their per-workgroup partial sums (allocated at first use)
+  double* small_k = nullptr;     // K_nm [rows_p][64] of the small pass 1, read back by the small pass 2
+  bool small_k_valid = false;    // ... of the current kernel parameters and inducing points (as have_v)
   int w_as_ws = 1;            // GPRHIP_W_AS_WS=0 (read at creation): pass-2 SYRK through the plain weighted kernel (do_pass2)
   // GPRHIP_MERGED_X (read at creation): 0 = X~ and X = X~ U^-T as two launches, as in rounds 1-2 (A/B runs); 1 (default) =
   // the two-phase product for shards large enough to pay for R^-1; 2 = always (parity tests at small sizes)
@@ -599,7 +601,7 @@ void do_pass1(gprhip_problem* p, const gprhip_hypers* h, int want_grad, int64_t 
     throw HipFail{ST_STATE};
   }
   p->have_v = false;
-  if (!reuse) p->have_k = false;
+  if (!reuse) p->have_k = p->small_k_valid = false;
   // K_nm of the first chunk does not depend on U: it is built on the second stream while the (latency-bound, few-CU)
   // factorisation and inversion of K_m run -- 0.4 ms of every evaluation, which is what a chunk's builder takes.
   // (Not under the per-stage timer, whose events sit on the main stream.)
@@ -639,7 +641,10 @@ void do_pass1(gprhip_problem* p, const gprhip_hypers* h, int want_grad, int64_t 
       a.rows = (int)p->n; a.rows_p = (int)round_up(p->n, TILE); a.m = p->m; a.mp = mp; a.d = p->d;
       a.sigma2 = h->sigma2;
       a.V = Vstore; a.r = p->r; a.is = p->is; a.yis = p->yis; a.part = p->small_part;
+      if (!p->small_k && p->d <= 8 && !p->has_ms()) p->small_k = p->alloc<double>((int64_t)a.rows_p * 64);
+      a.Kout = (p->d <= 8 && !p->has_ms()) ? p->small_k : nullptr;
       launch_small_pass1(a, ar1, ar1_c, ar1_tail, s);
+      p->small_k_valid = a.Kout != nullptr;
       tstop(p);
       p->stage = 1;
       p->have_v = true;
@@ -773,6 +778,7 @@ void do_pass2(gprhip_problem* p, const double* ar1, double* ar2) {
       SmallPass2Args a;
       a.cp = p->cp; a.pts = p->pts(); a.Z = p->Z; a.uinv = p->uinv; a.rinv = p->rinv; a.bvec = p->bvec; a.ttil = p->ttil;
       a.V = Vstore; a.y = mo ? nullptr : p->y; a.is = p->is; a.r = p->r;
+      a.Kin = (p->small_k_valid && p->d <= 8 && !p->has_ms()) ? p->small_k : nullptr;
       a.big = proj ? p->X : nullptr; a.D = proj ? p->D : 0;
       a.rows = (int)p->n; a.rows_p = (int)round_up(p->n, TILE); a.m = p->m; a.mp = mp; a.d = p->d;
       a.variational = p->h.variational;

@@ -230,11 +230,13 @@ struct SmallPass1Args {
   int rows, rows_p, m, mp, d;
   double sigma2;
   double *V, *r, *is, *yis;          // out: V [rows_p][mp] (padding zero), r / is / yis [rows_p]
+  double* Kout;                      // out (or null): K_nm [rows_p][64] for pass 2
   double* part;                      // scratch, small_part_len doubles
 };
 struct SmallPass2Args {
   CovParams cp;
   const double *pts, *Z, *uinv, *rinv, *bvec, *ttil, *V, *y, *is, *r;
+  const double* Kin;                 // K_nm [rows_p][64] as pass 1 left it, or null: recomputed (always for d > 8, multiscales)
   const double* big;                 // original inputs [rows][D] (Cov_se_fat with tproj) or null
   int D, rows, rows_p, m, mp, d, variational;
   double *w, *v, *es, *X;            // out: w, v [rows_p], es [rows_p] (or null), X [rows_p][mp] (columns < 64; or null)

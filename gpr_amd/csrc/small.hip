@@ -179,7 +179,9 @@ __global__ __launch_bounds__(256) void small_pass1_kernel(SmallPass1Args a) {
         if constexpr (MS) acc = (acc + diff * (diff / sc[k])) + lsc[k];
         else acc = acc + diff * diff;
       }
-      Kt[r * SLD + col] = (r0 + r < a.rows && live_c) ? exp_fast(a.cp.log_sf2 + a.cp.inv_ell2_05 * acc, ek) : 0.0;
+      const double kv = (r0 + r < a.rows && live_c) ? exp_fast(a.cp.log_sf2 + a.cp.inv_ell2_05 * acc, ek) : 0.0;
+      Kt[r * SLD + col] = kv;
+      if (a.Kout) a.Kout[(int64_t)(r0 + r) * SM + col] = kv;  // kept for pass 2 (E = X .* K without a second exp)
     }
     __syncthreads();
     sd4 acc[4];
@@ -272,7 +274,10 @@ __global__ __launch_bounds__(256) void small_reduce1_kernel(const double* __rest
 // MS (multiscales, d <= 8): K as grad_fused_ms_kernel forms it, the extra column sums of p_k^2 E (`Log_multiscale_m05,
 // lib/cov_se_fat.ml:598-622), and for the `Proj derivative one weight per (row, dimension), sum_c E_rc / ms_kc (:585-595),
 // formed from the E tile in LDS.  MS instantiations take the staged-inputs (WIDE) route for any D.
-template <int DT, int DBT, bool MS>
+// KR: K_nm of pass 1 is read back (a.Kin, [rows_p][64]: requested at the top of a block, parked in V's tile once V is done
+// with) instead of recomputed -- the sixteen exp per thread and block are a fifth of this kernel otherwise; instantiated
+// for d <= 8, D <= 16, no multiscales.
+template <int DT, int DBT, bool MS, bool KR = false>
 __global__ __launch_bounds__(256) void small_pass2_kernel(SmallPass2Args a) {
   extern __shared__ __attribute__((aligned(16))) double small_lds[];
   double* const Ui = small_lds;          // [SM][SLD]  U^-1
@@ -355,6 +360,11 @@ __global__ __launch_bounds__(256) void small_pass2_kernel(SmallPass2Args a) {
       xs[idx] = (k < d && r0 + r < a.rows) ? a.pts[(int64_t)(r0 + r) * d + k] : 0.0;
     }
     load_corner(a.V + (int64_t)r0 * a.mp, a.mp, Vt, tid);
+    double kreg[KR ? 16 : 1];  // this thread's K entries of the block (column, 16 rows): requested now, used in the E phase
+    if constexpr (KR) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) kreg[i] = a.Kin[(int64_t)(r0 + rg * 16 + i) * SM + col];
+    }
     if (tid < SRB) isr[tid] = a.is[r0 + tid];
     const bool rowlive = tid < SRB && r0 + tid < a.rows;  // the row phase below: one thread per row
     const double rreg = rowlive ? a.r[r0 + tid] : 0.0;
@@ -435,6 +445,11 @@ __global__ __launch_bounds__(256) void small_pass2_kernel(SmallPass2Args a) {
         Vt[r * SLD + k] = (k < D && r0 + r < a.rows) ? a.big[(int64_t)(r0 + r) * D + k] : 0.0;
       }
     }
+    if constexpr (KR) {  // V is done with: its tile takes the block's K (rows of this wavefront)
+      static_assert(!(KR && (DBT > 16 || MS)), "the staged-inputs variants need the tile themselves");
+#pragma unroll
+      for (int i = 0; i < 16; ++i) Vt[(rg * 16 + i) * SLD + col] = kreg[i];
+    }
     // E = X .* K of the block: column sums, moments against the points (and the original inputs), sum E, sum E |x - z|^2
 #pragma unroll 4
     for (int i = 0; i < 16; ++i) {
@@ -446,8 +461,10 @@ __global__ __launch_bounds__(256) void small_pass2_kernel(SmallPass2Args a) {
         if constexpr (MS) dist += diff * diff * isc[k];
         else dist = dist + diff * diff;
       }
-      const bool live = live_c && r0 + r < a.rows;
-      const double e = live ? Qt[r * SLD + col] * exp_fast(a.cp.log_sf2 + a.cp.inv_ell2_05 * dist, ek) : 0.0;
+      [[maybe_unused]] const bool live = live_c && r0 + r < a.rows;
+      double e;
+      if constexpr (KR) e = Qt[r * SLD + col] * Vt[r * SLD + col];  // (K is zero on padded rows and columns)
+      else e = live ? Qt[r * SLD + col] * exp_fast(a.cp.log_sf2 + a.cp.inv_ell2_05 * dist, ek) : 0.0;
 #pragma unroll
       for (int k = 0; k < DT; ++k) {
         gx[k] += xs[r * DT + k] * e;
@@ -848,6 +865,8 @@ static void small_attrs() {
   set(reinterpret_cast<const void*>(&small_pass2_kernel<DT, 1, false>), small_lds2(DT));                       \
   set(reinterpret_cast<const void*>(&small_pass2_kernel<DT, 16, false>), small_lds2(DT));                      \
   set(reinterpret_cast<const void*>(&small_pass2_kernel<DT, 64, false>), small_lds2(DT));                      \
+  set(reinterpret_cast<const void*>(&small_pass2_kernel<(DT > 8 ? 8 : DT), 1, false, true>), small_lds2(DT > 8 ? 8 : DT));  \
+  set(reinterpret_cast<const void*>(&small_pass2_kernel<(DT > 8 ? 8 : DT), 16, false, true>), small_lds2(DT > 8 ? 8 : DT)); \
   set(reinterpret_cast<const void*>(&small_finish_kernel<DT, false>), small_lds3(DT));
     GPRHIP_SMALL_SET(4)
     GPRHIP_SMALL_SET(8)
@@ -902,6 +921,13 @@ void launch_small_pass2(const SmallPass2Args& a, int col_rows, double* tile, dou
       if (ms) {
         if (a.D == 0) hipLaunchKernelGGL((small_pass2_kernel<DT, 1, true>), dim3(ng), dim3(256), small_lds2(DT, true), s, a);
         else hipLaunchKernelGGL((small_pass2_kernel<DT, 64, true>), dim3(ng), dim3(256), small_lds2(DT, true), s, a);
+        return;
+      }
+    }
+    if constexpr (DT <= 8) {
+      if (a.Kin && a.D <= 16) {
+        if (a.D == 0) hipLaunchKernelGGL((small_pass2_kernel<DT, 1, false, true>), dim3(ng), dim3(256), small_lds2(DT), s, a);
+        else hipLaunchKernelGGL((small_pass2_kernel<DT, 16, false, true>), dim3(ng), dim3(256), small_lds2(DT), s, a);
         return;
       }
     }
