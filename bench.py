@@ -2,14 +2,19 @@
 """FITC nLML + hyper-gradient throughput on MI355X (BASELINE.json metric).
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
+        ONE process for any N -- the reference's launch shape (bin/ocaml_gpr.ml is one process): with N > 1 the N devices
+        are reached through the C ABI's own multi-device entry, gprhip_ctx_create(devices[]) -> gprhip_sharded_eval
+        (row shards, one worker thread per device and the RCCL all-reduces inside libgprhip.so).
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
+        one process per GPU (RANK / WORLD_SIZE in the environment), the collective owned by torch.distributed (RCCL).
+Both launches run the same shards, exchange buffers and kernels and print the same line (`launch` says which).
 
 One "step" = one complete evaluation (log evidence l1+l2, dl/dsigma2 and dl/dtheta for all
 2 + d*m hypers) of cov_se_iso FITC at n=1,000,000, m=2048, d=8, fp64 (BASELINE.json configs[1]),
-with fresh theta and inducing points every step (as under an optimiser) and the training inputs
-already resident in HBM.  With N > 1 the n training points are row-sharded over the ranks
-(strong scaling of the same n) with two RCCL all-reduces per step.
+with fresh theta and inducing points every step (as under an optimiser; the K sets are drawn before the timed
+region) and the training inputs already resident in HBM.  With N > 1 the n training points are row-sharded over the
+devices (strong scaling of the same n) with two RCCL all-reduces per step.
 Rank 0 prints ONE JSON line.
 
 The timed region carries one HIP-event pair per step (around the dominant kernel, on the library's own stream);
@@ -193,11 +198,14 @@ def other_configs(gpr_amd, steps=3):
     del X, y, Z
     n, m, d = 1_000_000, 4096, 16
     X, y, Z = synth(4, n, m, d)
-    p = gpr_amd.Problem(gpr_amd.COV_SE_ISO, n, d, d, m)
-    p.set_inputs(X)
-    p.set_targets(y)
-    measure("C4 shard: cov_se_iso FITC nLML+grad, one GPU's n=1000000 rows of n=8000000, m=4096 d=16, fp64",
-            p, dict(log_ell=0.5 * np.log(d), log_sf2=0.0, sigma2=0.1, inducing=Z), n, m, d, "f64")
+    # ("precision unspecified -> run fp64, also report fp32")
+    for prec, dtype in ((gpr_amd.F64, "f64"), (gpr_amd.F32_BULK, "f32")):
+        p = gpr_amd.Problem(gpr_amd.COV_SE_ISO, n, d, d, m, precision=prec)
+        p.set_inputs(X)
+        p.set_targets(y)
+        measure("C4 shard: cov_se_iso FITC nLML+grad, one GPU's n=1000000 rows of n=8000000, m=4096 d=16, %s"
+                % ("fp64" if dtype == "f64" else "fp32 bulk (n x m contractions fp32, m x m work fp64)"),
+                p, dict(log_ell=0.5 * np.log(d), log_sf2=0.0, sigma2=0.1, inducing=Z), n, m, d, dtype)
     return out
 
 
@@ -224,6 +232,104 @@ def context_entry(gpr_amd, n, m, d, seed, steps=2):
     return out
 
 
+class _CtxRunner:
+    """The reference's own launch shape: ONE host process (bin/ocaml_gpr.ml:176-177, :340-342) that reaches all devices
+    through the C ABI's multi-device entry -- gprhip_ctx_create(devices[]) -> gprhip_sharded_create / _set_inputs /
+    _set_targets -> gprhip_sharded_eval: row shards, per-device worker threads and the two RCCL all-reduces live inside
+    libgprhip.so (gpr_amd/csrc/ctx.hip).  Same surface as gpr_amd.dist.ShardedProblem as far as this file uses it."""
+
+    launch = "single-process ctx"
+
+    def __init__(self, gpr_amd, devices, n, d, m):
+        self.ctx = gpr_amd.Context(devices)
+        self.sp = gpr_amd.ShardedDeviceProblem(self.ctx, gpr_amd.COV_SE_ISO, n, d, d, m)
+        self.local = self.sp.problem(0)      # shard 0's device problem: stage / kernel timings are read from it
+        self.devices = list(devices)
+        self.mode = {0: "none", 1: "rccl", 2: "same-device sum"}[self.ctx.comm_mode]
+        self.n_local = self.sp.shard(0)[2] - self.sp.shard(0)[1]
+
+    def set_data(self, X, y):
+        self.sp.set_inputs(X)
+        self.sp.set_targets(y)
+
+    def eval(self, **kw):
+        return self.sp.eval(**kw)
+
+    def comm_report(self, step, tim):
+        self.sp.set_timing(1)
+        ms = []
+        for _ in range(3):
+            step()
+            st = self.sp.comm_stats()
+            ms.append(st["ms"])
+        per_eval, nbytes = st["collectives"], st["bytes"]
+        step(want_grad=False)
+        ev_only = self.sp.comm_stats()["collectives"]
+        self.sp.set_timing(0)
+        return {"launch": self.launch, "mode": self.mode, "backend": "rccl (dlopen, in-library)" if self.mode == "rccl" else self.mode,
+                "devices": self.devices, "rccl_ranks": len(self.devices) if self.mode == "rccl" else 0,
+                "collectives_per_gradient_eval": per_eval, "collectives_per_evidence_eval": ev_only,
+                "allreduce_ms": [float(np.mean([a[i] for a in ms])) for i in range(2)],
+                "allreduce_bytes": [int(b) for b in nbytes],
+                "replicated_mxm_ms": _mxm_ms(tim)}
+
+    def close(self):
+        self.sp.close()
+        self.ctx.close()
+
+
+class _RankRunner:
+    """One process per GPU under torch.distributed.run (the launch the driver uses for N > 1): gpr_amd.dist.ShardedProblem
+    over the staged calls, the collective owned by torch.distributed (backend nccl = RCCL)."""
+
+    launch = "torchrun"
+
+    def __init__(self, gpr_amd, n, d, m, rank, world, device, backend, launched):
+        from gpr_amd.dist import ShardedProblem, shard_rows
+        self.lo, self.hi = shard_rows(n, rank, world)
+        self.sp = ShardedProblem(gpr_amd.COV_SE_ISO, n, d, d, m, rank=rank, world=world, device=device)
+        self.local = self.sp.local
+        self.n_local = self.hi - self.lo
+        self.world, self.backend, self.launched = world, backend, launched
+
+    def set_data(self, X, y):
+        self.sp.set_inputs(X[:, self.lo:self.hi])
+        self.sp.set_targets(y[self.lo:self.hi])
+
+    def eval(self, **kw):
+        return self.sp.eval(**kw)
+
+    def comm_report(self, step, tim):
+        if not self.launched:
+            return None
+        sp = self.sp
+        sp.timing = True
+        c0 = sp.collectives
+        step()
+        per_eval = sp.collectives - c0
+        ar = [list(sp.last_comm_ms)]
+        for _ in range(2):
+            step()
+            ar.append(list(sp.last_comm_ms))
+        sp.timing = False
+        c1 = sp.collectives
+        step(want_grad=False)
+        return {"launch": self.launch, "mode": "rccl" if self.backend == "nccl" else self.backend, "backend": self.backend,
+                "rccl_ranks": self.world if self.backend == "nccl" else 0,
+                "collectives_per_gradient_eval": per_eval, "collectives_per_evidence_eval": sp.collectives - c1,
+                "allreduce_ms": [float(np.mean([a[i] for a in ar if len(a) > i])) for i in range(len(ar[0]))],
+                "allreduce_bytes": [int(sp.ar1.numel() * 8), int(sp.ar2.numel() * 8)],
+                "replicated_mxm_ms": _mxm_ms(tim)}
+
+    def close(self):
+        self.sp.close()
+
+
+def _mxm_ms(tim):
+    """The m x m phases every shard repeats (the Amdahl term of the row split), from the per-stage pass."""
+    return float(sum(np.mean(tim.get(k_, [0.0])) for k_ in ("km_chol", "b_chol", "inverses", "finish")))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -235,31 +341,42 @@ def main():
     ap.add_argument("--dims", dest="d", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-configs", action="store_true", help="skip the C3 / C4-shard block")
-    # validation aids (tests/test_gpu_parity.py runs the N>1 code path on a 1-GPU box with them); the
-    # driver's runs use the defaults: RCCL, one device per rank
-    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"])
-    ap.add_argument("--share-device", action="store_true", help="all ranks use cuda:0 (testing only)")
+    # validation aids (tests/test_gpu_parity.py runs the N>1 code paths on a 1-GPU box with them); the driver's runs
+    # use the defaults: one device per shard, RCCL
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="torchrun launch only")
+    ap.add_argument("--share-device", action="store_true", help="torchrun launch: all ranks use cuda:0 (testing only)")
+    ap.add_argument("--same-device", action="store_true",
+                    help="single-process launch: the N shards all live on device 0 and the exchange is a device-local "
+                         "fixed-order sum (validation mode of gprhip_ctx_create; testing only)")
     args = ap.parse_args()
 
     os.environ.pop("GPRHIP_TIMING", None)
     import torch
-    import torch.distributed as dist
     import gpr_amd
-    from gpr_amd.dist import ShardedProblem, shard_rows
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)"
-                         % (args.gpus, world))
-    if gpr_amd.device_count() < 1:
+    # Two launches, one measurement:
+    #   python bench.py --gpus N                      ONE process, the C ABI's multi-device entry (the reference's shape)
+    #   python -m torch.distributed.run ... bench.py  one process per GPU (RANK / WORLD_SIZE in the environment)
+    launched = "RANK" in os.environ
+    world = int(os.environ.get("WORLD_SIZE", "1")) if launched else 1
+    rank = int(os.environ.get("RANK", "0")) if launched else 0
+    local_rank = int(os.environ.get("LOCAL_RANK", "0")) if launched else 0
+    if launched and world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d under torch.distributed.run" % (args.gpus, world))
+    visible = gpr_amd.device_count()
+    if visible < 1:
         raise SystemExit("bench.py: no HIP device; the HIP path has no CPU fallback")
-    if args.share_device:
-        local_rank = 0
-    torch.cuda.set_device(local_rank)
-    launched = "RANK" in os.environ  # under torch.distributed.run a process group exists even with one rank
+    single_process_multi = (not launched) and args.gpus > 1
+    if single_process_multi and not args.same_device and visible < args.gpus:
+        raise SystemExit("bench.py: --gpus %d but only %d HIP device(s) visible (--same-device runs the %d-way partition "
+                         "on one device for validation)" % (args.gpus, visible, args.gpus))
+    n_gpus = args.gpus
+    dist = None
     if launched:
+        import torch.distributed as dist
+        if args.share_device:
+            local_rank = 0
+        torch.cuda.set_device(local_rank)
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
@@ -268,10 +385,13 @@ def main():
 
     n, m, d, seed = args.n, args.m, args.d, 2
     X, y, Z0 = synth(seed, n, m, d)
-    lo, hi = shard_rows(n, rank, world)
-    sp = ShardedProblem(gpr_amd.COV_SE_ISO, n, d, d, m, rank=rank, world=world, device=local_rank)
-    sp.set_inputs(X[:, lo:hi])
-    sp.set_targets(y[lo:hi])
+    if single_process_multi:
+        devices = [0] * n_gpus if args.same_device else list(range(n_gpus))
+        sp = _CtxRunner(gpr_amd, devices, n, d, m)
+    else:
+        devices = [local_rank]
+        sp = _RankRunner(gpr_amd, n, d, m, rank, world, local_rank, args.backend, launched)
+    sp.set_data(X, y)
     del X, y
     rng = np.random.default_rng(1234)  # same stream on every rank: identical theta everywhere
     le0 = 0.5 * np.log(d)
@@ -284,14 +404,15 @@ def main():
     cursor = [0]
 
     def step(want_grad=True):
-        Z, le, lsf, s2 = thetas[cursor[0] % n_sets]
+        Z, le, lsf, s2 = thetas[cursor[0] % n_sets]  # (the untimed passes after the headline walk the same sets again)
         cursor[0] += 1
         return sp.eval(log_ell=le, log_sf2=lsf, sigma2=s2, inducing=Z, want_grad=want_grad)
 
     def barrier():
         if launched:
             dist.barrier()
-        torch.cuda.synchronize()
+        for dv in sorted(set(devices)):
+            torch.cuda.synchronize(dv)
 
     def max_over_ranks(x):
         if not launched or world == 1:
@@ -309,7 +430,7 @@ def main():
     kernel_ms, step_s = [], []
     for _ in range(args.steps):
         ts = time.perf_counter()
-        ev = step()  # returns after eval_finish has drained the library's stream: a step's wall time is well defined
+        ev = step()  # returns after eval_finish has drained the library's stream(s): a step's wall time is well defined
         step_s.append(time.perf_counter() - ts)
         kernel_ms.append(sp.local.last_timings().get("kernel_p1_syrk_B", 0.0))
     barrier()
@@ -333,26 +454,8 @@ def main():
     barrier()
     dt_nl = max_over_ranks(time.perf_counter() - t1)
     assert np.isfinite(ev0.l)
-    comm = None
-    if launched:
-        sp.timing = True
-        c0 = sp.collectives
-        step()
-        per_eval = sp.collectives - c0
-        ar = [list(sp.last_comm_ms)]
-        for _ in range(2):
-            step()
-            ar.append(list(sp.last_comm_ms))
-        sp.timing = False
-        c1 = sp.collectives
-        step(want_grad=False)
-        comm = {"backend": args.backend, "rccl_ranks": world if args.backend == "nccl" else 0,
-                "collectives_per_gradient_eval": per_eval, "collectives_per_evidence_eval": sp.collectives - c1,
-                "allreduce_ms": [float(np.mean([a[i] for a in ar if len(a) > i])) for i in range(len(ar[0]))],
-                "allreduce_bytes": [int(sp.ar1.numel() * 8), int(sp.ar2.numel() * 8)],
-                "replicated_mxm_ms": float(np.mean(tim.get("km_chol", [0.0])) + np.mean(tim.get("b_chol", [0.0]))
-                                           + np.mean(tim.get("inverses", [0.0])) + np.mean(tim.get("finish", [0.0])))}
-    n_local = hi - lo
+    comm = sp.comm_report(step, tim)
+    n_local = sp.n_local
     sp.close()
 
     line = None
@@ -360,6 +463,7 @@ def main():
         ms_per_step = dt / args.steps * 1e3
         value = n * args.steps / dt
         F = algorithmic_flops(n, m, d)
+        F0 = n * (2.0 * m * m + 2.0 * m * d) + 2.0 / 3.0 * m ** 3
         # dominant kernel by time per launch: gprhip::gemm_f64_tn_ws -- the SYRK-shaped accumulations over the shard's
         # training points: B~ = V^T diag(1/s) V in pass 1 and G~ = V^T diag(v) V in pass 2 (two launches of the same shape
         # per gradient evaluation since round 4, each n_local * m^2 algorithmic flops -- SURVEY 8(d): "SYRK B nm^2",
@@ -373,19 +477,24 @@ def main():
         engine_ms = sum(stage.get(k_, 0.0) for k_ in
                         ("p1_syrk_B", "p2_syrk_W", "p1_trmm_V", "p2_trmm_Q", "p2_trmm_S", "p2_trmm_X", "p2_trmm_SX"))
         cov_ms = stage.get("p1_cov")
-        traffic = profile_traffic(n_local, m) if (n, m, d, world) == (1_000_000, 2048, 8, 1) else None
+        traffic = profile_traffic(n_local, m) if (n, m, d, n_gpus) == (1_000_000, 2048, 8, 1) else None
         first = traffic["launches"][0] if traffic and traffic["launches"] else None
+
+        def short(k):
+            return "%dM" % (k // 1_000_000) if k % 1_000_000 == 0 else ("%dk" % (k // 1000) if k % 1000 == 0 else str(k))
         line = {
-            "metric": "FITC nLML+grad training-points/sec at n=1M m=2048 d=8",
-            "value": value, "unit": "training-points/s", "n_gpus": world, "steps": args.steps,
+            "metric": "FITC nLML+grad training-points/sec at n=%s m=%d d=%d" % (short(n), m, d),
+            "value": value, "unit": "training-points/s", "n_gpus": n_gpus, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
-            # BASELINE.md section 2 quotes the median evaluation: `value` stays the contract's K steps / wall time
-            # (host-side theta generation between steps included); the per-step spread is beside it
+            # BASELINE.md section 2 quotes the median evaluation: `value` stays the contract's K steps / wall time.  Since
+            # round 4 the K hyper-parameter sets are drawn BEFORE the timed region (rounds 1-3 drew them between the steps,
+            # inside it: ~1 ms per step at this size); the per-step spread is beside it
             "step_ms": {"median": step_med * 1e3, "min": float(np.min(step_s)) * 1e3, "max": float(np.max(step_s)) * 1e3,
                         "value_at_median": n / step_med},
             "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "launch": sp.launch if n_gpus > 1 or launched else "single process, one device",
             "config": {"workload": "cov_se_iso FITC nLML + full hyper-gradient, n=%d m=%d d=%d fp64 "
-                                   "(BASELINE.json configs[1]); n row-sharded over %d GPU(s)" % (n, m, d, world),
+                                   "(BASELINE.json configs[1]); n row-sharded over %d GPU(s)" % (n, m, d, n_gpus),
                        "n": n, "m": m, "d": d, "n_hypers": int(ev.grad.shape[0]) + 1},
             "roofline": {"bound": "mfma", "kernel": DOMINANT["f64"] + "  (OP_TN: weighted SYRK over training points + column sums on the diagonal tiles)",
                          "launches_per_step": 2,
@@ -395,9 +504,9 @@ def main():
                          "traffic_source": traffic,
                          "algorithmic_bytes_per_launch": float(n_local) * m * 8,
                          "avg_launch_ms": syrk_ms, "flops_per_launch": flops_per_launch},
-            "roofline_job": {"algorithmic_flops_per_step": F, "achieved": F / (dt / args.steps) * 1e-12 / world,
+            "roofline_job": {"algorithmic_flops_per_step": F, "achieved": F / (dt / args.steps) * 1e-12 / n_gpus,
                              "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s per GPU",
-                             "frac": F / (dt / args.steps) * 1e-12 / world / PEAK_FP64_MFMA_TFLOPS,
+                             "frac": F / (dt / args.steps) * 1e-12 / n_gpus / PEAK_FP64_MFMA_TFLOPS,
                              "mfma_engine_ms_per_step": engine_ms},
             # the K_nm builder: HBM-bound while the point dimension is small (d = 8: 2d+~30 flops per 8-byte element),
             # fp64-VALU/exp-bound from d >= 16; bytes written / its time
@@ -409,16 +518,22 @@ def main():
             "stage_ms": stage,
             "evidence_only": {"value": n * nl_steps / dt_nl, "unit": "training-points/s",
                               "ms_per_step": dt_nl / nl_steps * 1e3, "steps": nl_steps,
-                              "algorithmic_flops_per_step": n * (2.0 * m * m + 2.0 * m * d) + 2.0 / 3.0 * m ** 3},
+                              "algorithmic_flops_per_step": F0,
+                              "achieved": F0 / (dt_nl / nl_steps) * 1e-12 / n_gpus, "peak": PEAK_FP64_MFMA_TFLOPS,
+                              "unit_achieved": "TFLOP/s per GPU",
+                              "frac": F0 / (dt_nl / nl_steps) * 1e-12 / n_gpus / PEAK_FP64_MFMA_TFLOPS},
             "last_eval": {"l": float(ev.l), "dl_dsigma2": float(ev.dl_dsigma2),
                           "grad_norm": float(np.linalg.norm(ev.grad))},
         }
         if comm:
             line["multi_gpu"] = comm
-        if world == 1 and not args.no_configs:
+        if single_process_multi and args.same_device:
+            line["validation_only"] = ("--same-device: the %d shards share device 0, so every per-GPU figure of this line "
+                                       "is a sum over shards on one device, not a scaling measurement" % n_gpus)
+        if n_gpus == 1 and not args.no_configs:
             line["single_process_context"] = context_entry(gpr_amd, n, m, d, seed)
             line["configs"] = other_configs(gpr_amd)
-        if world == 1 and not args.no_cpu_baseline:
+        if n_gpus == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(m, d, seed)
         print(json.dumps(line))
     if launched:

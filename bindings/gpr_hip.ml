@@ -918,31 +918,72 @@ module Make_variant
         let test ?epsabs ?max_iter ?report t = make_test step gradient_norm ?epsabs ?max_iter ?report t
       end
 
-      (* Optim.SMD (lib/fitc_gp.ml:1828-2017): per-parameter gains eta adapted through the auxiliary vector nu, the
-         Hessian-vector product taken as a finite difference of gradients along nu (two more evaluations per step) *)
+      (* Optim.SMD (lib/fitc_gp.ml:1835-2017): stochastic meta-descent.  Per-parameter gains eta adapted through the
+         auxiliary vector nu; lambda * H nu is a CENTRAL difference of gradients along nu (:1952-1979: two more evaluations
+         per step, at +eps and -eps), the nu update uses the OLD gains (:1992), and the hyper update keeps the reference's
+         index convention as written (:1986-1990: [Vec.mul ~n:n_hypers eta ~ofsy:hyper_ix old_gradient] reads eta from its
+         first entry while the gradient is read past the sigma2 slot).  Defaults and argument checks: :1848-1900. *)
       module SMD = struct
         type t = { eps : float; lambda : float; mu : float; eta : vec; nu : vec; common : common }
 
-        let create ?(eps = 1e-8) ?(lambda = 0.99) ?(mu = 0.1) ?eta0 ?nu0 ?kernel ?sigma2 ?inducing ?n_rand_inducing
-            ?learn_sigma2 ?hypers ~inputs ~targets () =
+        let create ?(eps = 1e-8) ?lambda ?mu ?eta0 ?nu0 ?kernel ?sigma2 ?inducing ?n_rand_inducing ?learn_sigma2 ?hypers
+            ~inputs ~targets () =
+          let loc = "Gpr.Fitc_gp.Optim.SMD.create" in
+          let lambda =
+            match lambda with
+            | None -> 0.1
+            | Some l when l < 0. || l > 1. -> failwith (Printf.sprintf "%s: violating 0 <= lambda(%f) <= 1" loc l)
+            | Some l -> l
+          in
+          let mu =
+            match mu with
+            | None -> 1e-3
+            | Some mu when mu < 0. -> failwith (Printf.sprintf "%s: violating 0 <= mu(%f)" loc mu)
+            | Some mu -> mu
+          in
           let common = common_create ?kernel ?sigma2 ?inducing ?n_rand_inducing ?learn_sigma2 ?hypers ~inputs ~targets () in
           let n = Vec.dim common.params in
-          let eta = match eta0 with Some v -> copy v | None -> Vec.make n 0.1 in
-          let nu = match nu0 with Some v -> copy v | None -> Vec.make0 n in
+          let eta =
+            match eta0 with
+            | None -> Vec.make n 1e-3
+            | Some v ->
+                if Vec.dim v <> n then failwith (Printf.sprintf "%s: dim(eta0) = %d <> n_all_hypers(%d)" loc (Vec.dim v) n);
+                for i = 1 to n do
+                  if v.{i} <= 0. then failwith (Printf.sprintf "%s: eta0.{%d} < 0: %f" loc i v.{i})
+                done;
+                copy v
+          in
+          let nu =
+            match nu0 with
+            | None -> Vec.make n 1e-3
+            | Some v ->
+                if Vec.dim v <> n then failwith (Printf.sprintf "%s: dim(nu0) = %d <> n_all_hypers(%d)" loc (Vec.dim v) n);
+                copy v
+          in
           { eps; lambda; mu; eta; nu; common }
 
         let step t =
           let c = t.common in
           let n = Vec.dim c.params in
-          (* H nu ~ (grad(params + eps nu) - grad(params)) / eps *)
-          let shifted = copy c.params in
-          axpy ~alpha:t.eps t.nu shifted;
-          let hv = copy (common_move c shifted).gradient in
-          axpy ~alpha:(-1.) c.gradient hv;
-          scal (1. /. t.eps) hv;
-          let eta = Vec.init n (fun i -> t.eta.{i} *. max 0.5 (1. +. (t.mu *. t.nu.{i} *. c.gradient.{i}))) in
-          let nu = Vec.init n (fun i -> (t.lambda *. t.nu.{i}) +. (eta.{i} *. (c.gradient.{i} +. (t.lambda *. hv.{i})))) in
-          let params = Vec.init n (fun i -> c.params.{i} +. (eta.{i} *. c.gradient.{i})) in
+          let n_hypers = Array.length c.hypers in
+          let off = if c.learn_sigma2 then 1 else 0 in
+          let old_eta = t.eta and old_nu = t.nu and old_gradient = c.gradient in
+          (* lambda * H nu ~ lambda / (2 eps) * (grad(params + eps nu) - grad(params - eps nu));  params.{1} is
+             log sigma2 when it is learnt, so "exp (log_old_sigma2 +. eps *. old_nu.{1})" is the same shift *)
+          let grad_at eps =
+            let shifted = copy c.params in
+            axpy ~alpha:eps old_nu shifted;
+            copy (common_move c shifted).gradient
+          in
+          let lambda_hessian_nu = Vec.sub (grad_at t.eps) (grad_at (-.t.eps)) in
+          scal (t.lambda /. (2. *. t.eps)) lambda_hessian_nu;
+          let eta = Vec.init n (fun i -> old_eta.{i} *. Float.max 0.5 (1. +. (t.mu *. old_gradient.{i} *. old_nu.{i}))) in
+          let params = copy c.params in
+          if c.learn_sigma2 then params.{1} <- c.params.{1} +. (eta.{1} *. old_gradient.{1});
+          for i = 1 to n_hypers do
+            params.{off + i} <- c.params.{off + i} +. (eta.{i} *. old_gradient.{off + i})
+          done;
+          let nu = Vec.init n (fun i -> (old_eta.{i} *. (old_gradient.{i} +. lambda_hessian_nu.{i})) +. (t.lambda *. old_nu.{i})) in
           { t with eta; nu; common = common_move c params }
 
         let gradient_norm t = nrm2 t.common.gradient

@@ -551,6 +551,16 @@ def _run_bench(extra, nproc):
     common = ["--steps", "2", "--warmup", "1", "--points", "20011", "--inducing", "200", "--dims", "4", "--no-cpu-baseline", "--no-configs"]
     if nproc == 1 and not extra:
         cmd = [sys.executable, "bench.py", "--gpus", "1"] + common
+    elif "--same-device" in extra or "--expect-failure" in extra:  # ONE process, gprhip_ctx_create(devices[])
+        env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+        cmd = [sys.executable, "bench.py", "--gpus", str(nproc)] + common + [e for e in extra if e != "--expect-failure"]
+        out = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=600, env=env)
+        if "--expect-failure" in extra:
+            return out
+        assert out.returncode == 0, out.stderr[-2000:]
+        lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+        assert len(lines) == 1, out.stdout
+        return json.loads(lines[0])
     else:
         with socket.socket() as s:
             s.bind(("127.0.0.1", 0))
@@ -575,6 +585,33 @@ def test_bench_two_ranks_on_one_device_match_single_rank():
     for k in ("l", "dl_dsigma2", "grad_norm"):
         a, b = one["last_eval"][k], two["last_eval"][k]
         assert abs(a - b) <= TOL_SHARD * max(1.0, abs(a)), (k, a, b)
+
+
+def test_bench_single_process_eight_way_matches_one_gpu_and_torchrun():
+    """`python bench.py --gpus 8` with NO launcher: the reference's host is one process (bin/ocaml_gpr.ml:176-177,
+    :340-342), so the N-GPU bench goes through the C ABI's own multi-device entry (gprhip_ctx_create ->
+    gprhip_sharded_eval).  On the one GPU a test box has, --same-device puts the eight shards on device 0 (validation
+    mode: fixed-order device-local sum as the exchange).  Same seeded hyper-parameter stream in every launch, so the last
+    evaluation must agree with the one-GPU run and with the torchrun launch of the same partition."""
+    one = _run_bench([], 1)
+    ctx8 = _run_bench(["--same-device"], 8)
+    assert ctx8["n_gpus"] == 8 and ctx8["scaling"] == "strong" and ctx8["launch"] == "single-process ctx"
+    mg = ctx8["multi_gpu"]
+    assert mg["launch"] == "single-process ctx" and mg["mode"] == "same-device sum" and mg["devices"] == [0] * 8
+    assert mg["collectives_per_gradient_eval"] == 2 and mg["collectives_per_evidence_eval"] == 1
+    assert all(b > 0 for b in mg["allreduce_bytes"]) and mg["replicated_mxm_ms"] > 0.0
+    assert "n=20011 m=200 d=4" in ctx8["metric"]  # the metric string follows the arguments
+    assert 0.0 < ctx8["evidence_only"]["frac"] < 1.0
+    two = _run_bench(["--backend", "gloo", "--share-device"], 2)
+    assert two["launch"] == "torchrun" and two["multi_gpu"]["launch"] == "torchrun"
+    for other in (ctx8, two):
+        for k in ("l", "dl_dsigma2", "grad_norm"):
+            a, b = one["last_eval"][k], other["last_eval"][k]
+            assert abs(a - b) <= TOL_SHARD * max(1.0, abs(a)), (k, a, b)
+    # more devices asked for than the box has, without --same-device: a message naming both counts, non-zero exit
+    visible = gpr_amd.device_count()
+    out = _run_bench(["--expect-failure"], visible + 1)
+    assert out.returncode != 0 and "--gpus %d" % (visible + 1) in out.stderr and "%d HIP device" % visible in out.stderr
 
 
 def test_bench_under_torchrun_with_rccl_one_rank():
