@@ -14,6 +14,7 @@
 #include <condition_variable>
 #include <functional>
 #include <memory>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -164,6 +165,8 @@ struct gprhip_ctx {
   Rccl rccl;
   std::vector<rccl_comm_t> comms;
   std::vector<std::unique_ptr<Worker>> workers;
+  // lifetime bookkeeping, guarded by g_lifetime_mu: a garbage-collected host may finalise a sharded problem and its
+  // context on different threads (OCaml 5 domains), in either order
   int live_problems = 0;
   bool closed = false;  // gprhip_ctx_destroy was called while sharded problems were alive: the last of them frees the context
 };
@@ -184,6 +187,8 @@ struct gprhip_sharded {
 };
 
 namespace {
+
+std::mutex g_lifetime_mu;  // guards gprhip_ctx::live_problems / closed of every context
 
 template <typename F>
 int guarded(F&& f) {
@@ -335,9 +340,14 @@ static void ctx_free(gprhip_ctx* c) {
 // the two handles in either order) only marks it, and the last sharded problem frees it.
 void gprhip_ctx_destroy(gprhip_ctx* c) {
   if (!c) return;
-  if (c->live_problems > 0) {
+  {
+    std::lock_guard<std::mutex> g(g_lifetime_mu);
+    if (c->closed) return;  // (a second destroy of a context that is waiting for its problems)
+    if (c->live_problems > 0) {
+      c->closed = true;
+      return;
+    }
     c->closed = true;
-    return;
   }
   ctx_free(c);
 }
@@ -348,8 +358,26 @@ int gprhip_ctx_comm_mode(const gprhip_ctx* c) { return c ? c->mode : GPRHIP_COMM
 int gprhip_sharded_create(gprhip_ctx* c, int cov_kind, int precision, int64_t n, int D, int d, int m, int64_t chunk_rows,
                           gprhip_sharded** out) {
   return guarded([&] {
-    if (!c || !out || c->closed) fail(GPRHIP_EBADARG, "gprhip_sharded_create: NULL argument or destroyed context");
+    if (!c || !out) fail(GPRHIP_EBADARG, "gprhip_sharded_create: NULL argument");
     *out = nullptr;
+    {  // the problem counts as alive from here on, so that a concurrent gprhip_ctx_destroy cannot free the context under it
+      std::lock_guard<std::mutex> g(g_lifetime_mu);
+      if (c->closed) fail(GPRHIP_EBADARG, "gprhip_sharded_create: destroyed context");
+      ++c->live_problems;
+    }
+    struct Reserve {
+      gprhip_ctx* c;
+      bool keep = false;
+      ~Reserve() {
+        if (keep) return;
+        bool last;
+        {
+          std::lock_guard<std::mutex> g(g_lifetime_mu);
+          last = --c->live_problems == 0 && c->closed;
+        }
+        if (last) ctx_free(c);
+      }
+    } reserve{c};
     const int nd = (int)c->devices.size();
     if (n < nd) fail(GPRHIP_EBADARG, "gprhip_sharded_create: fewer training points than devices");
     std::unique_ptr<gprhip_sharded> sp(new gprhip_sharded());
@@ -389,7 +417,7 @@ int gprhip_sharded_create(gprhip_ctx* c, int cov_kind, int precision, int64_t n,
       destroy_parts();
       throw;
     }
-    ++c->live_problems;
+    reserve.keep = true;
     *out = sp.release();
   });
 }
@@ -407,7 +435,12 @@ void gprhip_sharded_destroy(gprhip_sharded* sp) {
   }
   gprhip_ctx* const c = sp->ctx;
   delete sp;
-  if (--c->live_problems == 0 && c->closed) ctx_free(c);
+  bool last;
+  {
+    std::lock_guard<std::mutex> g(g_lifetime_mu);
+    last = --c->live_problems == 0 && c->closed;
+  }
+  if (last) ctx_free(c);
 }
 
 int gprhip_sharded_shard(const gprhip_sharded* sp, int idx, int* device, int64_t* row_lo, int64_t* row_hi) {

@@ -13,6 +13,7 @@
 //                          fused gradient accumulators over E = X .* K_nm.
 // Exchange 2            :  sum over shards of (G~_part, gradient column accumulators, scalars).
 // Finish                :  W = U^-1 (I - B~^-1 - t~ t~^T - G~) U^-T;  traces;  dl/dsigma2, dl/dtheta.
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 #include <vector>
@@ -454,12 +455,16 @@ void upload_hypers(gprhip_problem* p, const gprhip_hypers* h) {
     set_error("gprhip: log_hetero_skedasticity given for Cov_se_iso");
     throw HipFail{ST_BAD_ARG};
   }
-  p->h = *h;
-  p->h.inducing = nullptr;  // borrowed; the padded copy lives in hZ
   if (h->log_multiscales_m05 && p->kind == GPRHIP_COV_SE_ISO) {
     set_error("gprhip: log_multiscales_m05 given for Cov_se_iso");
     throw HipFail{ST_BAD_ARG};
   }
+  p->h = *h;                // (after every argument check: a refused call leaves no borrowed pointer behind)
+  p->h.inducing = nullptr;  // borrowed; the padded copy lives in hZ
+  // the optional arrays are presence flags from here on, pointing at the library's own pinned copies (filled below)
+  p->h.tproj = h->tproj ? p->hTproj : nullptr;
+  p->h.log_hetero_skedasticity = h->log_hetero_skedasticity ? p->hHet : nullptr;
+  p->h.log_multiscales_m05 = h->log_multiscales_m05 ? p->hMs : nullptr;
   // the pinned block may still be the source of the previous evaluation's transfer (a pass 1 repeated without a finish)
   GPR_HIP(hipEventSynchronize(p->ev_hy));
   int64_t used = (int64_t)p->mp * p->d + 64;  // doubles of the block this evaluation uploads (a prefix)
@@ -1187,17 +1192,36 @@ void do_predict(gprhip_problem* p, const double* test_inputs, int64_t ld, int64_
   // test points in one pass instead of 49 (5.4 -> 0.7 ms), each of which ends in a stream synchronisation.
   int64_t chunk = p->chunk;
   const int64_t want = std::min<int64_t>(131072, round_up(nt, TILE));
+  const bool proj = p->has_proj();
+  // few inducing points: a chunk is one kernel (small.hip) that keeps its n x m tiles in LDS -- it needs the row buffers
+  // only, not the two chunk x mp matrices (268 MB at 131072 rows that a cached small model would pin for nothing)
+  const bool small = p->small_path && !p->f32 && p->m <= 64 && mp == TILE && p->d <= 16 && !p->has_ms();
+  auto release = [p](auto*& q) {  // a prediction buffer that is being regrown: freed now, not at problem destruction
+    if (!q) return;
+    auto it = std::find(p->allocs.begin(), p->allocs.end(), static_cast<void*>(q));
+    if (it != p->allocs.end()) p->allocs.erase(it);
+    (void)hipFree(q);
+    q = nullptr;
+  };
   if (want > chunk) {
-    if (p->pred_rows < want) {
-      const int64_t rows = std::min<int64_t>(131072, std::max(want, 8 * chunk));
+    const int64_t rows = std::min<int64_t>(131072, std::max(want, 8 * chunk));
+    if (!small && p->pred_rows < want) {
+      GPR_HIP(hipStreamSynchronize(s));
+      release(p->predA);
+      release(p->predB);
+      p->pred_rows = 0;
       p->predA = p->alloc<char>(rows * mp * p->esz);
       p->predB = p->alloc<char>(rows * mp * p->esz);
-      p->xt = nullptr;  // (the row buffers follow)
       p->pred_rows = rows;
     }
-    chunk = p->pred_rows;
+    chunk = small ? std::max(p->xt_rows >= want ? p->xt_rows : rows, p->chunk) : p->pred_rows;
   }
   if (!p->xt || p->xt_rows < chunk) {
+    GPR_HIP(hipStreamSynchronize(s));
+    release(p->xt);
+    release(p->pt);
+    release(p->prow);
+    p->xt_rows = 0;
     p->xt = p->alloc<double>(chunk * p->D);
     p->pt = p->alloc<double>(chunk * p->d);
     p->prow = p->alloc<double>(3 * chunk);
@@ -1208,8 +1232,6 @@ void do_predict(gprhip_problem* p, const double* test_inputs, int64_t ld, int64_
   double* rmean = p->prow;
   double* rk = p->prow + chunk;
   double* rb = p->prow + 2 * chunk;
-  const bool proj = p->has_proj();
-  const bool small = p->small_path && !p->f32 && p->m <= 64 && mp == TILE && p->d <= 16 && !p->has_ms();
   for (int64_t lo = 0; lo < nt; lo += chunk) {
     const int rows = (int)std::min<int64_t>(chunk, nt - lo);
     const int rows_p = (int)round_up(rows, TILE);
@@ -1293,24 +1315,50 @@ double condition_km(gprhip_problem* p) {
   double* y = x + mp;
   std::vector<double> h0(mp, 0.0);
   for (int i = 0; i < m; ++i) h0[i] = 1.0 + 0.5 * std::sin(1.0 + 0.37 * i);  // the padding (a decoupled identity block) stays 0
+  // Rounds of 16 steps until both Rayleigh quotients have settled (relative change < 1e-2 over a round; at most 16 rounds:
+  // lambda_max(A^-1) converges slowly when K_m + jitter has a cluster of small eigenvalues, and a fixed 16 steps could pass
+  // exactly the coefficients the fp32 guard exists to refuse).
+  double lam[2] = {0.0, 0.0};
   for (int which = 0; which < 2; ++which) {
     const double* F = which == 0 ? p->umat : p->uinv;
     GPR_HIP(hipMemcpyAsync(x, h0.data(), (size_t)mp * sizeof(double), hipMemcpyHostToDevice, s));
     hipLaunchKernelGGL(normalize_kernel, dim3(1), dim3(256), 0, s, x, mp, p->scal + SC_LMAX + which);
-    for (int it = 0; it < 16; ++it) {
-      if (which == 0) {  // x <- U^T (U x)
-        launch_triu_matvec(F, mp, x, y, 0, s);
-        launch_triu_matvec(F, mp, y, x, 1, s);
-      } else {           // x <- U^-1 (U^-T x)
-        launch_triu_matvec(F, mp, x, y, 1, s);
-        launch_triu_matvec(F, mp, y, x, 0, s);
+    double prev = 0.0;
+    for (int round = 0; round < 16; ++round) {
+      for (int it = 0; it < 16; ++it) {
+        if (which == 0) {  // x <- U^T (U x)
+          launch_triu_matvec(F, mp, x, y, 0, s);
+          launch_triu_matvec(F, mp, y, x, 1, s);
+        } else {           // x <- U^-1 (U^-T x)
+          launch_triu_matvec(F, mp, x, y, 1, s);
+          launch_triu_matvec(F, mp, y, x, 0, s);
+        }
+        hipLaunchKernelGGL(normalize_kernel, dim3(1), dim3(256), 0, s, x, mp, p->scal + SC_LMAX + which);
       }
-      hipLaunchKernelGGL(normalize_kernel, dim3(1), dim3(256), 0, s, x, mp, p->scal + SC_LMAX + which);
+      GPR_HIP(hipMemcpyAsync(&lam[which], p->scal + SC_LMAX + which, sizeof(double), hipMemcpyDeviceToHost, s));
+      GPR_HIP(hipStreamSynchronize(s));
+      if (round > 0 && std::fabs(lam[which] - prev) <= 1e-2 * std::fabs(lam[which])) break;
+      prev = lam[which];
     }
   }
-  double lam[2] = {0.0, 0.0};
-  GPR_HIP(hipMemcpyAsync(lam, p->scal + SC_LMAX, 2 * sizeof(double), hipMemcpyDeviceToHost, s));
-  GPR_HIP(hipStreamSynchronize(s));
+  // Cross-check from the factor itself: every squared pivot U_ii^2 lies inside the spectrum of A (it is the reciprocal of a
+  // diagonal entry of the inverse of a leading block, whose eigenvalues interlace A's), so max U_ii^2 / min U_ii^2 is a
+  // lower bound of cond(A) as well; the larger of the two estimates is reported.
+  {
+    hipLaunchKernelGGL(copy_diag_kernel, dim3((mp + 255) / 256), dim3(256), 0, s, p->umat, mp, y);
+    std::vector<double> dg(mp);
+    GPR_HIP(hipMemcpyAsync(dg.data(), y, (size_t)mp * sizeof(double), hipMemcpyDeviceToHost, s));
+    GPR_HIP(hipStreamSynchronize(s));
+    double dmax = 0.0, dmin = HUGE_VAL;
+    for (int i = 0; i < m; ++i) {
+      dmax = std::max(dmax, dg[i] * dg[i]);
+      dmin = std::min(dmin, dg[i] * dg[i]);
+    }
+    if (dmin > 0.0 && dmax / dmin > lam[0] * lam[1]) {
+      p->cond_km = dmax / dmin;
+      return p->cond_km;
+    }
+  }
   p->cond_km = lam[0] * lam[1];
   return p->cond_km;
 }

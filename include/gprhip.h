@@ -17,7 +17,9 @@
  *   - Host pointers are borrowed for the duration of the call only.
  *   - Every function returns 0 on success or a GPRHIP_E* code; gprhip_last_error() gives the
  *     message (thread-local).  No C++ exception crosses the boundary.
- *   - A context/problem must not be used from two host threads at once.
+ *   - A context/problem must not be used from two host threads at once.  The one exception is lifetime: the destroy
+ *     calls of a context and of its sharded problems may come from different threads in any order (finalisers of a
+ *     garbage-collected host on another domain); that bookkeeping is guarded inside the library.
  */
 #ifndef GPRHIP_H
 #define GPRHIP_H

@@ -184,3 +184,44 @@ def test_ocaml_module_defines_every_value_of_the_reference_signature():
             if not re.search(r"\blet (rec )?%s\b" % v, body):
                 missing.append("%s.%s" % (mod, v))
     assert not missing, missing
+
+
+def test_ocaml_stub_file_type_checks_against_the_header():
+    """bindings/gpr_hip_stubs.c has never met OCaml's own <caml/*.h> (no OCaml in the image), but everything a C
+    compiler can check without them IS checked: `gcc -std=c99 -Wall -Wextra -Werror -fsyntax-only` over the stub file
+    against include/gprhip.h (every call of a gprhip_* entry point: argument count and types) and against
+    tests/caml_standin/caml/*.h -- a declarations-only stand-in for the part of the documented OCaml C interface the
+    stubs use (value, CAMLparam*/CAMLlocal*/CAMLreturn, Caml_ba_array_val, caml_alloc_custom, ...), clearly labelled as
+    such, never linked or run."""
+    import subprocess
+    standin = os.path.join(ROOT, "tests", "caml_standin")
+    for h in os.listdir(os.path.join(standin, "caml")):
+        assert "STAND-IN, NOT OCaml's header" in open(os.path.join(standin, "caml", h)).read(), h
+    cmd = ["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-fsyntax-only", "-I", standin,
+           "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "bindings", "gpr_hip_stubs.c")]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr[-3000:]
+    # the check has teeth: a stub calling an entry point with one argument too few must be rejected
+    src = open(os.path.join(ROOT, "bindings", "gpr_hip_stubs.c")).read()
+    assert "gprhip_set_targets(Problem_val(prob), " in src
+    broken = src.replace("gprhip_set_targets(Problem_val(prob), ", "gprhip_set_targets(", 1)
+    out = subprocess.run(cmd[:-1] + ["-x", "c", "-"], input=broken, capture_output=True, text=True, timeout=120)
+    assert out.returncode != 0
+
+
+@pytest.mark.skipif(not os.path.exists("/root/reference/lib/fitc_gp.ml"),
+                    reason="the reference tree exists in the build container only")
+def test_ocaml_smd_step_is_the_references_update():
+    """bindings/gpr_hip.ml's Optim.SMD (uncompiled): the pieces of the reference's step that a drop-in must not change
+    silently (lib/fitc_gp.ml:1952-1995) are there -- a central difference (gradients at +eps and -eps, scaled by
+    lambda / (2 eps)), the nu update with the OLD gains, and the reference's defaults (lambda 0.1, mu 1e-3, eta0 = nu0 =
+    1e-3)."""
+    ref = open("/root/reference/lib/fitc_gp.ml").read()
+    assert "scal (lambda /. (2. *. eps)) res" in ref and "Vec.mul old_eta (Vec.add old_gradient lambda_hessian_nu)" in ref
+    ml = open(os.path.join(ROOT, "bindings", "gpr_hip.ml")).read()
+    smd = ml[ml.index("module SMD = struct"):]
+    smd = smd[:smd.index("let test ")]
+    assert "grad_at t.eps" in smd and "grad_at (-.t.eps)" in smd
+    assert "t.lambda /. (2. *. t.eps)" in smd
+    assert "old_eta.{i} *. (old_gradient.{i} +. lambda_hessian_nu.{i})" in smd and "t.lambda *. old_nu.{i}" in smd
+    assert "| None -> 0.1" in smd and "| None -> 1e-3" in smd and smd.count("Vec.make n 1e-3") == 2
