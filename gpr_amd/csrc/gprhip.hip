@@ -158,6 +158,11 @@ struct gprhip_problem {
   int merged_x_mode = 1;
   // GPRHIP_POTRF_ENGINE=1 (read at creation): the round-2 factorisation (engine launches per step) + recursive-doubling inverse
   bool engine_steps = false;
+  // GPRHIP_POTRF_CHAIN=1 (read at creation; default 0): factorisation + inverse of matrices of two or more 128-blocks as
+  // ONE persistent launch with device-side dependencies (chol.hip, potrf_upper_chain) instead of three launches per step.
+  // Built in round 5, bit-identical, and measured 1.4 - 2.8 x SLOWER than the launches: kept for A/B
+  int potrf_chain_mode = 0;
+  PotrfChain* chain = nullptr;  // its task list and flag words (created at the first factorisation)
   // n x m storage: double, or float in the fp32-bulk mode (element size `esz`)
   void *bufA = nullptr, *bufB = nullptr, *Vstore = nullptr;
   // Cov_se_fat with projection hypers: K_nm of all rows, kept from pass 1 for the gradient kernel of pass 2 (which then
@@ -411,6 +416,13 @@ void potrf_trtri(gprhip_problem* p, double* A, double* X, double* tmp, int* info
     potrf_upper(p, A, info);
     trtri_upper(p, A, X, tmp);
     return;
+  }
+  if (p->potrf_chain_mode && p->mp >= 2 * TILE) {
+    if (!p->chain) p->chain = potrf_chain_create(p->mp);
+    if (p->chain) {
+      potrf_upper_chain(p->stream, p->chain, A, p->mp, p->dinv, info, tmp, X, p->m);
+      return;
+    }
   }
   potrf_upper_blocked(p->stream, A, p->mp, p->dinv, info, tmp, X, p->m);
 }
@@ -1063,6 +1075,12 @@ void do_finish_collect(gprhip_problem* p, gprhip_result* res, double* grad, doub
   const double* const ha1tail = p->a1_in_scal ? hscal + SC_A1TAIL : p->ex_host;
   const double* const hcol = p->ex_host + A1_TAIL;  // column block + Proj second term + scalar tail of exchange 2
   const double* const htail = hcol + p->col_rows() * mp + (int64_t)p->dbig() * d;
+  if (hinfo[0] == POTRF_CHAIN_ABORT_CODE || hinfo[1] == POTRF_CHAIN_ABORT_CODE) {
+    p->have_v = p->have_k = false;
+    set_error("gprhip: internal error: a dependency wait of the one-launch factorisation ran into its bound "
+              "(GPRHIP_POTRF_CHAIN=0 selects the step-by-step launches)");
+    throw HipFail{ST_HIP_ERROR};
+  }
   if (hinfo[0] != 0 || hinfo[1] != 0) {
     p->have_v = p->have_k = false;  // V came out of a failed factor
     char buf[160];
@@ -1734,6 +1752,7 @@ int gprhip_problem_create_ex(int device, int cov_kind, int precision, int64_t n,
     if (const char* e = getenv("GPRHIP_F32_COEFF_TOL")) p->f32_coeff_tol = atof(e);
     if (const char* e = getenv("GPRHIP_MERGED_X")) p->merged_x_mode = atoi(e);
     if (const char* e = getenv("GPRHIP_POTRF_ENGINE")) p->engine_steps = atoi(e) != 0;
+    if (const char* e = getenv("GPRHIP_POTRF_CHAIN")) p->potrf_chain_mode = atoi(e);
     GPR_HIP(hipStreamCreate(&p->stream));
     GPR_HIP(hipStreamCreate(&p->stream2));
     GPR_HIP(hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming));
@@ -1839,6 +1858,7 @@ void gprhip_problem_destroy(gprhip_problem* p) {
     hipEventDestroy(p->timer.k1);
   }
   for (void* a : p->allocs) hipFree(a);
+  potrf_chain_destroy(p->chain);
   delete p;
 }
 

@@ -47,6 +47,7 @@ void launch_project(const double* X, int64_t n, int D, int d, const double* tpro
 void launch_potrf_diag(double* A, int mp, int j, double* dinv, int* info, hipStream_t s);
 // flags bit0: the block already holds an upper factor -- skip the factorisation, only write inv(U_jj) to dinv
 // m_real (0 = mp): rows and columns from m_real on are identity padding; micro-panels wholly inside it are skipped
+void potrf_fetch_timestamps(unsigned long long* out64);  // tools/potrf_check: phase stamps of a flags-bit-8 launch
 void launch_potrf_diag_flags(double* A, int mp, int j, double* dinv, int* info, int flags, hipStream_t s, int m_real = 0);
 // Whole blocked factorisation A = U^T U (upper, in place; the strict lower parts of the diagonal blocks are zeroed, the
 // tiles below the diagonal untouched) + inv(U_jj) of every diagonal block in dinv [mp/128][128][128], without the
@@ -56,6 +57,19 @@ void launch_potrf_diag_flags(double* A, int mp, int j, double* dinv, int* info, 
 // receives the block inverses as before.
 void potrf_upper_blocked(hipStream_t s, double* A, int mp, double* dinv, int* info, double* Yscratch = nullptr,
                          double* Xinv = nullptr, int m_real = 0);
+// The same factorisation + inverse as ONE persistent launch with device-side dependencies (chol.hip, round 5): the
+// workspace holds the task lists and flag words of an mp x mp problem (mp / 128 >= 2 blocks; create returns null
+// otherwise) on the current device.  *info: first non-positive pivot (1-based), or POTRF_CHAIN_ABORT_CODE if a
+// dependency wait ran into its bound (an internal error: the caller reports GPRHIP_EHIP).
+struct PotrfChain;
+constexpr int POTRF_CHAIN_ABORT_CODE = 0x7ffffff0;
+PotrfChain* potrf_chain_create(int mp);
+void potrf_chain_destroy(PotrfChain* ch);
+// trace (device, [ntasks + mp/128][4] 64-bit words, or null): per task / diagonal block the 100 MHz wall-clock stamps
+// {taken, dependencies seen, work done, flag set} -- tools/potrf_check TRACE=<m>
+void potrf_upper_chain(hipStream_t s, PotrfChain* ch, double* A, int mp, double* dinv, int* info, double* Y, double* Xinv,
+                       int m_real = 0, unsigned long long* trace = nullptr);
+int potrf_chain_tasks(const PotrfChain* ch, int* kinds4);  // the task list ({kind, j, a, b} each), returns its length
 // Single-block matrices (mp = 128): A = chol(I + src) (upper, in place of a load: src = the (0,0) tile of an exchange-1
 // buffer), Xinv = A^-1, and the m-vectors that follow in pass 2 (chol.hip, potrf_diag_body<true>):
 //   b = Xinv^T cvec, t~ = Xinv b, t = uinv t~, logdet = log|I + src|, bb = |b|^2

@@ -1896,15 +1896,23 @@ def test_diagonal_block_harness():
     # block inverses in one launch) at 1 .. 32 block rows; the strict lower triangle is poisoned with 1e300
     rows = re.findall(r"blocked potrf m=(\d+): \S+ us  info=(-?\d+)  max \|U\^T U - A\| / max\|A\| = (\S+)  "
                       r"max \|U_jj Dinv_j - I\| = (\S+)", out.stdout)
-    assert [int(r[0]) for r in rows] == [128, 384, 1024, 2048, 4096], out.stdout[-2000:]
+    assert [int(r[0]) for r in rows] == [128, 256, 384, 512, 1024, 2048, 4096], out.stdout[-2000:]
     for _, info, ea, ed in rows:
         assert int(info) == 0 and float(ea) < 1e-13 and float(ed) < 1e-10
     # ... and with the identity carried along as right-hand side: the same factor, U X = I, X upper triangular
     inv = re.findall(r"blocked potrf\+inverse m=(\d+): \S+ us  factor differs by (\S+)  max \|U X - I\| = (\S+)  "
                      r"max \|strict lower of X\| = (\S+)", out.stdout)
-    assert [int(r[0]) for r in inv] == [128, 384, 1024, 2048, 4096], out.stdout[-2000:]
+    assert [int(r[0]) for r in inv] == [128, 256, 384, 512, 1024, 2048, 4096], out.stdout[-2000:]
     for _, eu, ei, el in inv:
         assert float(eu) == 0.0 and float(ei) < 1e-10 and float(el) == 0.0
+    # the same factorisation + inverse as ONE persistent launch with device-side dependencies (potrf_upper_chain: measured
+    # slower than the step launches and off by default, DESIGN section 14 -- but it must stay correct): no dependency wait
+    # ran into its bound, and both results are bit-identical to the step launches'
+    chain = re.findall(r"chain potrf\+inverse m=(\d+): \S+ us \(stepwise \S+\)  info=(-?\d+)\S*  factor differs by (\S+)  "
+                       r"inverse differs by (\S+)", out.stdout)
+    assert [int(r[0]) for r in chain] == [256, 384, 512, 1024, 2048, 4096], out.stdout[-2000:]
+    for _, info, du, dx in chain:
+        assert int(info) == 0 and float(du) == 0.0 and float(dx) == 0.0
 
 
 # ---- round 4: single-process multi-device context (gprhip_ctx_* / gprhip_sharded_*), element-wise covariance pins

@@ -18,7 +18,7 @@ int main() {
   double *dA, *dD; int* dI;
   hipMalloc(&dA, n*n*8); hipMalloc(&dD, n*n*8); hipMalloc(&dI, 8); hipMemset(dI, 0, 8);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-  for (int flags : {0, 1, 2, 3, 2 + 4, 2 + 8, 2 + 16, 2 + 4 + 8 + 16}) {
+  for (int flags : {0, 1, 2, 3, 2 + 32}) {
     float best = 1e9;
     for (int rep = 0; rep < 5; ++rep) {
       hipMemcpy(dA, A.data(), n*n*8, hipMemcpyHostToDevice);
@@ -27,7 +27,20 @@ int main() {
       hipEventRecord(e1, 0); hipEventSynchronize(e1);
       float ms; hipEventElapsedTime(&ms, e0, e1); best = std::min(best, ms);
     }
-    printf("flags=%d (1 skip factor, 2 skip invert, 4 skip diag16, 8 skip panel solve, 16 skip trailing): %.1f us\n", flags, best * 1e3);
+    printf("flags=%d (1 skip factor, 2 skip invert, 32 factor-only step of the blocked factorisation): %.1f us\n", flags, best * 1e3);
+  }
+  if (getenv("TS")) {  // phase stamps of the factor (s_memtime ticks, thread 0): chain | barrier | panel | first-row update
+    for (int fl : {2 + 256, 256}) {
+      hipMemcpy(dA, A.data(), n*n*8, hipMemcpyHostToDevice);
+      launch_potrf_diag_flags(dA, n, 0, dD, dI, fl, 0, m_real);
+      hipDeviceSynchronize();
+      unsigned long long t[64];
+      potrf_fetch_timestamps(t);
+      printf("flags=%d  ticks of wavefront 0 per micro-panel [chain + stores | barrier 1 | X tile | barrier 2 + diagonal tile + relayout]:\n", fl);
+      for (int k = 0; k < 8 && t[4 + 4 * k] > t[0]; ++k)
+        printf("  k=%d: %5llu %5llu %5llu %5llu\n", k, t[1 + 4 * k] - t[4 * k], t[2 + 4 * k] - t[1 + 4 * k], t[3 + 4 * k] - t[2 + 4 * k],
+               t[4 + 4 * k] - t[3 + 4 * k]);
+    }
   }
   // correctness of the full kernel
   hipMemcpy(dA, A.data(), n*n*8, hipMemcpyHostToDevice);
@@ -41,7 +54,7 @@ int main() {
 
   // the whole blocked factorisation (potrf_upper_blocked: factor-only diagonal kernel, substitution panel, small-tile
   // trailing update, block inverses at the end) against its definition, and its time
-  for (int m : {128, 384, 1024, 2048, 4096}) {
+  for (int m : {128, 256, 384, 512, 1024, 2048, 4096}) {
     const int nb = m / 128;
     std::vector<double> B((size_t)m * 64), S((size_t)m * m);
     for (auto& v : B) v = (double)rand() / RAND_MAX - 0.5;
@@ -121,6 +134,67 @@ int main() {
     }
     printf("blocked potrf+inverse m=%d: %.1f us  factor differs by %.1e  max |U X - I| = %.2e  max |strict lower of X| = %.1e\n",
            m, besti * 1e3, eu, ei, el);
+    // the same as ONE persistent launch with device-side dependencies (potrf_upper_chain): bit-identical factor and inverse
+    if (m >= 256 && m <= 8192) {
+      PotrfChain* ch = potrf_chain_create(m);
+      double* dX2;
+      hipMalloc(&dX2, (size_t)m * m * 8);
+      hipMemset(dX2, 0xff, (size_t)m * m * 8);
+      float bestc = 1e9;
+      const int reps = getenv("CHAIN_REPS") ? atoi(getenv("CHAIN_REPS")) : 6;
+      for (int rep = 0; rep < reps; ++rep) {
+        hipMemcpy(dS, S.data(), (size_t)m * m * 8, hipMemcpyHostToDevice);
+        hipMemset(dJ, 0, 8);
+        hipEventRecord(e0, 0);
+        potrf_upper_chain(0, ch, dS, m, dV, dJ, dY, dX2);
+        hipEventRecord(e1, 0); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1); bestc = std::min(bestc, ms);
+      }
+      int cinfo = -1;
+      hipMemcpy(&cinfo, dJ, 4, hipMemcpyDeviceToHost);
+      std::vector<double> U3((size_t)m * m), X3((size_t)m * m);
+      hipMemcpy(U3.data(), dS, (size_t)m * m * 8, hipMemcpyDeviceToHost);
+      hipMemcpy(X3.data(), dX2, (size_t)m * m * 8, hipMemcpyDeviceToHost);
+      double du = 0, dx = 0;
+      for (int i = 0; i < m; ++i)
+        for (int j = 0; j < m; ++j) {
+          if (j >= i) du = std::max(du, fabs(U3[(size_t)i * m + j] - U2[(size_t)i * m + j]));
+          dx = std::max(dx, fabs(X3[(size_t)i * m + j] - Xi[(size_t)i * m + j]));
+        }
+      printf("chain potrf+inverse m=%d: %.1f us (stepwise %.1f)  info=%d%s  factor differs by %.1e  inverse differs by %.1e\n", m,
+             bestc * 1e3, besti * 1e3, cinfo, cinfo == POTRF_CHAIN_ABORT_CODE ? " (ABORTED)" : "", du, dx);
+      if (getenv("TRACE") && atoi(getenv("TRACE")) == m) {  // the launch's timeline (100 MHz wall clock, us from the first stamp)
+        const int nt = potrf_chain_tasks(ch, nullptr);
+        std::vector<int> tk((size_t)nt * 4);
+        potrf_chain_tasks(ch, tk.data());
+        unsigned long long* dT;
+        hipMalloc(&dT, (size_t)(nt + nb) * 32);
+        hipMemset(dT, 0, (size_t)(nt + nb) * 32);
+        hipMemcpy(dS, S.data(), (size_t)m * m * 8, hipMemcpyHostToDevice);
+        hipMemset(dJ, 0, 8);
+        potrf_upper_chain(0, ch, dS, m, dV, dJ, dY, dX2, 0, dT);
+        hipDeviceSynchronize();
+        std::vector<unsigned long long> tt((size_t)(nt + nb) * 4);
+        hipMemcpy(tt.data(), dT, tt.size() * 8, hipMemcpyDeviceToHost);
+        unsigned long long t0 = ~0ull;
+        for (auto v : tt) if (v && v < t0) t0 = v;
+        auto us = [&](unsigned long long v) { return v ? (double)(v - t0) * 0.01 : -1.0; };
+        const char* names[] = {"P ", "PY", "U ", "UY"};
+        const int maxj = getenv("TRACE_STEPS") ? atoi(getenv("TRACE_STEPS")) : 3;
+        for (int j = 0; j < nb; ++j) {
+          const unsigned long long* d = &tt[(size_t)(nt + j) * 4];
+          printf("D(%d)            start %8.2f  deps %8.2f  done %8.2f  flag %8.2f\n", j, us(d[0]), us(d[1]), us(d[2]), us(d[3]));
+          if (j >= maxj) continue;
+          for (int i = 0; i < nt; ++i)
+            if (tk[4 * i + 1] == j && (tk[4 * i] != 2 && tk[4 * i] != 3 || (tk[4 * i + 3] >> 16) == 1 || getenv("TRACE_ALL")))
+              printf("  %s(%d,%3d,%3d) #%5d start %8.2f  deps %8.2f  done %8.2f  flag %8.2f\n", names[tk[4 * i]], j, tk[4 * i + 2],
+                     tk[4 * i + 3] & 0xffff, i, us(tt[4 * (size_t)i]), us(tt[4 * (size_t)i + 1]), us(tt[4 * (size_t)i + 2]), us(tt[4 * (size_t)i + 3]));
+        }
+        hipFree(dT);
+      }
+      hipFree(dX2);
+      potrf_chain_destroy(ch);
+    }
     hipFree(dY); hipFree(dX);
     hipFree(dS); hipFree(dV); hipFree(dJ);
   }
