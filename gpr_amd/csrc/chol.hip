@@ -156,7 +156,9 @@ __device__ __forceinline__ void potrf_factor_lds(double* __restrict__ T, double*
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int l15 = lane & 15, lq = lane >> 4;
   constexpr int YC = 64;  // first column of the carried right-hand side
-  constexpr int NH = PT / 64 - 1;  // helper wavefronts
+  // helper wavefronts: all but wavefront 0 and its SIMD partner (wavefront i runs on SIMD i % 4: wavefront 4 would share
+  // the chain's issue port -- with it busy the chain took 4500 - 5400 cycles per micro-panel instead of 3700)
+  constexpr int NH = PT / 64 - 2;
   const int nmp = k_end / MB;
   // tile (ci, cj) -= X_ci^T X_cj with X = rows k0p.. of T (the solved panel)
   auto update_tile = [&](int k0p, int ci, int cj) {
@@ -234,8 +236,13 @@ __device__ __forceinline__ void potrf_factor_lds(double* __restrict__ T, double*
       }
       if (ts && lane == 0) g_potrf_ts[4 + 4 * k] = clock64();
     }
+  } else if (wid == 4) {
+    for (int k = 0; k < nmp; ++k) {
+      __syncthreads();  // 1
+      __syncthreads();  // 2
+    }
   } else {
-    const int w = wid - 1;
+    const int w = wid < 4 ? wid - 1 : wid - 2;
     for (int k = 0; k < nmp; ++k) {
       const int k0 = k * MB;
       __syncthreads();  // 1

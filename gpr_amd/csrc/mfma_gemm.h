@@ -85,6 +85,13 @@ struct GemmArgsT {
   double* rp_sumsq = nullptr;
   double* rp_dot = nullptr;
   const double* rp_vec = nullptr;
+  // Round barrier (set by launch_gemm for the launches it pays on: fp32 SYRK-shaped split-K launches): the 64 workgroups
+  // an XCD holds at a time -- one residency round of its item list: one 8 x 8 super tile of one k-slice -- wait for each
+  // other before their first stage, so that they stream the 16 operand panels they share in step (round_ctr:
+  // [8][round_stride] arrival counts, zeroed in front of the launch; a workgroup waits at most round_ticks x 10 ns).
+  int* round_ctr = nullptr;
+  int round_stride = 0;
+  int round_ticks = 0;
   int lab_skip = 0;  // tools/gemm_check.hip only (timing ablation): 1 = no epilogue at all
   int lab_nostep = 0;  // engine lab (GPRHIP_LAB_NOSTEP=1, timing only, results wrong): the operand pointers do not advance
                        // from stage to stage, so every refill after the first hits the L2 -- how much of a launch is
