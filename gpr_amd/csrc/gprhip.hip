@@ -535,14 +535,41 @@ void upload_hypers(gprhip_problem* p, const gprhip_hypers* h) {
 int pick_kslices(int mp, int64_t rows_p, int max_slices, int64_t slice_rows, bool f64) {
   const int nt = mp / TILE, tiles = nt * (nt + 1) / 2;
   const int slots = 64;
+  auto items_of = [&](int ks) {  // items of one XCD: off-diagonal tiles per slice + the diagonal tiles' own slices
+    const int ksd = gemm_syrk_diag_slices(ks, f64, true);
+    return (tiles - nt) * (ks / 8) + nt * ((ksd + 7) / 8);
+  };
+  if (rows_p < 32 * slice_rows) {
+    // Mid-size shards (round 5): with few tiles (36 at m = 1024, 10 at m = 512) and few `slice_rows`-sized slices the
+    // launch is one or two badly filled residency rounds -- 72 items per XCD for 64 slots at n = 100 000, m = 1024, ten
+    // items at n = 50 000, m = 512.  Here the factor is chosen over the WHOLE feasible range by the time a launch of that
+    // shape takes: residency rounds (the last, partial one at about half price while it leaves every CU a single
+    // workgroup) x (fixed cost of an item + its rows at half a CU's matrix rate) + the slice sum that follows.
+    const double t_fixed = 10.0, t_row = f64 ? 0.22 : 0.11;  // us per item; us per training point of a 128 x 128 tile item
+    int best = 8;
+    double best_t = 1e300;
+    for (int ks = 8; ks <= max_slices / 8 * 8; ks += 8) {
+      if ((int64_t)ks * TILE > rows_p && ks > 8) break;  // at least 128 training points per slice
+      const int items = items_of(ks);
+      const int full = items / slots, rem = items % slots;
+      const double rounds = full + (rem == 0 ? 0.0 : (rem <= slots / 2 ? 0.55 : 1.0));
+      const double t_item = t_fixed + (double)rows_p / ks * t_row;
+      const double t_sum = (double)ks * tiles * TILE * TILE * (f64 ? 8.0 : 4.0) / 3.0e6;  // us at 3 TB/s
+      const double t = rounds * t_item + t_sum;
+      if (t < best_t - 1e-9) {
+        best_t = t;
+        best = ks;
+      }
+    }
+    return best;
+  }
   int target = (int)((rows_p / slice_rows + 7) / 8 * 8);
   target = std::max(8, std::min(target, max_slices / 8 * 8));
   int best = target;
   double best_eff = 0.0;
   for (int ks = std::max(8, target - 16); ks <= std::min(max_slices / 8 * 8, target + 16); ks += 8) {
     if ((int64_t)ks * BK * 8 > rows_p && ks > 8) continue;
-    const int ksd = gemm_syrk_diag_slices(ks, f64, true);  // items of one XCD: off-diagonal tiles per slice + the diagonal tiles' own slices
-    const int items = (tiles - nt) * (ks / 8) + nt * ((ksd + 7) / 8);
+    const int items = items_of(ks);
     const double eff = (double)items / ((double)((items + slots - 1) / slots) * slots);
     if (eff > best_eff + 1e-9) {
       best_eff = eff;
@@ -1739,6 +1766,9 @@ int gprhip_problem_create_ex(int device, int cov_kind, int precision, int64_t n,
     if (const char* e = getenv("GPRHIP_SLICE_ROWS")) p->slice_rows = std::max<int64_t>(1024, atoll(e));
     p->kslices = (int)std::max<int64_t>(8, std::min<int64_t>((round_up(n, p->slice_rows) / p->slice_rows + 23) / 8 * 8,
                                                               (40LL << 30) / (p->mp * (int64_t)p->mp * 8) / 8 * 8));
+    // mid-size shards take many short slices (pick_kslices): room for up to 128 of them within 2 GB
+    if (n < 32 * p->slice_rows)
+      p->kslices = (int)std::max<int64_t>(p->kslices, std::min<int64_t>(128, (2LL << 30) / (p->mp * (int64_t)p->mp * 8) / 8 * 8));
     if (const char* e = getenv("GPRHIP_KSLICES")) p->kslices = std::max(8, atoi(e) / 8 * 8);
     if (const char* e = getenv("GPRHIP_TIMING")) {
       p->timer.on = atoi(e) >= 2;
