@@ -132,6 +132,21 @@ def profile_traffic(n, m):
         out["launches"].append({"kernel": r["kernel"], "avg_ms": r["avg_ms"], "fetch_bytes": r["hbm_fetch_bytes_per_launch"],
                                 "write_bytes": r["hbm_write_bytes_per_launch"], "bytes_over_algorithmic": b / algo,
                                 "mfma_util": r.get("mfma_util"), "clock_ghz": r.get("clock_ghz")})
+    # The figure belongs to the run, not to the kernel (it follows how far the workgroups of a k-slice drift apart against
+    # the 4 MB L2 window): the range over EVERY committed pass of this command is quoted beside the newest one.
+    seen = []
+    for q in paths:
+        try:
+            for r in json.load(open(q)):
+                if "gemm_f64_tn_w" in r["kernel"] and r["avg_ms"] > 5.0:
+                    seen.append((r["hbm_fetch_bytes_per_launch"] + r["hbm_write_bytes_per_launch"], os.path.relpath(q, ROOT)))
+        except Exception:
+            pass
+    if seen:
+        lo, hi = min(seen), max(seen)
+        out["range_over_committed_passes"] = {"min_bytes": lo[0], "min_from": lo[1], "max_bytes": hi[0], "max_from": hi[1],
+                                              "passes": len(seen), "min_over_algorithmic": lo[0] / algo,
+                                              "max_over_algorithmic": hi[0] / algo}
     return out
 
 

@@ -76,6 +76,8 @@ SIGNATURES = {
     "gprhip_eval": (C.c_int, [_vp, C.POINTER(Hypers), C.c_int, C.POINTER(Result), _dp, _dp]),
     "gprhip_ar1_len": (C.c_int64, [_vp]),
     "gprhip_ar2_len": (C.c_int64, [_vp]),
+    "gprhip_exchange_len": (C.c_int64, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "gprhip_exchange_offset": (C.c_int64, [C.c_int, C.c_int, C.c_int]),
     "gprhip_eval_pass1": (C.c_int, [_vp, C.POINTER(Hypers), C.c_int, C.c_int64, _vp]),
     "gprhip_eval_pass2": (C.c_int, [_vp, _vp, _vp]),
     "gprhip_eval_finish": (C.c_int, [_vp, _vp, C.POINTER(Result), _dp, _dp]),

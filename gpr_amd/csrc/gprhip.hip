@@ -1955,10 +1955,22 @@ int64_t gprhip_n_hypers(const gprhip_problem* p, int flags) {
          ((flags & 4) ? (int64_t)p->d * p->m : 0);
 }
 
-int64_t gprhip_ar1_len(const gprhip_problem* p) { return p ? packed_upper_len(p->mp) + p->mp + A1_TAIL : 0; }
-int64_t gprhip_ar2_len(const gprhip_problem* p) {
-  return p ? packed_upper_len(p->mp) + p->col_rows() * p->mp + (int64_t)p->dbig() * p->d + A2_TAIL : 0;
+int64_t gprhip_exchange_len(int cov_kind, int D, int d, int m, int which) {
+  if (m < 1 || d < 1 || D < 1 || (which != 1 && which != 2) || (cov_kind != GPRHIP_COV_SE_ISO && cov_kind != GPRHIP_COV_SE_FAT))
+    return 0;
+  const int mp = (int)round_up(m, TILE);
+  if (which == 1) return packed_upper_len(mp) + mp + A1_TAIL;
+  const bool fat = cov_kind == GPRHIP_COV_SE_FAT;
+  const int64_t dbig = fat ? D : 0, col_rows = d + 1 + dbig + (fat ? d : 0);  // gprhip_problem::col_rows / dbig
+  return packed_upper_len(mp) + col_rows * mp + dbig * d + A2_TAIL;
 }
+int64_t gprhip_exchange_offset(int m, int r, int c) {
+  const int mp = (int)round_up(m, TILE);
+  if (m < 1 || r < 0 || c < 0 || r >= mp || c >= mp || r / TILE > c / TILE) return -1;
+  return packed_upper_off(r, c);
+}
+int64_t gprhip_ar1_len(const gprhip_problem* p) { return p ? gprhip_exchange_len(p->kind, p->D, p->d, p->m, 1) : 0; }
+int64_t gprhip_ar2_len(const gprhip_problem* p) { return p ? gprhip_exchange_len(p->kind, p->D, p->d, p->m, 2) : 0; }
 
 int gprhip_eval_pass1(gprhip_problem* p, const gprhip_hypers* h, int want_grad, int64_t n_total,
                       double* d_ar1) {

@@ -140,6 +140,12 @@ int gprhip_eval(gprhip_problem* p, const gprhip_hypers* h, int want_grad, gprhip
  * n used in the n*log(2*pi) term is n_total given here (sum over shards). */
 int64_t gprhip_ar1_len(const gprhip_problem* p);
 int64_t gprhip_ar2_len(const gprhip_problem* p);
+/* The same lengths from the problem's dimensions alone (no device, no handle; which = 1 | 2), and the position of entry
+ * (r, c) of the symmetric m x m part that heads both buffers -- stored as its upper 128 x 128 tiles only, tile (bm <= bn)
+ * at ((bn (bn + 1) / 2 + bm) * 128 * 128, row-major inside (r, c < m rounded up to 128; the tile of (r, c) must be on or
+ * above the diagonal, else -1).  A host that owns the collective sizes and fills its buffers with these. */
+int64_t gprhip_exchange_len(int cov_kind, int D, int d, int m, int which);
+int64_t gprhip_exchange_offset(int m, int r, int c);
 int gprhip_eval_pass1(gprhip_problem* p, const gprhip_hypers* h, int want_grad, int64_t n_total,
                       double* d_ar1);
 int gprhip_eval_pass2(gprhip_problem* p, const double* d_ar1, double* d_ar2);

@@ -7,6 +7,11 @@ whitened formulation (B~ = I + V^T S^-1 V by SYRK + potrf instead of the referen
 DESIGN.md section 3) on top of
 the oracle's covariance functions, so it doubles as an independent check of that algebra against
 the reference-sequence oracle.
+
+Its exchange buffers are the LIBRARY's: lengths from gprhip_exchange_len and the symmetric m x m parts packed as upper
+128 x 128 tiles at gprhip_exchange_offset (both device-free entry points of libgprhip.so) -- so the world_size-2 test
+reduces buffers of exactly the size and layout the GPU path reduces, and a change of the packed layout on the device side
+shows up here.
 """
 import ctypes
 
@@ -23,14 +28,33 @@ def _view(ptr, length):
 
 class StagedDouble:
     def __init__(self, kernel_factory, n, D, d, m):
-        """kernel_factory(log_ell, log_sf2, tproj) -> oracle kernel object."""
+        """kernel_factory(log_ell, log_sf2, tproj) -> oracle kernel object.  (Cov_se_iso layouts: D == d.)"""
+        from gpr_amd import _lib
         self.kernel_factory, self.n, self.D, self.d, self.m = kernel_factory, n, D, d, m
+        self._lib = _lib.load()
+        self.mp = (m + 127) // 128 * 128
+        # position of every entry of the upper triangle (tile-wise upper: r // 128 <= c // 128) in the packed part
+        rr, cc = np.triu_indices(m)
+        self._pk_r, self._pk_c = rr, cc
+        self._pk_off = np.array([self._lib.gprhip_exchange_offset(m, int(r), int(c)) for r, c in zip(rr, cc)], dtype=np.int64)
+        assert self._pk_off.min() >= 0
+        self.packed = int(self._lib.gprhip_exchange_len(0, D, d, m, 1)) - self.mp - 4
 
     def ar1_len(self):
-        return self.m * self.m + self.m + 4
+        return int(self._lib.gprhip_exchange_len(0, self.D, self.d, self.m, 1))
 
     def ar2_len(self):
-        return self.m * self.m + (self.d + 1) * self.m + 8
+        return int(self._lib.gprhip_exchange_len(0, self.D, self.d, self.m, 2))
+
+    def _pack(self, buf, sym):
+        """upper triangle of the symmetric m x m `sym` into the packed head of an exchange buffer"""
+        buf[:self.packed] = 0.0
+        buf[self._pk_off] = sym[self._pk_r, self._pk_c]
+
+    def _unpack(self, buf):
+        out = np.zeros((self.m, self.m))
+        out[self._pk_r, self._pk_c] = buf[self._pk_off]
+        return out + np.triu(out, 1).T
 
     def set_inputs(self, x):
         self.X = np.asfortranarray(x, dtype=np.float64)
@@ -60,16 +84,19 @@ class StagedDouble:
         self.is_ = 1.0 / s
         yy = np.zeros(self.n) if model_only else self.y
         ar1 = _view(ar1_ptr, self.ar1_len())
-        ar1[:m * m] = ((V * self.is_[:, None]).T @ V).reshape(-1)
-        ar1[m * m:m * m + m] = V.T @ (self.is_ * yy)
-        ar1[m * m + m:] = [np.sum(np.log(s)), np.sum(self.is_ * yy * yy), np.sum(self.is_ * self.r), 0.0]
+        ar1[:] = 0.0
+        self._pack(ar1, (V * self.is_[:, None]).T @ V)
+        pk, mp = self.packed, self.mp
+        ar1[pk:pk + m] = V.T @ (self.is_ * yy)
+        ar1[pk + mp:] = [np.sum(np.log(s)), np.sum(self.is_ * yy * yy), np.sum(self.is_ * self.r), 0.0]
 
     def eval_pass2(self, ar1_ptr, ar2_ptr):
         m, d = self.m, self.d
         ar1 = _view(ar1_ptr, self.ar1_len())
-        self.tail1 = ar1[m * m + m:].copy()
-        Bt = np.eye(m) + ar1[:m * m].reshape(m, m)
-        c = ar1[m * m:m * m + m]
+        pk, mp = self.packed, self.mp
+        self.tail1 = ar1[pk + mp:].copy()
+        Bt = np.eye(m) + self._unpack(ar1)
+        c = ar1[pk:pk + m]
         self.R = np.linalg.cholesky(Bt).T
         Ri = sl.solve_triangular(self.R, np.eye(m))
         self.b = Ri.T @ c
@@ -96,18 +123,21 @@ class StagedDouble:
         for i in range(d):
             df = pts[i, :][:, None] - self.Z[i, :][None, :]
             sq += df * df
-        ar2[:m * m] = ((V * v[:, None]).T @ V).reshape(-1)
+        self._pack(ar2, (V * v[:, None]).T @ V)
         col = np.vstack([E.sum(0)[None, :], pts @ E])
-        ar2[m * m:m * m + (d + 1) * m] = col.reshape(-1)
-        ar2[m * m + (d + 1) * m:] = [v.sum(), self.is_.sum(), np.sum(w * res), v1.sum(), E.sum(),
-                                     np.sum(E * sq), 0.0, 0.0]
+        pk, mp = self.packed, self.mp
+        colv = ar2[pk:pk + (d + 1) * mp].reshape(d + 1, mp)   # [d + 1][mp]: sum E, sum p_k E
+        colv[:, :m] = col
+        ar2[pk + (d + 1) * mp:] = [v.sum(), self.is_.sum(), np.sum(w * res), v1.sum(), E.sum(),
+                                   np.sum(E * sq), 0.0, 0.0]
 
     def eval_finish(self, ar2_ptr):
         m, d = self.m, self.d
         ar2 = _view(ar2_ptr, self.ar2_len())
-        G = ar2[:m * m].reshape(m, m)
-        col = ar2[m * m:m * m + (d + 1) * m].reshape(d + 1, m)
-        tail = ar2[m * m + (d + 1) * m:]
+        pk, mp = self.packed, self.mp
+        G = self._unpack(ar2)
+        col = ar2[pk:pk + (d + 1) * mp].reshape(d + 1, mp)[:, :m]
+        tail = ar2[pk + (d + 1) * mp:]
         logdet_bt = 2 * np.sum(np.log(np.diag(self.R)))
         l1 = -0.5 * (logdet_bt + self.tail1[0] + self.n_total * O.LOG_2PI)
         if self.variational:

@@ -129,16 +129,26 @@ def _free_port():
     return port
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, shape=(501, 16, 3)):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        n, m, d = 501, 16, 3
+        n, m, d = shape
         X, y, Z = synth(8, n, m, d)
         lo, hi = shard_rows(n, rank, world)
+        # the row partition of the single-process context (gprhip_shard_rows, device-free) is the same one
+        import ctypes as C
+        from gpr_amd import _lib
+        a, b = C.c_int64(), C.c_int64()
+        _lib.check(_lib.load().gprhip_shard_rows(n, world, rank, C.byref(a), C.byref(b)))
+        assert (a.value, b.value) == (lo, hi)
         sd = StagedDouble(_factory, hi - lo, d, d, m)
         sp = ShardedProblem(0, n, d, d, m, backend=sd)
+        # the buffers this test all-reduces have the length and packed layout of the device path's
+        mp, nt = (m + 127) // 128 * 128, (m + 127) // 128
+        packed = nt * (nt + 1) // 2 * 128 * 128  # upper 128 x 128 tiles only
+        assert sp.ar1.numel() == sd.ar1_len() == packed + mp + 4 and sp.ar2.numel() == packed + (d + 1) * mp + 8
         sp.set_inputs(X[:, lo:hi])
         sp.set_targets(y[lo:hi])
         ev = sp.eval(log_ell=0.4, log_sf2=0.0, sigma2=0.1, inducing=Z)
@@ -151,19 +161,20 @@ def _worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-def test_world_size_2_sharded_eval_over_gloo():
+@pytest.mark.parametrize("shape", [(501, 16, 3), (703, 150, 3)])  # one tile of inducing points; two tile rows (three packed tiles)
+def test_world_size_2_sharded_eval_over_gloo(shape):
     world = 2
     port = _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, shape)) for r in range(world)]
     for p in procs:
         p.start()
     results = [q.get(timeout=120) for _ in range(world)]
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    n, m, d = 501, 16, 3
+    n, m, d = shape
     X, y, Z = synth(8, n, m, d)
     ref = O.evaluate_fast(O.SeIsoKernel(0.4, 0.0), Z, X, y, 0.1)
     for rank, l, dls2, grad, l0 in results:
