@@ -5,6 +5,7 @@
 // increasing order of (x_i - z_i)*(x_i - z_i), separate multiply and add (no FMA
 // contraction), then exp(log_sf2 + inv_ell2_05 * r2).  Only the last-ulp behaviour of
 // exp() can differ from the CPU.
+#include <cstdlib>
 #include "kernels.h"
 #include "exp_fast.h"
 
@@ -330,8 +331,10 @@ void launch_cov_upper(const CovParams& cp, const double* Z, int m, int mp, int d
                       const double* het, double* km, double* kj, hipStream_t s) {
   dim3 grid(mp / 256 + (mp % 256 ? 1 : 0), (mp + 31) / 32);
   // the m x m covariance sits on the latency chain in front of the factorisation: 8 rows per thread instead of 32 puts
-  // four times as many workgroups on the chip (m = 2048: 48 -> 17 us)
-  const int rb = 8;
+  // four times as many workgroups on the chip (m = 2048: 48 -> 17 us); round 5: 2 rows per thread up to m = 1024
+  // (m = 512: 17.9 us as 128 workgroups of 8-row threads, profiles/r05_timeline_n50000_m512.txt)
+  static const int rb_env = [] { const char* e = getenv("GPRHIP_COV_UPPER_ROWS"); return e ? atoi(e) : 0; }();
+  const int rb = rb_env > 0 ? rb_env : (mp <= 1024 ? 2 : 8);
   dim3 grid8(grid.x, (mp + rb - 1) / rb);
   no_wide_multiscales(cp, d);
   dispatch_dt(d, [&](auto dt) {

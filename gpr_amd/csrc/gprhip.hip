@@ -334,6 +334,11 @@ void potrf_upper(gprhip_problem* p, double* A, int* info) {
   potrf_upper_n(p->stream, A, p->mp, p->dinv, info, p->engine_steps, p->m);
 }
 
+// k-slices of an m x m product of triangular factors: few output tiles, each up to m / 128 blocks deep.  From three
+// 128-blocks on the k-range is split (slices end on block boundaries) -- at m = 512 the two products of the finish stage
+// took 64 and 69 us as 16 workgroups of up to four blocks each (profiles/r05_timeline_n50000_m512.txt).
+static int mxm_slices(int mp) { return mp >= 3 * TILE ? std::min(4, mp / TILE) : 1; }
+
 // A non-batched m x m product with few output tiles and a long k-range, split over `ks` k-slices so that the
 // launch fills the chip; partial products go to the split-K scratch and are summed in a fixed order.
 void gemm_splitk(gprhip_problem* p, GemmOp op, GemmArgs g, int ks) {
@@ -434,7 +439,7 @@ void triu_xxt(gprhip_problem* p, const double* X, double* C, hipStream_t st) {
   g.M = p->mp; g.N = p->mp; g.K = p->mp; g.tri = TRI_KLO_MAX; g.upper_only = 1;
   // few tiles, long triangular k-ranges: four k-slices (ending on block boundaries) fill the chip
   const int64_t mm = (int64_t)p->mp * p->mp;
-  const int ks = (p->mp >= 1024 && 4 * mm * 8 <= p->slices_bytes) ? 4 : 1;
+  const int ks = (mxm_slices(p->mp) > 1 && 4 * mm * 8 <= p->slices_bytes) ? mxm_slices(p->mp) : 1;
   if (ks > 1) {
     g.C = static_cast<double*>(p->slices);
     g.kslices = ks;
@@ -1051,7 +1056,7 @@ void do_finish_enqueue(gprhip_problem* p, const double* ar2, bool light = false)
     GemmArgs y;  // Y = W~ U^-T
     y.A = p->wtil; y.lda = mp; y.B = p->uinv; y.ldb = mp; y.C = p->kj; y.ldc = mp;  // kj is free after potrf; R~ stays in bmat
     y.M = mp; y.N = mp; y.K = mp; y.tri = TRI_KLO_BN;
-    const int wks = ((int64_t)(mp / TILE) * (mp / TILE) <= 256 && mp >= 1024) ? 4 : 1;
+    const int wks = ((int64_t)(mp / TILE) * (mp / TILE) <= 256) ? mxm_slices(mp) : 1;
     gemm_splitk(p, OP_NT, y, wks);
     GemmArgs w;  // W = U^-1 Y   (lib/fitc_gp.ml:1196-1203)
     w.A = p->uinv; w.lda = mp; w.B = p->kj; w.ldb = mp; w.C = p->wmat; w.ldc = mp;

@@ -1,4 +1,5 @@
-"""Two evaluations of a small-n problem at m=2048 (for kernel timelines of the m x m phases)."""
+"""Three gradient evaluations of one shape (for kernel timelines).  usage: python3 tools/one_eval.py [n m d]  (default: N from the
+environment or 16384, m = 2048, d = 8)"""
 import os
 import sys
 
@@ -9,6 +10,8 @@ import gpr_amd  # noqa: E402
 from bench import synth  # noqa: E402
 
 n, m, d = int(os.environ.get("N", 16384)), 2048, 8
+if len(sys.argv) >= 4:
+    n, m, d = (int(v) for v in sys.argv[1:4])
 X, y, Z = synth(2, n, m, d)
 p = gpr_amd.Problem(gpr_amd.COV_SE_ISO, n, d, d, m)
 p.set_inputs(X)
