@@ -665,7 +665,7 @@ __global__ __launch_bounds__(256) void potrf_panel_kernel(double* __restrict__ A
 // r > j and the column blocks c <= j (nsym = number of symmetric sub-tiles; Y may be null).
 template <bool ALL>
 __device__ __forceinline__ void potrf_update_body(double* __restrict__ A, int mp, int j, double* __restrict__ Y,
-                                                  int nsym) {
+                                                  int sym_lo, int sym_cnt, int y_lo) {
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int l15 = lane & 15, lq = lane >> 4;
   const int ns = (mp / NB - 1 - j) * 2;
@@ -674,8 +674,10 @@ __device__ __forceinline__ void potrf_update_body(double* __restrict__ A, int mp
   int64_t r0, c0;
   const double* Xb;
   double* Cp;
-  if ((int)blockIdx.x < nsym) {
-    int si = 0, rem = blockIdx.x;  // sub-tile (si <= sj) of the trailing part, in 64-blocks
+  // the launch covers sub-tiles sym_lo .. sym_lo + sym_cnt - 1 of the symmetric list and the tiles of Y from y_lo on (a
+  // whole step: 0, all, 0; the look-ahead split of potrf_upper_blocked: the two lists' prefixes = block row j + 1 first)
+  if ((int)blockIdx.x < sym_cnt) {
+    int si = 0, rem = sym_lo + (int)blockIdx.x;  // sub-tile (si <= sj) of the trailing part, in 64-blocks
     while (rem >= ns - si) {
       rem -= ns - si;
       ++si;
@@ -686,7 +688,7 @@ __device__ __forceinline__ void potrf_update_body(double* __restrict__ A, int mp
     Xb = X + (int64_t)lq * mp + c0 + l15;
     Cp = A + (r0 + lq) * mp + c0 + l15;
   } else {
-    const int t = (int)blockIdx.x - nsym, ncb = 2 * (j + 1);
+    const int t = y_lo + (int)blockIdx.x - sym_cnt, ncb = 2 * (j + 1);
     r0 = base + (t / ncb) * 64 + (wid >> 1) * 32;
     c0 = (int64_t)(t % ncb) * 64 + (wid & 1) * 32;
     Xb = Y + (int64_t)(j * NB + lq) * mp + c0 + l15;
@@ -737,12 +739,12 @@ __device__ __forceinline__ void potrf_update_body(double* __restrict__ A, int mp
       for (int r = 0; r < 4; ++r) Cp[(int64_t)(16 * i + 4 * r) * mp + 16 * jj] = acc[i][jj][r];
 }
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) void potrf_update_all_kernel(
-    double* __restrict__ A, int mp, int j, double* __restrict__ Y, int nsym) {
-  potrf_update_body<true>(A, mp, j, Y, nsym);
+    double* __restrict__ A, int mp, int j, double* __restrict__ Y, int sym_lo, int sym_cnt, int y_lo) {
+  potrf_update_body<true>(A, mp, j, Y, sym_lo, sym_cnt, y_lo);
 }
 __global__ __launch_bounds__(256) void potrf_update_kernel(double* __restrict__ A, int mp, int j,
-                                                           double* __restrict__ Y, int nsym) {
-  potrf_update_body<false>(A, mp, j, Y, nsym);
+                                                           double* __restrict__ Y, int sym_lo, int sym_cnt, int y_lo) {
+  potrf_update_body<false>(A, mp, j, Y, sym_lo, sym_cnt, y_lo);
 }
 
 // Y = identity (the right-hand side carried through the factorisation), and the final X = Y^T
@@ -1192,11 +1194,19 @@ void launch_potrf_diag_flags(double* A, int mp, int j, double* dinv, int* info, 
 // dinv: per step a factor-only diagonal kernel, the substitution panel and the small-tile trailing update; the block
 // inverses (which nothing on the chain needs any more) are formed by one launch over all blocks at the end.
 void potrf_upper_blocked(hipStream_t s, double* A, int mp, double* dinv, int* info, double* Yscratch, double* Xinv,
-                         int m_real) {
+                         int m_real, const PotrfAux* aux) {
   potrf_attrs();
   static const int all_tiles = [] {  // largest step (in 64 x 64 sub-tiles) that runs the all-loads-first update kernel
     const char* e = getenv("GPRHIP_POTRF_ALL_TILES");
     return e ? atoi(e) : 768;
+  }();
+  // smallest rest of a step (sub-tiles outside block row j + 1) that goes to the side stream (GPRHIP_POTRF_LOOKAHEAD; 0 = never,
+  // the default: measured SLOWER than one stream -- m = 2048: 946 against 856 us, m = 1024: 441 against 384 us,
+  // tools/potrf_check, profiles/r05_potrf_lookahead.txt -- the two cross-stream event waits of a step cost more than the
+  // part of the update they take off the chain)
+  static const int la_min = [] {
+    const char* e = getenv("GPRHIP_POTRF_LOOKAHEAD");
+    return e ? atoi(e) : 0;
   }();
   const int nb = mp / NB;
   if (nb == 1) {  // a single block: factor and inverse in one launch
@@ -1215,6 +1225,20 @@ void potrf_upper_blocked(hipStream_t s, double* A, int mp, double* dinv, int* in
   }
   double* const Y = Xinv ? Yscratch : nullptr;
   if (Y) hipLaunchKernelGGL(set_identity_kernel, dim3((mp + 255) / 256, mp), dim3(256), 0, s, Y, mp);
+  auto update = [&](hipStream_t st, int j, int sym_lo, int sym_cnt, int y_lo, int y_cnt, int step_tiles) {
+    if (sym_cnt + y_cnt <= 0) return;
+    if (step_tiles <= all_tiles)
+      hipLaunchKernelGGL(potrf_update_all_kernel, dim3(sym_cnt + y_cnt), dim3(256), 0, st, A, mp, j, Y, sym_lo, sym_cnt, y_lo);
+    else
+      hipLaunchKernelGGL(potrf_update_kernel, dim3(sym_cnt + y_cnt), dim3(256), 0, st, A, mp, j, Y, sym_lo, sym_cnt, y_lo);
+  };
+  // Look-ahead (round 5; built, measured, off by default -- see la_min above).  The next diagonal block, the next panel and the next step's share of Y read block row j + 1
+  // of the trailing update only -- the first 2 ns - 1 sub-tiles of its symmetric list and the first two sub-tile rows of
+  // its Y part.  With a side stream those go out alone on `s` (a launch of a few dozen workgroups) and the rest of the
+  // step's update runs on the side stream beside the next diagonal block's factorisation (30 us of one CU); `s` waits for
+  // it only in front of the NEXT step's update, which touches the same tiles.  Per step on `s`: diag + panel + the short
+  // update instead of diag + panel + the whole update (11 - 17 us at m = 2048, 20 - 40 us at m = 4096).
+  bool pending = false;  // a rest launch of the previous step is in flight on the side stream
   for (int j = 0; j < nb; ++j) {
     double* dj = dinv + (int64_t)j * NB * NB;
     hipLaunchKernelGGL(potrf_diag_kernel, dim3(1), dim3(PT), POTRF_LDS, s, A, mp, j, dj, info, 2 + 32, m_real);
@@ -1223,11 +1247,26 @@ void potrf_upper_blocked(hipStream_t s, double* A, int mp, double* dinv, int* in
     if (rest + nrhs > 0)
       hipLaunchKernelGGL(potrf_panel_kernel, dim3(2 * rest + nrhs), dim3(256), PANEL_LDS, s, A, mp, j, dj, Y);
     if (rest > 0) {
-      const int nsym = ns * (ns + 1) / 2, tiles = nsym + ns * nrhs;
-      if (tiles <= all_tiles) hipLaunchKernelGGL(potrf_update_all_kernel, dim3(tiles), dim3(256), 0, s, A, mp, j, Y, nsym);
-      else hipLaunchKernelGGL(potrf_update_kernel, dim3(tiles), dim3(256), 0, s, A, mp, j, Y, nsym);
+      const int nsym = ns * (ns + 1) / 2, ny = ns * nrhs, tiles = nsym + ny;
+      const int csym = std::min(nsym, 2 * ns - 1), cy = std::min(ny, 2 * nrhs);  // block row j + 1
+      const bool split = aux && aux->side && la_min > 0 && (nsym - csym) + (ny - cy) >= la_min;
+      if (pending) {  // this step's update writes the tiles the previous step's rest is still writing
+        GPR_HIP(hipStreamWaitEvent(s, aux->ev_rest[(j - 1) & 1], 0));
+        pending = false;
+      }
+      if (split) {
+        GPR_HIP(hipEventRecord(aux->ev_panel[j & 1], s));
+        GPR_HIP(hipStreamWaitEvent(aux->side, aux->ev_panel[j & 1], 0));
+        update(aux->side, j, csym, nsym - csym, cy, ny - cy, tiles);
+        GPR_HIP(hipEventRecord(aux->ev_rest[j & 1], aux->side));
+        pending = true;
+        update(s, j, 0, csym, 0, cy, tiles);
+      } else {
+        update(s, j, 0, nsym, 0, ny, tiles);
+      }
     }
   }
+  if (pending) GPR_HIP(hipStreamWaitEvent(s, aux->ev_rest[(nb - 2) & 1], 0));
   if (Y) hipLaunchKernelGGL(transpose_kernel, dim3(mp / 32, mp / 32), dim3(256), 0, s, Y, mp, Xinv);
   else hipLaunchKernelGGL(potrf_diag_kernel, dim3(nb), dim3(PT), POTRF_LDS, s, A, mp, 0, dinv, info, 1, m_real);
   GPR_HIP(hipGetLastError());

@@ -118,6 +118,9 @@ struct gprhip_problem {
   hipStream_t stream2 = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   hipEvent_t ev_rf = nullptr, ev_binv = nullptr;  // pass 2: R^-1 and B~^-1 come from the second stream (do_pass2)
+  // third stream + events: look-ahead of the blocked factorisation (chol.hip, potrf_upper_blocked) -- a stream of its own,
+  // because stream2 carries the first row chunk's covariance beside the K_m factorisation
+  PotrfAux potrf_aux{};
   std::vector<void*> allocs;
 
   double *X = nullptr, *y = nullptr, *P = nullptr;
@@ -429,7 +432,7 @@ void potrf_trtri(gprhip_problem* p, double* A, double* X, double* tmp, int* info
       return;
     }
   }
-  potrf_upper_blocked(p->stream, A, p->mp, p->dinv, info, tmp, X, p->m);
+  potrf_upper_blocked(p->stream, A, p->mp, p->dinv, info, tmp, X, p->m, p->potrf_aux.side ? &p->potrf_aux : nullptr);
 }
 
 // C (upper tiles) = X X^T for upper-triangular X: (U^T U)^-1 = U^-1 U^-T   (Utils.ichol, lib/utils.ml:110-113)
@@ -1790,6 +1793,13 @@ int gprhip_problem_create_ex(int device, int cov_kind, int precision, int64_t n,
     if (const char* e = getenv("GPRHIP_POTRF_CHAIN")) p->potrf_chain_mode = atoi(e);
     GPR_HIP(hipStreamCreate(&p->stream));
     GPR_HIP(hipStreamCreate(&p->stream2));
+    if (p->mp >= 3 * TILE && getenv("GPRHIP_POTRF_LOOKAHEAD") && atoi(getenv("GPRHIP_POTRF_LOOKAHEAD")) > 0) {  // (A/B runs only)
+      GPR_HIP(hipStreamCreate(&p->potrf_aux.side));
+      for (int k = 0; k < 2; ++k) {
+        GPR_HIP(hipEventCreateWithFlags(&p->potrf_aux.ev_panel[k], hipEventDisableTiming));
+        GPR_HIP(hipEventCreateWithFlags(&p->potrf_aux.ev_rest[k], hipEventDisableTiming));
+      }
+    }
     GPR_HIP(hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming));
     GPR_HIP(hipEventCreateWithFlags(&p->ev_join, hipEventDisableTiming));
     GPR_HIP(hipEventCreateWithFlags(&p->ev_rf, hipEventDisableTiming));
@@ -1888,6 +1898,14 @@ void gprhip_problem_destroy(gprhip_problem* p) {
   if (p->ev_join) hipEventDestroy(p->ev_join);
   if (p->ev_rf) hipEventDestroy(p->ev_rf);
   if (p->ev_binv) hipEventDestroy(p->ev_binv);
+  if (p->potrf_aux.side) {
+    hipStreamSynchronize(p->potrf_aux.side);
+    hipStreamDestroy(p->potrf_aux.side);
+    for (int k = 0; k < 2; ++k) {
+      hipEventDestroy(p->potrf_aux.ev_panel[k]);
+      hipEventDestroy(p->potrf_aux.ev_rest[k]);
+    }
+  }
   if (p->timer.k0) {
     hipEventDestroy(p->timer.k0);
     hipEventDestroy(p->timer.k1);

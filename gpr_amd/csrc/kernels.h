@@ -55,8 +55,14 @@ void launch_potrf_diag_flags(double* A, int mp, int j, double* dinv, int* info, 
 // With Xinv != null the inverse of the factor, inv(U) (upper, zeros below), is produced by the same steps (an identity
 // right-hand side in the mp x mp scratch Yscratch rides along) and dinv only serves as scratch; with Xinv == null dinv
 // receives the block inverses as before.
+// aux (optional): a side stream and four events of the caller's -- the part of every step's trailing update that the next
+// diagonal block does not need then runs on the side stream beside that block's factorisation (look-ahead).
+struct PotrfAux {
+  hipStream_t side = nullptr;
+  hipEvent_t ev_panel[2] = {nullptr, nullptr}, ev_rest[2] = {nullptr, nullptr};
+};
 void potrf_upper_blocked(hipStream_t s, double* A, int mp, double* dinv, int* info, double* Yscratch = nullptr,
-                         double* Xinv = nullptr, int m_real = 0);
+                         double* Xinv = nullptr, int m_real = 0, const PotrfAux* aux = nullptr);
 // The same factorisation + inverse as ONE persistent launch with device-side dependencies (chol.hip, round 5): the
 // workspace holds the task lists and flag words of an mp x mp problem (mp / 128 >= 2 blocks; create returns null
 // otherwise) on the current device.  *info: first non-positive pivot (1-based), or POTRF_CHAIN_ABORT_CODE if a

@@ -115,6 +115,31 @@ int main() {
       hipEventRecord(e1, 0); hipEventSynchronize(e1);
       float ms; hipEventElapsedTime(&ms, e0, e1); besti = std::min(besti, ms);
     }
+    {  // the same with the look-ahead split of the trailing update (side stream): timing, and the results below are its
+      PotrfAux aux;
+      hipStream_t ms;  // (not the null stream: it synchronises with every other stream)
+      hipStreamCreateWithFlags(&ms, hipStreamNonBlocking);
+      hipStreamCreateWithFlags(&aux.side, hipStreamNonBlocking);
+      for (int k = 0; k < 2; ++k) {
+        hipEventCreateWithFlags(&aux.ev_panel[k], hipEventDisableTiming);
+        hipEventCreateWithFlags(&aux.ev_rest[k], hipEventDisableTiming);
+      }
+      float bestl = 1e9, best1 = 1e9;
+      for (int rep = 0; rep < 8; ++rep) {
+        hipMemcpy(dS, S.data(), (size_t)m * m * 8, hipMemcpyHostToDevice);
+        hipMemset(dX, 0xff, (size_t)m * m * 8);
+        hipDeviceSynchronize();
+        hipEventRecord(e0, ms);
+        potrf_upper_blocked(ms, dS, m, dV, dJ, dY, dX, 0, (rep & 1) ? &aux : nullptr);
+        hipEventRecord(e1, ms); hipEventSynchronize(e1);
+        float t; hipEventElapsedTime(&t, e0, e1);
+        if (rep & 1) bestl = std::min(bestl, t); else best1 = std::min(best1, t);
+      }
+      printf("  with look-ahead (side stream) m=%d: %.1f us (one stream %.1f)\n", m, bestl * 1e3, best1 * 1e3);
+      hipStreamSynchronize(aux.side);
+      hipStreamDestroy(aux.side);
+      hipStreamDestroy(ms);
+    }
     std::vector<double> U2((size_t)m * m), Xi((size_t)m * m);
     hipMemcpy(U2.data(), dS, (size_t)m * m * 8, hipMemcpyDeviceToHost);
     hipMemcpy(Xi.data(), dX, (size_t)m * m * 8, hipMemcpyDeviceToHost);
