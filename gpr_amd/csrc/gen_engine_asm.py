@@ -85,7 +85,8 @@ def gen(c):
         return reg(128 + aw * (4 * i + j), aw)
 
     tb = 88 if c.f64 else 80                   # first of our temporaries (the HIP code is capped below it)
-    W = lambda s: reg(tb + fw * s, fw)       # weight fragment of set s
+    # weight fragment of set s (fp32: on even registers, so that it can be the 64-bit second source of v_pk_mul_f32)
+    W = lambda s: reg(tb + 2 * s, fw)
     W2 = lambda s: reg(tb + 4 + fw * s, fw)
     AX = lambda kk: "v%d" % (tb + kk - 1)            # kk >= 1 (x-major A address of k-step kk)
     BX = lambda kk: "v%d" % (tb + (nkk - 1) + kk - 1)
@@ -126,8 +127,17 @@ def gen(c):
                     emit("v_cvt_f64_f32 %[t64], %[t0]")
                     emit("v_add_f64 %%[cs%d], %%[cs%d], %%[t64]" % (i, i))
         if c.var >= 1:
-            for i in range(4):
-                emit("%s %s, %s, %s" % ("v_mul_f64" if c.f64 else "v_mul_f32", A(s, i), A(s, i), W(s)))
+            if c.f64:
+                for i in range(4):
+                    emit("v_mul_f64 %s, %s, %s" % (A(s, i), A(s, i), W(s)))
+            else:
+                # fp32: the four A fragments of a k-step are two aligned register pairs -- two packed multiplies (the
+                # weight's low half for both halves) instead of four scalar ones: every VALU instruction beside the MFMA
+                # stream costs its issue cycles, and an fp32 k-step is only 512 cycles of MFMAs
+                for i in (0, 2):
+                    pair = "v[%d:%d]" % (96 + 8 * s + i, 96 + 8 * s + i + 1)
+                    wp = "v[%d:%d]" % (tb + 2 * s, tb + 2 * s + 1)
+                    emit("v_pk_mul_f32 %s, %s, %s op_sel_hi:[1,0]" % (pair, pair, wp))
             emit("s_nop 1")
         for i in range(4):
             for j in range(4):
