@@ -608,9 +608,12 @@ constexpr int PANEL_LDS = (36 + 8) * MB * MB * 8;
 // With an identity right-hand side Y carried along (potrf_upper_blocked with Yinv), workgroups beyond the panel's own
 // solve block row j of Y the same way: Y[j, c] <- U_jj^-T Y[j, c] for the column blocks c <= j that are non-zero, so that
 // Y ends as U^-T and the separate triangular inversion goes away.
+// Round 5: Y is never initialised and never transposed by launches of its own -- the block that starts as the identity
+// (column block j of block row j) is not loaded, a block of Y is written back only while a later step reads it, and every
+// solved block goes out a second time, transposed, as block (c, j) of X = U^-1 (X == null: Y is kept, X is not formed).
 __global__ __launch_bounds__(256) void potrf_panel_kernel(double* __restrict__ A, int mp, int j,
                                                           const double* __restrict__ dmicro,
-                                                          double* __restrict__ Y) {
+                                                          double* __restrict__ Y, double* __restrict__ X) {
   extern __shared__ __attribute__((aligned(16))) double L[];  // [36][16][16] blocks (i <= b) of U_jj, then [8][16][16] D_b
   double* Dm = L + 36 * MB * MB;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -631,20 +634,30 @@ __global__ __launch_bounds__(256) void potrf_panel_kernel(double* __restrict__ A
   const int c0 = rhs ? ((int)blockIdx.x - na) * 64 + wid * 16 : (j + 1) * NB + blockIdx.x * 64 + wid * 16;
   double* Ap = (rhs ? Y : A) + (int64_t)j * NB * mp + c0 + l15;
   pd4 T[8];
+  const bool ident = rhs && X && c0 >= j * NB;  // (this block of Y is the identity so far)
 #pragma unroll
   for (int b = 0; b < 8; ++b)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) T[b][r] = Ap[(int64_t)(16 * b + lq + 4 * r) * mp];
+    for (int r = 0; r < 4; ++r)
+      T[b][r] = ident ? ((16 * b + lq + 4 * r == c0 - j * NB + l15) ? 1.0 : 0.0) : Ap[(int64_t)(16 * b + lq + 4 * r) * mp];
   __syncthreads();
   const int fo = lq * 16 + l15;  // fragment element of k-step r: [(lq + 4r)][l15] -> fo + 64 r
+  const bool keep = !(rhs && X) || j + 1 < mp / NB;  // (the last block row of Y is read by nobody)
   int blk = 0;
 #pragma unroll
   for (int b = 0; b < 8; ++b) {
     pd4 x = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
     for (int r = 0; r < 4; ++r) x = mfma_f64(Dm[b * 256 + fo + 64 * r], T[b][r], x);
+    if (keep) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) Ap[(int64_t)(16 * b + lq + 4 * r) * mp] = x[r];
+      for (int r = 0; r < 4; ++r) Ap[(int64_t)(16 * b + lq + 4 * r) * mp] = x[r];
+    }
+    if (rhs && X) {
+      double* Xp = X + (int64_t)(c0 + l15) * mp + (int64_t)j * NB + 16 * b + lq;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) Xp[4 * r] = x[r];
+    }
     ++blk;  // block (b, b) itself
 #pragma unroll
     for (int b2 = b + 1; b2 < 8; ++b2, ++blk)
@@ -665,7 +678,7 @@ __global__ __launch_bounds__(256) void potrf_panel_kernel(double* __restrict__ A
 // r > j and the column blocks c <= j (nsym = number of symmetric sub-tiles; Y may be null).
 template <bool ALL>
 __device__ __forceinline__ void potrf_update_body(double* __restrict__ A, int mp, int j, double* __restrict__ Y,
-                                                  int sym_lo, int sym_cnt, int y_lo) {
+                                                  int sym_lo, int sym_cnt, int y_lo, double* __restrict__ Xz) {
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int l15 = lane & 15, lq = lane >> 4;
   const int ns = (mp / NB - 1 - j) * 2;
@@ -674,6 +687,7 @@ __device__ __forceinline__ void potrf_update_body(double* __restrict__ A, int mp
   int64_t r0, c0;
   const double* Xb;
   double* Cp;
+  bool first = false;
   // the launch covers sub-tiles sym_lo .. sym_lo + sym_cnt - 1 of the symmetric list and the tiles of Y from y_lo on (a
   // whole step: 0, all, 0; the look-ahead split of potrf_upper_blocked: the two lists' prefixes = block row j + 1 first)
   if ((int)blockIdx.x < sym_cnt) {
@@ -693,6 +707,8 @@ __device__ __forceinline__ void potrf_update_body(double* __restrict__ A, int mp
     c0 = (int64_t)(t % ncb) * 64 + (wid & 1) * 32;
     Xb = Y + (int64_t)(j * NB + lq) * mp + c0 + l15;
     Cp = Y + (r0 + lq) * mp + c0 + l15;
+    // first touch of this tile of Y (column block j, Xz given: Y is not initialised by a launch of its own): it starts as zero
+    first = Xz != nullptr && c0 >= (int64_t)j * NB;
   }
   const double* Xa = X + (int64_t)lq * mp + r0 + l15;
   pd4 acc[2][2];
@@ -701,7 +717,7 @@ __device__ __forceinline__ void potrf_update_body(double* __restrict__ A, int mp
 #pragma unroll
     for (int jj = 0; jj < 2; ++jj)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) acc[i][jj][r] = Cp[(int64_t)(16 * i + 4 * r) * mp + 16 * jj];
+      for (int r = 0; r < 4; ++r) acc[i][jj][r] = first ? 0.0 : Cp[(int64_t)(16 * i + 4 * r) * mp + 16 * jj];
   if constexpr (ALL) {
     double av[NB / 4][2], bv[NB / 4][2];
 #pragma unroll
@@ -737,30 +753,23 @@ __device__ __forceinline__ void potrf_update_body(double* __restrict__ A, int mp
     for (int jj = 0; jj < 2; ++jj)
 #pragma unroll
       for (int r = 0; r < 4; ++r) Cp[(int64_t)(16 * i + 4 * r) * mp + 16 * jj] = acc[i][jj][r];
+  if (first) {  // ... and the block of U^-1 below the diagonal that mirrors it is zero
+    double* Zp = Xz + (r0 + lq) * mp + c0 + l15;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Zp[(int64_t)(16 * i + 4 * r) * mp + 16 * jj] = 0.0;
+  }
 }
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) void potrf_update_all_kernel(
-    double* __restrict__ A, int mp, int j, double* __restrict__ Y, int sym_lo, int sym_cnt, int y_lo) {
-  potrf_update_body<true>(A, mp, j, Y, sym_lo, sym_cnt, y_lo);
+    double* __restrict__ A, int mp, int j, double* __restrict__ Y, int sym_lo, int sym_cnt, int y_lo, double* __restrict__ Xz) {
+  potrf_update_body<true>(A, mp, j, Y, sym_lo, sym_cnt, y_lo, Xz);
 }
-__global__ __launch_bounds__(256) void potrf_update_kernel(double* __restrict__ A, int mp, int j,
-                                                           double* __restrict__ Y, int sym_lo, int sym_cnt, int y_lo) {
-  potrf_update_body<false>(A, mp, j, Y, sym_lo, sym_cnt, y_lo);
-}
-
-// Y = identity (the right-hand side carried through the factorisation), and the final X = Y^T
-__global__ void set_identity_kernel(double* __restrict__ Y, int mp) {
-  const int c = blockIdx.x * 256 + threadIdx.x, r = blockIdx.y;
-  if (c < mp) Y[(int64_t)r * mp + c] = (r == c) ? 1.0 : 0.0;
-}
-__global__ __launch_bounds__(256) void transpose_kernel(const double* __restrict__ Y, int mp, double* __restrict__ X) {
-  __shared__ double t[32][33];
-  const int bx = blockIdx.x * 32, by = blockIdx.y * 32;
-  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
-#pragma unroll
-  for (int i = 0; i < 32; i += 8) t[ty + i][tx] = Y[(int64_t)(by + ty + i) * mp + bx + tx];
-  __syncthreads();
-#pragma unroll
-  for (int i = 0; i < 32; i += 8) X[(int64_t)(bx + ty + i) * mp + by + tx] = t[tx][ty + i];
+__global__ __launch_bounds__(256) void potrf_update_kernel(double* __restrict__ A, int mp, int j, double* __restrict__ Y,
+                                                           int sym_lo, int sym_cnt, int y_lo, double* __restrict__ Xz) {
+  potrf_update_body<false>(A, mp, j, Y, sym_lo, sym_cnt, y_lo, Xz);
 }
 
 __global__ void zero_strict_lower_kernel(double* __restrict__ A, int mp) {
@@ -1224,13 +1233,16 @@ void potrf_upper_blocked(hipStream_t s, double* A, int mp, double* dinv, int* in
     throw HipFail{ST_BAD_ARG};
   }
   double* const Y = Xinv ? Yscratch : nullptr;
-  if (Y) hipLaunchKernelGGL(set_identity_kernel, dim3((mp + 255) / 256, mp), dim3(256), 0, s, Y, mp);
+  // (round 5: no launch sets Y to the identity and none transposes it at the end -- 5 us each on the chain of every
+  // factorisation: the panel kernel starts the diagonal blocks of Y from the identity and writes every solved block
+  // straight into X = U^-1, transposed; the update kernel's first touch of a tile of Y starts from zero and clears the
+  // mirrored tile of X)
   auto update = [&](hipStream_t st, int j, int sym_lo, int sym_cnt, int y_lo, int y_cnt, int step_tiles) {
     if (sym_cnt + y_cnt <= 0) return;
     if (step_tiles <= all_tiles)
-      hipLaunchKernelGGL(potrf_update_all_kernel, dim3(sym_cnt + y_cnt), dim3(256), 0, st, A, mp, j, Y, sym_lo, sym_cnt, y_lo);
+      hipLaunchKernelGGL(potrf_update_all_kernel, dim3(sym_cnt + y_cnt), dim3(256), 0, st, A, mp, j, Y, sym_lo, sym_cnt, y_lo, Xinv);
     else
-      hipLaunchKernelGGL(potrf_update_kernel, dim3(sym_cnt + y_cnt), dim3(256), 0, st, A, mp, j, Y, sym_lo, sym_cnt, y_lo);
+      hipLaunchKernelGGL(potrf_update_kernel, dim3(sym_cnt + y_cnt), dim3(256), 0, st, A, mp, j, Y, sym_lo, sym_cnt, y_lo, Xinv);
   };
   // Look-ahead (round 5; built, measured, off by default -- see la_min above).  The next diagonal block, the next panel and the next step's share of Y read block row j + 1
   // of the trailing update only -- the first 2 ns - 1 sub-tiles of its symmetric list and the first two sub-tile rows of
@@ -1245,7 +1257,7 @@ void potrf_upper_blocked(hipStream_t s, double* A, int mp, double* dinv, int* in
     const int rest = nb - 1 - j, ns = 2 * rest;
     const int nrhs = Y ? 2 * (j + 1) : 0;  // 64-column groups of the right-hand side that are non-zero in block row j
     if (rest + nrhs > 0)
-      hipLaunchKernelGGL(potrf_panel_kernel, dim3(2 * rest + nrhs), dim3(256), PANEL_LDS, s, A, mp, j, dj, Y);
+      hipLaunchKernelGGL(potrf_panel_kernel, dim3(2 * rest + nrhs), dim3(256), PANEL_LDS, s, A, mp, j, dj, Y, Xinv);
     if (rest > 0) {
       const int nsym = ns * (ns + 1) / 2, ny = ns * nrhs, tiles = nsym + ny;
       const int csym = std::min(nsym, 2 * ns - 1), cy = std::min(ny, 2 * nrhs);  // block row j + 1
@@ -1267,8 +1279,7 @@ void potrf_upper_blocked(hipStream_t s, double* A, int mp, double* dinv, int* in
     }
   }
   if (pending) GPR_HIP(hipStreamWaitEvent(s, aux->ev_rest[(nb - 2) & 1], 0));
-  if (Y) hipLaunchKernelGGL(transpose_kernel, dim3(mp / 32, mp / 32), dim3(256), 0, s, Y, mp, Xinv);
-  else hipLaunchKernelGGL(potrf_diag_kernel, dim3(nb), dim3(PT), POTRF_LDS, s, A, mp, 0, dinv, info, 1, m_real);
+  if (!Y) hipLaunchKernelGGL(potrf_diag_kernel, dim3(nb), dim3(PT), POTRF_LDS, s, A, mp, 0, dinv, info, 1, m_real);
   GPR_HIP(hipGetLastError());
 }
 
