@@ -1209,14 +1209,11 @@ void potrf_upper_blocked(hipStream_t s, double* A, int mp, double* dinv, int* in
     const char* e = getenv("GPRHIP_POTRF_ALL_TILES");
     return e ? atoi(e) : 768;
   }();
-  // smallest rest of a step (sub-tiles outside block row j + 1) that goes to the side stream (GPRHIP_POTRF_LOOKAHEAD; 0 = never,
-  // the default: measured SLOWER than one stream -- m = 2048: 946 against 856 us, m = 1024: 441 against 384 us,
-  // tools/potrf_check, profiles/r05_potrf_lookahead.txt -- the two cross-stream event waits of a step cost more than the
-  // part of the update they take off the chain)
-  static const int la_min = [] {
-    const char* e = getenv("GPRHIP_POTRF_LOOKAHEAD");
-    return e ? atoi(e) : 0;
-  }();
+  // aux->min_rest: smallest rest of a step (sub-tiles outside block row j + 1) that goes to the side stream; 0 / no aux =
+  // never, the library's default: measured SLOWER than one stream -- m = 2048: 946 against 856 us, m = 1024: 441 against
+  // 384 us, tools/potrf_check, profiles/r05_potrf_lookahead.txt -- the two cross-stream event waits of a step cost more
+  // than the part of the update they take off the chain
+  const int la_min = aux ? aux->min_rest : 0;
   const int nb = mp / NB;
   if (nb == 1) {  // a single block: factor and inverse in one launch
     // (a single block's inverse, [128][128], IS the mp x mp inverse: written straight to Xinv)

@@ -1794,6 +1794,7 @@ int gprhip_problem_create_ex(int device, int cov_kind, int precision, int64_t n,
     GPR_HIP(hipStreamCreate(&p->stream));
     GPR_HIP(hipStreamCreate(&p->stream2));
     if (p->mp >= 3 * TILE && getenv("GPRHIP_POTRF_LOOKAHEAD") && atoi(getenv("GPRHIP_POTRF_LOOKAHEAD")) > 0) {  // (A/B runs only)
+      p->potrf_aux.min_rest = atoi(getenv("GPRHIP_POTRF_LOOKAHEAD"));
       GPR_HIP(hipStreamCreate(&p->potrf_aux.side));
       for (int k = 0; k < 2; ++k) {
         GPR_HIP(hipEventCreateWithFlags(&p->potrf_aux.ev_panel[k], hipEventDisableTiming));

@@ -59,6 +59,7 @@ void launch_potrf_diag_flags(double* A, int mp, int j, double* dinv, int* info, 
 // diagonal block does not need then runs on the side stream beside that block's factorisation (look-ahead).
 struct PotrfAux {
   hipStream_t side = nullptr;
+  int min_rest = 0;  // steps whose update has at least this many sub-tiles outside block row j + 1 use the side stream (0: none)
   hipEvent_t ev_panel[2] = {nullptr, nullptr}, ev_rest[2] = {nullptr, nullptr};
 };
 void potrf_upper_blocked(hipStream_t s, double* A, int mp, double* dinv, int* info, double* Yscratch = nullptr,

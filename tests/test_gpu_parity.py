@@ -1423,6 +1423,34 @@ def test_two_phase_and_two_launch_x_products_agree(name, monkeypatch):
     assert relinf(res["2"].grad, res["0"].grad) <= (1e-8 if name.startswith("illcond") else 1e-10)
 
 
+@pytest.mark.parametrize("m", [300, 700])
+def test_opt_in_factorisation_variants_are_bit_identical(m, monkeypatch):
+    """Round 5 built two alternatives to the three-launches-per-step factorisation of K_m + jitter and B~ (chol.hip):
+    ONE persistent launch with device-side dependencies (GPRHIP_POTRF_CHAIN=1) and a look-ahead split of every step's
+    trailing update over two streams (GPRHIP_POTRF_LOOKAHEAD=n).  Both measured slower and stay off (DESIGN section 4,
+    "Round 5"), but they apply the same tile updates in the same order: whole evaluations through them return the very
+    same numbers as the default path (both switches are read when the problem is created)."""
+    n, d = 4000, 5
+    X, y, Z = synth(900 + m, n, m, d)
+    kw = dict(log_ell=0.5 * np.log(d), log_sf2=0.1, sigma2=0.05, inducing=Z)
+    res = {}
+    for tag, env in (("default", {}), ("chain", {"GPRHIP_POTRF_CHAIN": "1"}), ("lookahead", {"GPRHIP_POTRF_LOOKAHEAD": "1"})):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        p = gpr_amd.Problem(gpr_amd.COV_SE_ISO, n, d, d, m)
+        p.set_inputs(X)
+        p.set_targets(y)
+        res[tag] = p.eval(**kw)
+        p.close()
+        for k in env:
+            monkeypatch.delenv(k)
+    ref = O.evaluate_fast(O.SeIsoKernel(kw["log_ell"], kw["log_sf2"]), Z, X, y, kw["sigma2"])
+    assert abs(res["default"].l - ref["l"]) <= TOL_L * abs(ref["l"])
+    for tag in ("chain", "lookahead"):
+        assert res[tag].l == res["default"].l and res[tag].dl_dsigma2 == res["default"].dl_dsigma2, tag
+        assert np.array_equal(res[tag].grad, res["default"].grad) and np.array_equal(res[tag].coeffs, res["default"].coeffs), tag
+
+
 @pytest.mark.parametrize("n,m,d,log_ell,tol", [(2630, 176, 1, -0.0496, 3e-7), (2034, 432, 1, -0.1, 3e-7),
                                                 (3000, 540, 4, 0.55, 2e-8), (3488, 171, 32, 1.8, 1e-12)])
 def test_mean_coefficients_against_an_80_bit_evaluation(n, m, d, log_ell, tol):

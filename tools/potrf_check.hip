@@ -117,6 +117,7 @@ int main() {
     }
     {  // the same with the look-ahead split of the trailing update (side stream): timing, and the results below are its
       PotrfAux aux;
+      aux.min_rest = getenv("LOOKAHEAD") ? atoi(getenv("LOOKAHEAD")) : 24;
       hipStream_t ms;  // (not the null stream: it synchronises with every other stream)
       hipStreamCreateWithFlags(&ms, hipStreamNonBlocking);
       hipStreamCreateWithFlags(&aux.side, hipStreamNonBlocking);
