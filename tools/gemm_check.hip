@@ -462,7 +462,8 @@ int main() {
     return 0;
   }
   if (getenv("TS")) {
-    timestamps(OP_NN, 131072, 2048, 2048, TRI_KHI_BN, getenv("TS_OUT") ? getenv("TS_OUT") : "ts_nn.bin");
+    const int tm = getenv("TS_M") ? atoi(getenv("TS_M")) : 131072, tn = getenv("TS_N") ? atoi(getenv("TS_N")) : 2048;  // rows (a multiple of 128), m
+    timestamps(OP_NN, tm, tn, tn, TRI_KHI_BN, getenv("TS_OUT") ? getenv("TS_OUT") : "ts_nn.bin");
     return 0;
   }
   if (getenv("PEAK")) {
