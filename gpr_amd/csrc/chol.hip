@@ -462,47 +462,50 @@ __device__ __forceinline__ void potrf_diag_body(double* __restrict__ A, int mp, 
     }
   }
   if (!(flags & 2) && !carry) {
-    // block column b of the inverse, in place (LAPACK dtrtri order): wavefront ri < b owns the 16x16 tile (ri, b):
-    //   T1 = sum_{kt=ri}^{b-1} X(ri,kt) U(kt,b)   (X = the already inverted leading block; 4 MFMAs per kt)
-    //   X(ri,b) = -T1 D_b                           (T1 re-laid out as an A operand through the wave's LDS scratch)
-    // wavefront b copies D_b onto the diagonal tile.  All reads of U(.,b) finish before the first write.
+    // X = U^-1 in place, all eight block columns at once (round 5; the dtrtri order of rounds 1-4 walked them one after
+    // the other, two barriers each: 12 us).  Wavefront c owns block column c and solves it upwards by back substitution on
+    // the micro inverses:  X_cc = D_c,   X_bc = -D_b sum_{b < k <= c} U_bk X_kc   (b = c - 1 .. 0),
+    // its tiles held in registers -- an accumulator tile is the B operand of the next product as it stands (rows q + 4r in
+    // register r), the A operands (U_bk, D_b from LDS) are indexed to match.  The longest column is 36 tile products
+    // (3.8 us of MFMAs); U is overwritten only after every wavefront has read what it needs.
     const int l15 = lane & 15, lq = lane >> 4;
-    // (block columns wholly in the padding are already their own inverse: zero above a unit diagonal block)
-    for (int b = 0; b < k_end / MB; ++b) {
-      const double* D = dblk(T, b);
-      const int cb = b * MB;
-      pd4 t1 = {0.0, 0.0, 0.0, 0.0};
-      if (wid < b) {
-        const int rb = wid * MB;
-        for (int kt = wid; kt < b; ++kt) {
+    const int c = wid, nblk = k_end / MB;
+    pd4 xs[8];
+    if (c < nblk) {  // (block columns wholly in the padding are already their own inverse)
 #pragma unroll
-          for (int kk = 0; kk < 4; ++kk) {
-            const int k = kt * MB + 4 * kk + lq;
-            t1 = mfma_f64(T[(rb + l15) * LDT + k], T[k * LDT + cb + l15], t1);
-          }
+      for (int bb = 7; bb >= 0; --bb) {
+        if (bb > c) continue;
+        if (bb == c) {
+          const double* D = dblk(T, bb);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) xs[bb][r] = D[(lq + 4 * r) * LDT + l15];
+          continue;
         }
-        double* scr = T1 + wid * (MB * MB);   // [16][16] per wavefront
+        pd4 t = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-        for (int r = 0; r < 4; ++r) scr[(lq + 4 * r) * MB + l15] = t1[r];
-      }
-      __syncthreads();
-      if (wid < b) {
-        const int rb = wid * MB;
-        const double* scr = T1 + wid * (MB * MB);
+        for (int k = 7; k > bb; --k) {
+          if (k > c) continue;
+          const double* Ub = T + (bb * MB + l15) * LDT + k * MB + lq;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) t = mfma_f64(Ub[4 * r], xs[k][r], t);
+        }
+        const double* D = dblk(T, bb) + l15 * LDT + lq;
         pd4 x = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-          const int k = 4 * kk + lq;
-          x = mfma_f64(-scr[l15 * MB + k], D[k * LDT + l15], x);
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) T[(rb + lq + 4 * r) * LDT + cb + l15] = x[r];
-      } else if (wid == b) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) T[(cb + lq + 4 * r) * LDT + cb + l15] = D[(lq + 4 * r) * LDT + l15];
+        for (int r = 0; r < 4; ++r) x = mfma_f64(-D[4 * r], t[r], x);
+        xs[bb] = x;
       }
-      __syncthreads();
     }
+    __syncthreads();
+    if (c < nblk) {
+#pragma unroll
+      for (int bb = 0; bb < 8; ++bb) {
+        if (bb > c) continue;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) T[(bb * MB + lq + 4 * r) * LDT + c * MB + l15] = xs[bb][r];
+      }
+    }
+    __syncthreads();
   }
   if (flags & 2) return;
   for (int idx = tid; idx < NB * NB / 2; idx += PT) {
