@@ -227,6 +227,9 @@ struct gprhip_problem {
   }
   int ks_used = 8;
   int64_t slice_rows = 8192;  // training points per split-K slice of the SYRK launches (both precisions)
+  // training points per workgroup of the gradient kernels (grad_slab_rows: 256 or 1024), halved down to 64 while the launch
+  // would leave most of the chip idle (n = 2000, m = 128: 8 workgroups of 256 rows took 30 us; set at creation)
+  int grad_slab = 256;
   int tile_order = 3;  // block -> tile order of the chunk GEMMs (mfma_gemm.hip tile_of_block): paired column tiles, XCD-local groups
   int grad_scalar = 0;  // GPRHIP_GRAD_SCALAR: use the scalar gradient kernel even where the MFMA one applies
   // Cov_se_fat `Proj hypers: rows of the exchange-2 column block beyond d+1, and the D x d second term
@@ -947,7 +950,7 @@ void do_pass2(gprhip_problem* p, const double* ar1, double* ar2) {
       ga.ms = p->cp.ms; ga.rowes = nullptr; ga.shift = p->zshift;
       ga.K = (p->Kstore && p->have_k && proj && !ga.ms) ? static_cast<const TS*>(p->Kstore) + base * mp : nullptr;
       ga.col_rows = p->d + 1 + ga.D + (ga.ms ? p->d : 0);  // rows this launch produces (tightly packed)
-      ga.slab = grad_slab_rows((int)p->col_rows());
+      ga.slab = p->grad_slab;
       const int nslots = 4 * ((mp + 255) / 256);
       if (ga.ms && proj) {
         if (!p->rowes) {
@@ -1867,7 +1870,10 @@ int gprhip_problem_create_ex(int device, int cov_kind, int precision, int64_t n,
     p->slices = p->alloc<char>(p->slices_bytes);
     p->rowpart = p->alloc<double>((int64_t)pass1_row_blocks((int)chunk) * 4);
     p->gemvpart = p->alloc<double>((int64_t)p->kslices * mp);  // c~ partials, one row per k-slice
-    const int64_t gslab = grad_slab_rows((int)p->col_rows());
+    p->grad_slab = grad_slab_rows((int)p->col_rows());
+    while (p->grad_slab > 64 && ((n + p->grad_slab - 1) / p->grad_slab) * (int64_t)(mp / TILE) < 256) p->grad_slab /= 2;
+    if (const char* e = getenv("GPRHIP_GRAD_SLAB")) p->grad_slab = std::max(64, atoi(e) / 64 * 64);
+    const int64_t gslab = p->grad_slab;
     const int64_t nslab = (chunk + gslab - 1) / gslab;
     p->colpart = p->alloc<double>(nslab * p->col_rows() * mp);
     p->scalpart = p->alloc<double>(nslab * (mp / TILE) * 2);
