@@ -1394,4 +1394,43 @@ void launch_triu_matvec(const double* A, int mp, const double* x, double* y, int
   GPR_HIP(hipGetLastError());
 }
 
+// The same product with a rider: one more workgroup of the launch forms a scalar that would otherwise be a 5 us launch of
+// its own on the latency chain between the B~ factorisation and the Q' products --
+//   rider 1: rout[0] = 2 sum_{i < rn} log rA[i (mp + 1)]   (log determinant from a factor's diagonal, lib/utils.ml:95-101)
+//   rider 2: rout[0] = sum_{i < rn} rA[i]^2                 (|b|^2 of a vector an EARLIER launch finished)
+__global__ __launch_bounds__(256) void triu_matvec_rider_kernel(const double* __restrict__ A, int mp,
+                                                                const double* __restrict__ x, double* __restrict__ y,
+                                                                int trans, int rider, const double* __restrict__ rA, int rn,
+                                                                double* __restrict__ rout) {
+  if (blockIdx.x == gridDim.x - 1) {
+    __shared__ double red[256];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < rn; i += 256) s += rider == 1 ? log(rA[(int64_t)i * (mp + 1)]) : rA[i] * rA[i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+      if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) rout[0] = rider == 1 ? red[0] + red[0] : red[0];
+    return;
+  }
+  const int lane = threadIdx.x & 63;
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= mp) return;
+  double s = 0.0;
+  if (!trans) {
+    for (int k = i + lane; k < mp; k += 64) s += A[(int64_t)i * mp + k] * x[k];
+  } else {
+    for (int k = lane; k <= i; k += 64) s += A[(int64_t)k * mp + i] * x[k];
+  }
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  if (lane == 0) y[i] = s;
+}
+void launch_triu_matvec_rider(const double* A, int mp, const double* x, double* y, int trans, int rider, const double* rA,
+                              int rn, double* rout, hipStream_t s) {
+  hipLaunchKernelGGL(triu_matvec_rider_kernel, dim3((mp + 3) / 4 + 1), dim3(256), 0, s, A, mp, x, y, trans, rider, rA, rn, rout);
+  GPR_HIP(hipGetLastError());
+}
+
 }  // namespace gprhip

@@ -802,7 +802,6 @@ void do_pass2(gprhip_problem* p, const double* ar1, double* ar2) {
     hipLaunchKernelGGL(add_identity_upper_kernel, dim3((mp + 255) / 256, mp), dim3(256), 0, s, ar1, mp,
                        p->bmat);
     potrf_trtri(p, p->bmat, p->rinv, p->wmat, p->info + 1);
-    launch_logdet(p->bmat, mp, mp, p->scal + SC_LOGDET_B, s);
   }
   if (p->f32) launch_to_float(p->rinv, p->rinv_f, mm, s);
   TS* const Vstore = static_cast<TS*>(p->Vstore);
@@ -811,10 +810,10 @@ void do_pass2(gprhip_problem* p, const double* ar1, double* ar2) {
   TS* const slices = static_cast<TS*>(p->slices);
   // b = R~^-T c~ (= Q_n^T y~, lib/fitc_gp.ml:285-286);  t~ = R~^-1 b;  t = U^-1 t~ (trsv, :291 / :1167)
   if (!fused_b) {
-    launch_triu_matvec(p->rinv, mp, ar1_c, p->bvec, 1, s);
-    launch_triu_matvec(p->rinv, mp, p->bvec, p->ttil, 0, s);
+    // (log|B~| and |b|^2 ride on the first two launches: two launches less on the chain)
+    launch_triu_matvec_rider(p->rinv, mp, ar1_c, p->bvec, 1, 1, p->bmat, mp, p->scal + SC_LOGDET_B, s);
+    launch_triu_matvec_rider(p->rinv, mp, p->bvec, p->ttil, 0, 2, p->bvec, mp, p->scal + SC_BB, s);
     launch_triu_matvec(p->uinv, mp, p->ttil, p->tvec, 0, s);
-    hipLaunchKernelGGL(dot_kernel, dim3(1), dim3(256), 0, s, p->bvec, p->bvec, mp, p->scal + SC_BB);
   }
   tstop(p);
 

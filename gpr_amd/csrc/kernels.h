@@ -112,6 +112,9 @@ void launch_logdet(const double* A, int mp, int m, double* out, hipStream_t s);
 // y = op(A) x for an upper-triangular row-major mp x mp A; trans=0: y_i = sum_{k>=i} A[i][k] x_k,
 // trans=1: y_i = sum_{k<=i} A[k][i] x_k.
 void launch_triu_matvec(const double* A, int mp, const double* x, double* y, int trans, hipStream_t s);
+// ... with one more workgroup that forms a scalar on the side: rider 1: rout = 2 sum_{i<rn} log rA[i (mp+1)]; 2: sum_{i<rn} rA[i]^2
+void launch_triu_matvec_rider(const double* A, int mp, const double* x, double* y, int trans, int rider, const double* rA,
+                              int rn, double* rout, hipStream_t s);
 
 // ---- row kernels (rowops.hip)
 struct Pass1RowArgs {
