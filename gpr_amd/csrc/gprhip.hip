@@ -118,6 +118,10 @@ struct gprhip_problem {
   hipStream_t stream2 = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   hipEvent_t ev_rf = nullptr, ev_binv = nullptr;  // pass 2: R^-1 and B~^-1 come from the second stream (do_pass2)
+  // GPRHIP_COV_OVERLAP (read at creation): the covariance of row chunk c + 1 is built on the second stream beside the
+  // V = K U^-1 product of chunk c (the two chunk buffers alternate in pass 1) instead of in front of its own product
+  int cov_overlap = 0;
+  hipEvent_t ev_cov[2] = {nullptr, nullptr}, ev_vdone[2] = {nullptr, nullptr};
   // third stream + events: look-ahead of the blocked factorisation (chol.hip, potrf_upper_blocked) -- a stream of its own,
   // because stream2 carries the first row chunk's covariance beside the K_m factorisation
   PotrfAux potrf_aux{};
@@ -707,15 +711,31 @@ void do_pass1(gprhip_problem* p, const gprhip_hypers* h, int want_grad, int64_t 
       return;
     }
   }
+  // Overlap (GPRHIP_COV_OVERLAP=1): chunk c + 1's covariance goes out on the second stream just before chunk c's V product
+  // goes out on the main one, into the other chunk buffer (pass 1 uses one of the two at a time) -- it waits only for the V
+  // product that last read that buffer, i.e. it runs beside V(c).
+  const bool overlap = p->cov_overlap && cov0_ahead && p->nchunks >= 2;
+  TS* const bufB1 = static_cast<TS*>(p->bufB);
+  auto kbuf = [&](int c) -> TS* {
+    if (Kstore) return Kstore + (int64_t)c * p->chunk * mp;
+    return (overlap && (c & 1)) ? bufB1 : bufA;
+  };
   for (int c = 0; c < p->nchunks; ++c) {
     const int64_t rows = p->rows_of(c);
     const int rows_p = (int)round_up(rows, TILE);
     const int64_t base = (int64_t)c * p->chunk;
     TS* V = Vstore + base * mp;
-    TS* const Kc = Kstore ? Kstore + base * mp : bufA;  // this chunk's K_nm: kept, or in the chunk buffer
+    TS* const Kc = kbuf(c);  // this chunk's K_nm: kept, or in a chunk buffer
     if (!reuse) {
       tstart(p, "p1_cov");
-      if (c == 0 && cov0_ahead) GPR_HIP(hipStreamWaitEvent(s, p->ev_join, 0));
+      if (overlap) {
+        if (c + 1 < p->nchunks) {
+          if (c >= 1 && !Kstore) GPR_HIP(hipStreamWaitEvent(p->stream2, p->ev_vdone[(c - 1) & 1], 0));
+          cov_chunk<TS>(p, c + 1, kbuf(c + 1), p->stream2);
+          GPR_HIP(hipEventRecord(p->ev_cov[(c + 1) & 1], p->stream2));
+        }
+        GPR_HIP(hipStreamWaitEvent(s, c == 0 ? p->ev_join : p->ev_cov[c & 1], 0));
+      } else if (c == 0 && cov0_ahead) GPR_HIP(hipStreamWaitEvent(s, p->ev_join, 0));
       else cov_chunk<TS>(p, c, Kc);
       tstop(p);
       tstart(p, "p1_trmm_V");
@@ -724,6 +744,7 @@ void do_pass1(gprhip_problem* p, const gprhip_hypers* h, int want_grad, int64_t 
       g.M = rows_p; g.N = mp; g.K = mp; g.tri = TRI_KHI_BN; g.order = p->tile_order;
       g.rp_sumsq = p->rp1;  // r = k_diag - rowsum(V.^2) comes out of the epilogue (Mat.syrk_diag, :222-223)
       launch_gemm(OP_NN, g, s);
+      if (overlap) GPR_HIP(hipEventRecord(p->ev_vdone[c & 1], s));
       tstop(p);
     }
     tstart(p, "p1_rows");
@@ -1795,6 +1816,11 @@ int gprhip_problem_create_ex(int device, int cov_kind, int precision, int64_t n,
     if (const char* e = getenv("GPRHIP_POTRF_CHAIN")) p->potrf_chain_mode = atoi(e);
     GPR_HIP(hipStreamCreate(&p->stream));
     GPR_HIP(hipStreamCreate(&p->stream2));
+    if (const char* e = getenv("GPRHIP_COV_OVERLAP")) p->cov_overlap = atoi(e);
+    for (int k = 0; k < 2; ++k) {
+      GPR_HIP(hipEventCreateWithFlags(&p->ev_cov[k], hipEventDisableTiming));
+      GPR_HIP(hipEventCreateWithFlags(&p->ev_vdone[k], hipEventDisableTiming));
+    }
     if (p->mp >= 3 * TILE && getenv("GPRHIP_POTRF_LOOKAHEAD") && atoi(getenv("GPRHIP_POTRF_LOOKAHEAD")) > 0) {  // (A/B runs only)
       p->potrf_aux.min_rest = atoi(getenv("GPRHIP_POTRF_LOOKAHEAD"));
       GPR_HIP(hipStreamCreate(&p->potrf_aux.side));
@@ -1904,6 +1930,10 @@ void gprhip_problem_destroy(gprhip_problem* p) {
   if (p->ev_join) hipEventDestroy(p->ev_join);
   if (p->ev_rf) hipEventDestroy(p->ev_rf);
   if (p->ev_binv) hipEventDestroy(p->ev_binv);
+  for (int k = 0; k < 2; ++k) {
+    if (p->ev_cov[k]) hipEventDestroy(p->ev_cov[k]);
+    if (p->ev_vdone[k]) hipEventDestroy(p->ev_vdone[k]);
+  }
   if (p->potrf_aux.side) {
     hipStreamSynchronize(p->potrf_aux.side);
     hipStreamDestroy(p->potrf_aux.side);
