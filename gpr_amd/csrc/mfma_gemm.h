@@ -45,6 +45,10 @@ struct GemmArgsT {
   int upper_only = 0;    // compute only tiles with row tile <= column tile
   int order = 0;         // block -> tile order of full grids (see tile_of_block)
   int ipw = 1;           // items per workgroup (set by launch_gemm: 2 for the paired order 3)
+  // set by launch_gemm with ipw == 2: the first pair_split workgroups run column-tile PAIRS over the first M/128 - tail_panels row
+  // panels; the workgroups behind them run the SINGLE tiles of the last tail_panels row panels, longest k-range first -- short
+  // items at the end of the launch fill the slots the last round of equal-length pairs would leave idle
+  int pair_split = 0, tail_panels = 0;
   int desc2 = 0;         // set by launch_gemm (paired NN products with a triangular B): the second, short item of a pair walks
                          // its k-range downwards, so that the eight short items of a row panel read the same A block at the
                          // same time (GPRHIP_NN_DESC=0 switches it off)
