@@ -567,7 +567,10 @@ int pick_kslices(int mp, int64_t rows_p, int max_slices, int64_t slice_rows, boo
       if ((int64_t)ks * TILE > rows_p && ks > 8) break;  // at least 128 training points per slice
       const int items = items_of(ks);
       const int full = items / slots, rem = items % slots;
-      const double rounds = full + (rem == 0 ? 0.0 : (rem <= slots / 2 ? 0.55 : 1.0));
+      // a partly filled round behind full ones costs a whole round (the dispatcher refills CUs in pairs of slots as they fall
+      // free, so its workgroups still share their CUs: profiles/r05_ts_nn_m1024.txt); a launch that never fills the chip
+      // runs one workgroup per CU at nearly twice the speed
+      const double rounds = full + (rem == 0 ? 0.0 : (full == 0 && rem <= slots / 2 ? 0.55 : 1.0));
       const double t_item = t_fixed + (double)rows_p / ks * t_row;
       const double t_sum = (double)ks * tiles * TILE * TILE * (f64 ? 8.0 : 4.0) / 3.0e6;  // us at 3 TB/s
       const double t = rounds * t_item + t_sum;
