@@ -1289,6 +1289,7 @@ struct PotrfChain {
   ChainTask* tasks = nullptr;
 };
 
+void potrf_chain_destroy(PotrfChain* ch);
 // Task list of an nb-block factorisation with the carried inverse (host side; the order is explained at the kernel).
 PotrfChain* potrf_chain_create(int mp) {
   const int nb = mp / NB, n2 = 2 * nb;
@@ -1315,7 +1316,10 @@ PotrfChain* potrf_chain_create(int mp) {
     for (int R = j + 1; R < nb; ++R)
       for (int c64 = 0; c64 <= 2 * j + 1; ++c64) tasks.push_back({CT_UY, j, 2 * R, c64 | (2 << 16)});
   }
-  std::unique_ptr<PotrfChain> ch(new PotrfChain());
+  struct Free {  // (a failed allocation half-way must not leak the buffers before it)
+    void operator()(PotrfChain* c) const { potrf_chain_destroy(c); }
+  };
+  std::unique_ptr<PotrfChain, Free> ch(new PotrfChain());
   GPR_HIP(hipGetDevice(&ch->device));
   ch->mp = mp;
   ch->nb = nb;
