@@ -801,20 +801,6 @@ void launch_scatter_diag_blocks(const double* dinv, int mp, double* X, hipStream
   GPR_HIP(hipGetLastError());
 }
 
-__global__ __launch_bounds__(256) void logdet_kernel(const double* __restrict__ A, int mp, int m,
-                                                     double* __restrict__ out) {
-  __shared__ double red[256];
-  double s = 0.0;
-  for (int i = threadIdx.x; i < m; i += 256) s += log(A[(int64_t)i * mp + i]);
-  red[threadIdx.x] = s;
-  __syncthreads();
-  for (int o = 128; o > 0; o >>= 1) {
-    if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) out[0] = red[0] + red[0];
-}
-
 // One block per 64 output entries; a wavefront-wide dot per entry would be overkill for m <= 8k.
 __global__ __launch_bounds__(256) void triu_matvec_kernel(const double* __restrict__ A, int mp,
                                                           const double* __restrict__ x,
@@ -1385,11 +1371,6 @@ void launch_copy_block(const double* src, int64_t lds, double* dst, int64_t ldd,
                        hipStream_t s) {
   hipLaunchKernelGGL(copy_block_kernel, dim3((cols + 255) / 256, rows), dim3(256), 0, s, src, lds, dst,
                      ldd, rows, cols);
-  GPR_HIP(hipGetLastError());
-}
-
-void launch_logdet(const double* A, int mp, int m, double* out, hipStream_t s) {
-  hipLaunchKernelGGL(logdet_kernel, dim3(1), dim3(256), 0, s, A, mp, m, out);
   GPR_HIP(hipGetLastError());
 }
 

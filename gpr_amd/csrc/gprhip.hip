@@ -27,21 +27,6 @@
 namespace gprhip {
 const std::string& last_error();
 
-__global__ __launch_bounds__(256) void dot_kernel(const double* __restrict__ x,
-                                                  const double* __restrict__ y, int n,
-                                                  double* __restrict__ out) {
-  __shared__ double red[256];
-  double s = 0.0;
-  for (int i = threadIdx.x; i < n; i += 256) s += x[i] * y[i];
-  red[threadIdx.x] = s;
-  __syncthreads();
-  for (int o = 128; o > 0; o >>= 1) {
-    if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) out[0] = red[0];
-}
-
 // x <- x / |x| over the first n entries (single block); nrm[0] = |x| before the scaling
 __global__ __launch_bounds__(256) void normalize_kernel(double* __restrict__ x, int n, double* __restrict__ nrm) {
   __shared__ double red[256];

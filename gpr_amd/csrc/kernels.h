@@ -105,8 +105,6 @@ void launch_copy_block(const double* src, int64_t lds, double* dst, int64_t ldd,
                        hipStream_t s);
 // X (mp x mp) = block-diagonal matrix of the nb 128x128 blocks stored consecutively in dinv
 void launch_scatter_diag_blocks(const double* dinv, int mp, double* X, hipStream_t s);
-// out[0] = 2 * sum_{i<m} log A[i][i]   (lib/utils.ml:95-101)
-void launch_logdet(const double* A, int mp, int m, double* out, hipStream_t s);
 
 // ---- small dense vector ops on m-vectors (single block)
 // y = op(A) x for an upper-triangular row-major mp x mp A; trans=0: y_i = sum_{k>=i} A[i][k] x_k,
