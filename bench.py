@@ -345,15 +345,28 @@ def _mxm_ms(tim):
     return float(sum(np.mean(tim.get(k_, [0.0])) for k_ in ("km_chol", "b_chol", "inverses", "finish")))
 
 
+NAMED_CONFIGS = {
+    "c2": dict(n=1_000_000, m=2048, d=8, seed=2, baseline="BASELINE.json configs[1]"),
+    "c4": dict(n=8_000_000, m=4096, d=16, seed=4,
+               baseline="BASELINE.json configs[3]: n=8M m=4096 d=16, n-sharded across 8 GPUs with an RCCL all-reduce of the m x m sums"),
+    "c5": dict(n=1_000_000, m=2048, d=8, seed=5, baseline="BASELINE.json configs[4]: the hyper-gradient path at the C2 shape, 1 -> 8 GPUs"),
+}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     # names chosen not to be prefixes of torch.distributed.run options (it rejects "--n", "--m" as ambiguous)
-    ap.add_argument("--points", dest="n", type=int, default=1_000_000)
-    ap.add_argument("--inducing", dest="m", type=int, default=2048)
-    ap.add_argument("--dims", dest="d", type=int, default=8)
+    ap.add_argument("--points", dest="n", type=int, default=None)
+    ap.add_argument("--inducing", dest="m", type=int, default=None)
+    ap.add_argument("--dims", dest="d", type=int, default=None)
+    # BASELINE.json configs by name: shape and seed of SURVEY 8(d) ("Seeds: C1 1, C2 2, C3 3, C4 4, C5 5"); --points /
+    # --inducing / --dims still override (the 1-GPU test of the C4 launch runs it at n = 160 003 with --same-device)
+    ap.add_argument("--config", choices=sorted(NAMED_CONFIGS), default="c2",
+                    help="c2: n=1M m=2048 d=8 (headline, default); c4: n=8M m=4096 d=16 row-sharded (run with --gpus 8); "
+                         "c5: the gradient path at the c2 shape, 1 -> 8 GPUs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-configs", action="store_true", help="skip the C3 / C4-shard block")
     # validation aids (tests/test_gpu_parity.py runs the N>1 code paths on a 1-GPU box with them); the driver's runs
@@ -398,7 +411,9 @@ def main():
         else:
             dist.init_process_group("gloo")
 
-    n, m, d, seed = args.n, args.m, args.d, 2
+    cfg = NAMED_CONFIGS[args.config]
+    n, m, d, seed = args.n or cfg["n"], args.m or cfg["m"], args.d or cfg["d"], cfg["seed"]
+    as_named = (n, m, d) == (cfg["n"], cfg["m"], cfg["d"])
     X, y, Z0 = synth(seed, n, m, d)
     if single_process_multi:
         devices = [0] * n_gpus if args.same_device else list(range(n_gpus))
@@ -508,9 +523,10 @@ def main():
                         "value_at_median": n / step_med},
             "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "launch": sp.launch if n_gpus > 1 or launched else "single process, one device",
-            "config": {"workload": "cov_se_iso FITC nLML + full hyper-gradient, n=%d m=%d d=%d fp64 "
-                                   "(BASELINE.json configs[1]); n row-sharded over %d GPU(s)" % (n, m, d, n_gpus),
-                       "n": n, "m": m, "d": d, "n_hypers": int(ev.grad.shape[0]) + 1},
+            "config": {"workload": "cov_se_iso FITC nLML + full hyper-gradient, n=%d m=%d d=%d fp64 (%s%s); n row-sharded "
+                                   "over %d GPU(s)" % (n, m, d, cfg["baseline"], "" if as_named else
+                                                       ", at a size other than the named one", n_gpus),
+                       "name": args.config, "seed": seed, "n": n, "m": m, "d": d, "n_hypers": int(ev.grad.shape[0]) + 1},
             "roofline": {"bound": "mfma", "kernel": DOMINANT["f64"] + "  (OP_TN: weighted SYRK over training points + column sums on the diagonal tiles)",
                          "launches_per_step": 2,
                          "achieved": achieved, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",

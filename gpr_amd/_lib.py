@@ -48,6 +48,15 @@ class Hypers(C.Structure):
     ]
 
 
+class MemoryPlan(C.Structure):
+    """gprhip_memory_plan_t: bytes one shard holds on its device (include/gprhip.h)."""
+    _fields_ = [(k, C.c_int64) for k in ("total", "v_store", "chunk_buffers", "slices", "inputs", "row_vectors", "mxm", "rest",
+                                         "k_store_optional", "chunk_rows", "kslices")]
+
+    def as_dict(self):
+        return {k: int(getattr(self, k)) for k, _ in self._fields_}
+
+
 class Result(C.Structure):
     _fields_ = [
         ("l1", C.c_double),
@@ -63,6 +72,7 @@ _dp = C.POINTER(C.c_double)
 _vp = C.c_void_p
 SIGNATURES = {
     "gprhip_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "gprhip_memory_plan": (C.c_int, [C.c_int, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int64, C.POINTER(MemoryPlan)]),
     "gprhip_problem_create": (C.c_int, [C.c_int, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int,
                                         C.c_int64, C.POINTER(_vp)]),
     "gprhip_problem_create_ex": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int,
@@ -154,3 +164,10 @@ def device_count():
     n = C.c_int(0)
     check(load().gprhip_device_count(C.byref(n)))
     return n.value
+
+
+def memory_plan(cov_kind, n, D, d, m, precision=F64, chunk_rows=0):
+    """gprhip_memory_plan: bytes one shard of that shape holds on its device, by part (device-free arithmetic)."""
+    plan = MemoryPlan()
+    check(load().gprhip_memory_plan(int(cov_kind), int(precision), int(n), int(D), int(d), int(m), int(chunk_rows), C.byref(plan)))
+    return plan.as_dict()

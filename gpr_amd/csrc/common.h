@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <mutex>
 #include <string>
+#include <vector>
 
 namespace gprhip {
 
@@ -19,6 +20,9 @@ enum : int {
 };
 
 void set_error(const std::string& msg);
+// Distinct libamdhip64.so files mapped into the process (common.cpp); the creation entry points refuse to run with two
+std::vector<std::string> mapped_hip_runtimes();
+void check_single_hip_runtime(const char* who);
 
 struct HipFail {
   int status;

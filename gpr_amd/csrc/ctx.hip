@@ -41,6 +41,7 @@ struct Rccl {
   int (*GroupEnd)() = nullptr;
   const char* (*GetErrorString)(int) = nullptr;
   int (*GetVersion)(int*) = nullptr;
+  int (*CommGetAsyncError)(rccl_comm_t, int*) = nullptr;  // optional (absent from very old builds): checked after a group
   std::string path;
 };
 
@@ -75,6 +76,7 @@ void load_rccl(Rccl& r) {
   r.GroupEnd = reinterpret_cast<decltype(r.GroupEnd)>(sym("ncclGroupEnd"));
   r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(sym("ncclGetErrorString"));
   r.GetVersion = reinterpret_cast<decltype(r.GetVersion)>(sym("ncclGetVersion"));
+  r.CommGetAsyncError = reinterpret_cast<decltype(r.CommGetAsyncError)>(dlsym(r.handle, "ncclCommGetAsyncError"));
 }
 
 // ---- one worker thread per device: runs the stage calls of that device's shard so that the shards' launches are
@@ -251,6 +253,18 @@ void exchange(gprhip_sharded* sp, int which, int64_t len, const std::function<do
     if (rc == 0) rc = rc2;
     if (!dev_ok) fail(GPRHIP_EHIP, "gprhip_sharded_eval: hipSetDevice failed inside the exchange step");
     if (rc != 0) fail(GPRHIP_ECOMM, std::string("gprhip_sharded_eval: ncclAllReduce failed: ") + c->rccl.GetErrorString(rc));
+    // a rank that failed asynchronously (a lost peer, a fault inside the collective's kernel) is reported by its
+    // communicator, not by the enqueue calls above: surface it here as GPRHIP_ECOMM instead of a hang in the next
+    // stream synchronisation
+    if (c->rccl.CommGetAsyncError)
+      for (int i = 0; i < nd; ++i) {
+        int async = 0;
+        const int q = c->rccl.CommGetAsyncError(c->comms[i], &async);
+        if (q != 0 || async != 0)
+          fail(GPRHIP_ECOMM, "gprhip_sharded_eval: RCCL reports an asynchronous error on rank " + std::to_string(i) + " (device " +
+                                 std::to_string(c->devices[i]) + ") after exchange step " + std::to_string(which + 1) + ": " +
+                                 c->rccl.GetErrorString(q != 0 ? q : async));
+      }
   } else {  // all shards on one device: a fixed-order sum on the first shard's stream, fenced by events
     GPR_HIP(hipSetDevice(c->devices[0]));
     SumPtrs ptrs;
@@ -291,6 +305,7 @@ int gprhip_ctx_create(const int* devices, int ndev, gprhip_ctx** out) {
   return guarded([&] {
     if (!out || !devices || ndev < 1 || ndev > MAX_SHARDS) fail(GPRHIP_EBADARG, "gprhip_ctx_create: invalid arguments (1 <= ndev <= 64)");
     *out = nullptr;
+    check_single_hip_runtime("gprhip_ctx_create");
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess) count = 0;
     if (count < 1) fail(GPRHIP_EHIP, "gprhip_ctx_create: no HIP device visible");
@@ -388,6 +403,32 @@ int gprhip_sharded_create(gprhip_ctx* c, int cov_kind, int precision, int64_t n,
     sp->hi.resize(nd);
     for (int i = 0; i < nd; ++i)
       if (gprhip_shard_rows(n, nd, i, &sp->lo[i], &sp->hi[i]) != GPRHIP_OK) throw HipFail{GPRHIP_EBADARG};
+    {  // every shard's resident set against the free memory of its device (shards sharing a device: their sum), before
+       // the first shard allocates anything: a partition that cannot hold the problem fails here with the figures
+      std::vector<int64_t> need(nd, 0);
+      for (int i = 0; i < nd; ++i) {
+        gprhip_memory_plan_t plan;
+        const int st = gprhip_memory_plan(cov_kind, precision, sp->hi[i] - sp->lo[i], D, d, m, chunk_rows, &plan);
+        if (st != GPRHIP_OK) throw HipFail{st};
+        int first = i;
+        for (int j = 0; j < i; ++j)
+          if (c->devices[j] == c->devices[i]) { first = j; break; }
+        need[first] += plan.total;
+      }
+      for (int i = 0; i < nd; ++i) {
+        if (need[i] == 0) continue;
+        size_t free_b = 0, total_b = 0;
+        GPR_HIP(hipSetDevice(c->devices[i]));
+        GPR_HIP(hipMemGetInfo(&free_b, &total_b));
+        if ((uint64_t)need[i] > (uint64_t)free_b) {
+          char buf[256];
+          snprintf(buf, sizeof buf, "gprhip_sharded_create: the shards on device %d need %.1f GB (n = %lld rows over %d shards, m = %d) "
+                   "and %.1f GB are free of %.1f GB: use more devices or the fp32-bulk mode", c->devices[i], need[i] / 1e9,
+                   (long long)n, nd, m, free_b / 1e9, total_b / 1e9);
+          fail(GPRHIP_EOOM, buf);
+        }
+      }
+    }
     auto destroy_parts = [&] {
       for (auto*& q : sp->parts) {
         gprhip_problem_destroy(q);

@@ -111,6 +111,7 @@ struct gprhip_problem {
   // because stream2 carries the first row chunk's covariance beside the K_m factorisation
   PotrfAux potrf_aux{};
   std::vector<void*> allocs;
+  int64_t alloc_bytes = 0, planned_bytes = 0;  // hipMalloc'ed so far / gprhip_memory_plan's total for this problem
 
   double *X = nullptr, *y = nullptr, *P = nullptr;
   double *Z = nullptr, *tproj = nullptr;
@@ -206,6 +207,7 @@ struct gprhip_problem {
     void* ptr = nullptr;
     GPR_HIP(hipMalloc(&ptr, (size_t)std::max<int64_t>(count, 1) * sizeof(T)));
     allocs.push_back(ptr);
+    alloc_bytes += std::max<int64_t>(count, 1) * (int64_t)sizeof(T);
     return static_cast<T*>(ptr);
   }
   const double* pts() const { return kind == GPRHIP_COV_SE_FAT && h.tproj ? P : X; }
@@ -534,7 +536,7 @@ void upload_hypers(gprhip_problem* p, const gprhip_hypers* h) {
 // (tiles x slices / 8) fills whole residency rounds of an XCD (32 CUs x 2 blocks) is taken.
 int pick_kslices(int mp, int64_t rows_p, int max_slices, int64_t slice_rows, bool f64) {
   const int nt = mp / TILE, tiles = nt * (nt + 1) / 2;
-  const int slots = 64;
+  const int slots = std::max(8, gemm_resident_slots() / 8);  // workgroups one XCD holds at a time (64 on MI355X)
   auto items_of = [&](int ks) {  // items of one XCD: off-diagonal tiles per slice + the diagonal tiles' own slices
     const int ksd = gemm_syrk_diag_slices(ks, f64, true);
     return (tiles - nt) * (ks / 8) + nt * ((ksd + 7) / 8);
@@ -580,6 +582,81 @@ int pick_kslices(int mp, int64_t rows_p, int max_slices, int64_t slice_rows, boo
     }
   }
   return best;
+}
+
+// Training points per workgroup of the gradient kernels: grad_slab_rows (256 or 1024 by the accumulator rows), halved down
+// to 64 while a launch -- min(n, chunk) rows -- would leave most of the chip idle.  GPRHIP_GRAD_SLAB overrides with one of
+// the sizes the kernels and their partial buffers are exercised with: 64, 128, 256, 512, 1024 (anything else is rounded
+// down to the next of these).
+int pick_grad_slab(int col_rows, int64_t n, int64_t chunk, int mp) {
+  int slab = grad_slab_rows(col_rows);
+  const int64_t rows = std::min(n, chunk);
+  while (slab > 64 && ((rows + slab - 1) / slab) * (int64_t)(mp / TILE) < 256) slab /= 2;
+  if (const char* e = getenv("GPRHIP_GRAD_SLAB")) {
+    const int want = atoi(e);
+    slab = 64;
+    while (slab < 1024 && slab * 2 <= want) slab *= 2;
+  }
+  return slab;
+}
+
+// Row chunking and split-K scratch of a problem: one place, used by the creation entry point and by the memory plan.
+struct Sizing {
+  int64_t chunk = 0, slice_rows = 8192;
+  int nchunks = 0, kslices = 8;
+};
+Sizing problem_sizing(int64_t n, int mp, int64_t chunk_rows, bool f64) {
+  Sizing z;
+  int64_t chunk = chunk_rows > 0 ? chunk_rows : 131072;
+  if (const char* e = getenv("GPRHIP_CHUNK_ROWS")) chunk = atoll(e);
+  chunk = round_up(std::min<int64_t>(std::max<int64_t>(chunk, 1), round_up(n, TILE)), TILE);
+  z.chunk = chunk;
+  z.nchunks = (int)((n + chunk - 1) / chunk);
+  // partial-sum buffers of the split-K SYRK launches: one m x m slice per `slice_rows` training points, capped at 40 GB
+  // (fp32-bulk mode: fp32 accumulation runs over one slice before the fp64 slice sum.  Measured at config 3 against
+  // the fp64 evaluation, tools/lab10.sh: 2048 / 4096 / 8192 / 16384-row slices give the evidence to 7.4e-8 / 7.3e-8 /
+  // 5.6e-8 / 2.3e-8 and SYRK launches of 119.9 / 120.3 / 119.0 / 118.9 ms -- no reason for shorter slices than fp64's.)
+  if (const char* e = getenv("GPRHIP_SLICE_ROWS")) z.slice_rows = std::max<int64_t>(1024, atoll(e));
+  const int64_t mm8 = (int64_t)mp * mp * 8;
+  z.kslices = (int)std::max<int64_t>(8, std::min<int64_t>((round_up(n, z.slice_rows) / z.slice_rows + 23) / 8 * 8, (40LL << 30) / mm8 / 8 * 8));
+  if (n < 32 * z.slice_rows) {
+    // mid-size shards take many short slices: exactly the factor pick_kslices will choose for this shape (it depends on
+    // (m, rows, cap) only) within a cap of 128 slices / 2 GB -- not the cap itself, which at n = 100 000, m = 1024 was 1 GB
+    // of scratch beside a 0.8 GB V store; the m x m products that borrow the scratch need eight slices
+    const int cap = (int)std::max<int64_t>(8, std::min<int64_t>(128, (2LL << 30) / mm8 / 8 * 8));
+    const int64_t rows_p = (int64_t)(z.nchunks - 1) * chunk + round_up(n - (int64_t)(z.nchunks - 1) * chunk, TILE);
+    z.kslices = std::max(8, pick_kslices(mp, rows_p, cap, z.slice_rows, f64));
+  }
+  if (const char* e = getenv("GPRHIP_KSLICES")) z.kslices = std::max(8, atoi(e) / 8 * 8);
+  return z;
+}
+
+// Bytes a problem holds on its device (gprhip_memory_plan).  Everything gprhip_problem_create allocates plus the V store
+// the first evaluation adds; the optional copy of K_nm (Cov_se_fat with projection hypers) is listed but not counted -- it
+// is only taken while it leaves room.
+void memory_plan(int cov_kind, int precision, int64_t n, int D, int d, int m, int64_t chunk_rows, gprhip_memory_plan_t* o) {
+  const int mp = (int)round_up(m, TILE);
+  const bool f32 = precision == GPRHIP_F32_BULK, fat = cov_kind == GPRHIP_COV_SE_FAT;
+  const int64_t esz = f32 ? 4 : 8, mm = (int64_t)mp * mp;
+  const Sizing z = problem_sizing(n, mp, chunk_rows, !f32);
+  const int64_t npad = (int64_t)z.nchunks * z.chunk;
+  std::memset(o, 0, sizeof *o);
+  o->chunk_rows = z.chunk;
+  o->kslices = z.kslices;
+  o->inputs = (n * D + npad + (fat ? n * d : 0)) * 8;
+  o->row_vectors = npad * 8 * (5 + (fat ? 1 : 0)) + (f32 ? npad * 4 * 3 : 0);
+  o->v_store = npad * mp * esz;
+  o->k_store_optional = fat ? npad * mp * esz : 0;
+  o->chunk_buffers = 2 * z.chunk * mp * esz + 2 * z.chunk * 4 * (mp / TILE) * 8;
+  o->slices = (int64_t)z.kslices * mm * esz + (int64_t)z.kslices * mp * 8;
+  o->mxm = 10 * mm * 8 + (f32 ? 3 * mm * 4 : 0) + (int64_t)mp * TILE * 8 + (int64_t)(mp / TILE) * TILE * TILE * 8;
+  const int64_t col_rows = d + 1 + (fat ? D + d : 0), km_rows = d + 2 + (fat ? d : 0);
+  const int gslab = pick_grad_slab((int)col_rows, n, z.chunk, mp);
+  const int64_t nslab = (z.chunk + gslab - 1) / gslab;
+  o->rest = (gprhip_exchange_len(cov_kind, D, d, m, 1) + gprhip_exchange_len(cov_kind, D, d, m, 2)) * 8 +
+            nslab * col_rows * mp * 8 + (fat ? ((z.chunk + 255) / 256) * (int64_t)D * d * 8 : 0) +
+            (int64_t)((m + km_slab_rows() - 1) / km_slab_rows()) * km_rows * mp * 8 + (int64_t)(8 + km_rows + col_rows) * mp * 8;
+  o->total = o->inputs + o->row_vectors + o->v_store + o->chunk_buffers + o->slices + o->mxm + o->rest;
 }
 
 template <typename TS>
@@ -1365,7 +1442,10 @@ struct DevBuf {
 // and on A^-1 = U^-1 U^-T -- both factors are on the device, a step is two triangular matrix-vector products.  Power
 // iteration approaches an extreme eigenvalue from inside the spectrum, so the estimate is a lower bound of the true
 // condition number (within a small factor after 16 steps for the spectra a covariance matrix has).  Cached per evaluation.
-double condition_km(gprhip_problem* p) {
+// `enough`: a caller that only needs to know whether the estimate exceeds a threshold (the fp32-bulk guard) passes it -- the
+// pivot cross-check below is itself a lower bound and comes from one small transfer, so an ill-conditioned factor is
+// recognised without a single iteration step.
+double condition_km(gprhip_problem* p, double enough = HUGE_VAL) {
   if (p->cond_km >= 0.0) return p->cond_km;
   if (!p->have_factors) {
     set_error("gprhip_condition: no factor of K_m on the device (evaluate, or load a predictor with co-variance coefficients)");
@@ -1375,39 +1455,13 @@ double condition_km(gprhip_problem* p) {
   hipStream_t s = p->stream;
   const int mp = p->mp, m = p->m;
   DevBuf tmp;
-  double* x = tmp.get<double>(2 * (int64_t)mp);
-  double* y = x + mp;
-  std::vector<double> h0(mp, 0.0);
-  for (int i = 0; i < m; ++i) h0[i] = 1.0 + 0.5 * std::sin(1.0 + 0.37 * i);  // the padding (a decoupled identity block) stays 0
-  // Rounds of 16 steps until both Rayleigh quotients have settled (relative change < 1e-2 over a round; at most 16 rounds:
-  // lambda_max(A^-1) converges slowly when K_m + jitter has a cluster of small eigenvalues, and a fixed 16 steps could pass
-  // exactly the coefficients the fp32 guard exists to refuse).
-  double lam[2] = {0.0, 0.0};
-  for (int which = 0; which < 2; ++which) {
-    const double* F = which == 0 ? p->umat : p->uinv;
-    GPR_HIP(hipMemcpyAsync(x, h0.data(), (size_t)mp * sizeof(double), hipMemcpyHostToDevice, s));
-    hipLaunchKernelGGL(normalize_kernel, dim3(1), dim3(256), 0, s, x, mp, p->scal + SC_LMAX + which);
-    double prev = 0.0;
-    for (int round = 0; round < 16; ++round) {
-      for (int it = 0; it < 16; ++it) {
-        if (which == 0) {  // x <- U^T (U x)
-          launch_triu_matvec(F, mp, x, y, 0, s);
-          launch_triu_matvec(F, mp, y, x, 1, s);
-        } else {           // x <- U^-1 (U^-T x)
-          launch_triu_matvec(F, mp, x, y, 1, s);
-          launch_triu_matvec(F, mp, y, x, 0, s);
-        }
-        hipLaunchKernelGGL(normalize_kernel, dim3(1), dim3(256), 0, s, x, mp, p->scal + SC_LMAX + which);
-      }
-      GPR_HIP(hipMemcpyAsync(&lam[which], p->scal + SC_LMAX + which, sizeof(double), hipMemcpyDeviceToHost, s));
-      GPR_HIP(hipStreamSynchronize(s));
-      if (round > 0 && std::fabs(lam[which] - prev) <= 1e-2 * std::fabs(lam[which])) break;
-      prev = lam[which];
-    }
-  }
-  // Cross-check from the factor itself: every squared pivot U_ii^2 lies inside the spectrum of A (it is the reciprocal of a
-  // diagonal entry of the inverse of a leading block, whose eigenvalues interlace A's), so max U_ii^2 / min U_ii^2 is a
-  // lower bound of cond(A) as well; the larger of the two estimates is reported.
+  double* x0 = tmp.get<double>(3 * (int64_t)mp);
+  double* const xv[2] = {x0, x0 + mp};
+  double* y = x0 + 2 * (int64_t)mp;
+  // Cross-check from the factor itself, first: every squared pivot U_ii^2 lies inside the spectrum of A (it is the
+  // reciprocal of a diagonal entry of the inverse of a leading block, whose eigenvalues interlace A's), so
+  // max U_ii^2 / min U_ii^2 is a lower bound of cond(A); the larger of the two estimates is reported.
+  double pivot_ratio = 0.0;
   {
     hipLaunchKernelGGL(copy_diag_kernel, dim3((mp + 255) / 256), dim3(256), 0, s, p->umat, mp, y);
     std::vector<double> dg(mp);
@@ -1418,12 +1472,46 @@ double condition_km(gprhip_problem* p) {
       dmax = std::max(dmax, dg[i] * dg[i]);
       dmin = std::min(dmin, dg[i] * dg[i]);
     }
-    if (dmin > 0.0 && dmax / dmin > lam[0] * lam[1]) {
-      p->cond_km = dmax / dmin;
-      return p->cond_km;
+    if (dmin > 0.0) pivot_ratio = dmax / dmin;
+    if (pivot_ratio >= enough) return pivot_ratio;  // (not cached: a later gprhip_condition wants the full estimate)
+  }
+  std::vector<double> h0(mp, 0.0);
+  for (int i = 0; i < m; ++i) h0[i] = 1.0 + 0.5 * std::sin(1.0 + 0.37 * i);  // the padding (a decoupled identity block) stays 0
+  // Rounds of 16 steps until both Rayleigh quotients have settled (relative change < 1e-2 over a round; at most 16 rounds:
+  // lambda_max(A^-1) converges slowly when K_m + jitter has a cluster of small eigenvalues, and a fixed 16 steps could pass
+  // exactly the coefficients the fp32 guard exists to refuse).  The two iterations advance side by side: one transfer and
+  // one host synchronisation per round for both.
+  double lam[2] = {0.0, 0.0}, prev[2] = {0.0, 0.0};
+  bool settled[2] = {false, false};
+  for (int which = 0; which < 2; ++which) {
+    GPR_HIP(hipMemcpyAsync(xv[which], h0.data(), (size_t)mp * sizeof(double), hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(normalize_kernel, dim3(1), dim3(256), 0, s, xv[which], mp, p->scal + SC_LMAX + which);
+  }
+  for (int round = 0; round < 16 && !(settled[0] && settled[1]); ++round) {
+    for (int which = 0; which < 2; ++which) {
+      if (settled[which]) continue;
+      const double* F = which == 0 ? p->umat : p->uinv;
+      double* x = xv[which];
+      for (int it = 0; it < 16; ++it) {
+        if (which == 0) {  // x <- U^T (U x)
+          launch_triu_matvec(F, mp, x, y, 0, s);
+          launch_triu_matvec(F, mp, y, x, 1, s);
+        } else {           // x <- U^-1 (U^-T x)
+          launch_triu_matvec(F, mp, x, y, 1, s);
+          launch_triu_matvec(F, mp, y, x, 0, s);
+        }
+        hipLaunchKernelGGL(normalize_kernel, dim3(1), dim3(256), 0, s, x, mp, p->scal + SC_LMAX + which);
+      }
+    }
+    GPR_HIP(hipMemcpyAsync(lam, p->scal + SC_LMAX, 2 * sizeof(double), hipMemcpyDeviceToHost, s));
+    GPR_HIP(hipStreamSynchronize(s));
+    for (int which = 0; which < 2; ++which) {
+      if (settled[which]) continue;
+      if (round > 0 && std::fabs(lam[which] - prev[which]) <= 1e-2 * std::fabs(lam[which])) settled[which] = true;
+      prev[which] = lam[which];
     }
   }
-  p->cond_km = lam[0] * lam[1];
+  p->cond_km = std::max(pivot_ratio, lam[0] * lam[1]);
   return p->cond_km;
 }
 
@@ -1431,13 +1519,15 @@ double condition_km(gprhip_problem* p) {
 // n x m operands (measured: profiles/r03_f32_sweep.txt -- useless from cond ~ 1e6 on); their consumers refuse them then.
 void need_trustworthy_coeffs(gprhip_problem* p, const char* who) {
   if (!p->f32 || p->f32_coeff_tol <= 0.0 || !p->have_factors) return;
-  const double bound = condition_km(p) * 5.9604644775390625e-8;
+  // (an estimate beyond twice the threshold settles the question: the pivot ratio alone may then answer, without iterating)
+  const double cond = condition_km(p, 2.0 * p->f32_coeff_tol / 5.9604644775390625e-8);
+  const double bound = cond * 5.9604644775390625e-8;
   if (bound > p->f32_coeff_tol) {
     char buf[320];
     snprintf(buf, sizeof buf,
              "%s: the mean coefficients of this fp32-bulk evaluation are not trustworthy: cond(K_m + jitter) ~ %.3g, "
              "error bound %.3g > %.3g (GPRHIP_F32_COEFF_TOL); evaluate with GPRHIP_F64 for coefficients / predictions "
-             "(log evidence and gradient are unaffected)", who, p->cond_km, bound, p->f32_coeff_tol);
+             "(log evidence and gradient are unaffected)", who, cond, bound, p->f32_coeff_tol);
     set_error(buf);
     throw HipFail{GPRHIP_EPRECISION};
   }
@@ -1764,6 +1854,7 @@ int gprhip_problem_create_ex(int device, int cov_kind, int precision, int64_t n,
       set_error("gprhip_problem_create: invalid arguments (need n,D,d,m >= 1, d == D for Cov_se_iso)");
       throw HipFail{ST_BAD_ARG};
     }
+    check_single_hip_runtime("gprhip_problem_create");
     GPR_HIP(hipSetDevice(device));
     gemm_init();
     auto* p = new gprhip_problem();
@@ -1772,23 +1863,37 @@ int gprhip_problem_create_ex(int device, int cov_kind, int precision, int64_t n,
     p->f32 = (precision == GPRHIP_F32_BULK);
     p->esz = p->f32 ? 4 : 8;
     p->mp = (int)round_up(m, TILE);
-    int64_t chunk = chunk_rows > 0 ? chunk_rows : 131072;
-    if (const char* e = getenv("GPRHIP_CHUNK_ROWS")) chunk = atoll(e);
-    chunk = round_up(std::min<int64_t>(chunk, round_up(n, TILE)), TILE);
+    const Sizing z = problem_sizing(n, p->mp, chunk_rows, !p->f32);
+    const int64_t chunk = z.chunk;
     p->chunk = chunk;
-    p->nchunks = (int)((n + chunk - 1) / chunk);
-    // partial-sum buffers of the split-K SYRK launches: one m x m slice per `slice_rows` training points,
-    // capped at 40 GB
-    // (fp32-bulk mode: fp32 accumulation runs over one slice before the fp64 slice sum.  Measured at config 3 against
-    // the fp64 evaluation, tools/lab10.sh: 2048 / 4096 / 8192 / 16384-row slices give the evidence to 7.4e-8 / 7.3e-8 /
-    // 5.6e-8 / 2.3e-8 and SYRK launches of 119.9 / 120.3 / 119.0 / 118.9 ms -- no reason for shorter slices than fp64's.)
-    if (const char* e = getenv("GPRHIP_SLICE_ROWS")) p->slice_rows = std::max<int64_t>(1024, atoll(e));
-    p->kslices = (int)std::max<int64_t>(8, std::min<int64_t>((round_up(n, p->slice_rows) / p->slice_rows + 23) / 8 * 8,
-                                                              (40LL << 30) / (p->mp * (int64_t)p->mp * 8) / 8 * 8));
-    // mid-size shards take many short slices (pick_kslices): room for up to 128 of them within 2 GB
-    if (n < 32 * p->slice_rows)
-      p->kslices = (int)std::max<int64_t>(p->kslices, std::min<int64_t>(128, (2LL << 30) / (p->mp * (int64_t)p->mp * 8) / 8 * 8));
-    if (const char* e = getenv("GPRHIP_KSLICES")) p->kslices = std::max(8, atoi(e) / 8 * 8);
+    p->nchunks = z.nchunks;
+    p->slice_rows = z.slice_rows;
+    p->kslices = z.kslices;
+    {  // the whole resident set of the problem against what the device has free, BEFORE anything is allocated: a shard that
+       // cannot hold its V store fails here, by name and with the figures, not in the first evaluation's hipMalloc
+      gprhip_memory_plan_t plan;
+      memory_plan(cov_kind, precision, n, D, d, m, chunk_rows, &plan);
+      size_t free_b = 0, total_b = 0;
+      GPR_HIP(hipMemGetInfo(&free_b, &total_b));
+      const bool verbose = getenv("GPRHIP_VERBOSE") && atoi(getenv("GPRHIP_VERBOSE")) != 0;
+      if (verbose)
+        fprintf(stderr, "gprhip: device %d: problem n=%lld m=%d d=%d (%s): resident %.3f GB = V %.3f + chunk buffers %.3f + "
+                        "split-K slices %.3f + inputs %.3f + rows %.3f + m x m %.3f + rest %.3f  (optional K_nm copy %.3f); "
+                        "free %.3f of %.3f GB\n", device, (long long)n, m, d, p->f32 ? "fp32-bulk" : "fp64",
+                plan.total / 1e9, plan.v_store / 1e9, plan.chunk_buffers / 1e9, plan.slices / 1e9, plan.inputs / 1e9,
+                plan.row_vectors / 1e9, plan.mxm / 1e9, plan.rest / 1e9, plan.k_store_optional / 1e9, free_b / 1e9, total_b / 1e9);
+      if ((uint64_t)plan.total > (uint64_t)free_b) {
+        char buf[320];
+        snprintf(buf, sizeof buf, "gprhip_problem_create: the problem needs %.1f GB on device %d (V = K_nm U^-1 of %lld rows x %d: "
+                 "%.1f GB, split-K slices %.1f GB, chunk buffers %.1f GB) and %.1f GB are free of %.1f GB: shard the rows over more "
+                 "devices (gprhip_ctx_create) or use the fp32-bulk mode", plan.total / 1e9, device, (long long)n, p->mp,
+                 plan.v_store / 1e9, plan.slices / 1e9, plan.chunk_buffers / 1e9, free_b / 1e9, total_b / 1e9);
+        set_error(buf);
+        delete p;
+        *out = nullptr;
+        throw HipFail{ST_OOM};
+      }
+    }
     if (const char* e = getenv("GPRHIP_TIMING")) {
       p->timer.on = atoi(e) >= 2;
       p->timer.kernel = atoi(e) >= 1;
@@ -1883,9 +1988,7 @@ int gprhip_problem_create_ex(int device, int cov_kind, int precision, int64_t n,
     p->slices = p->alloc<char>(p->slices_bytes);
     p->rowpart = p->alloc<double>((int64_t)pass1_row_blocks((int)chunk) * 4);
     p->gemvpart = p->alloc<double>((int64_t)p->kslices * mp);  // c~ partials, one row per k-slice
-    p->grad_slab = grad_slab_rows((int)p->col_rows());
-    while (p->grad_slab > 64 && ((n + p->grad_slab - 1) / p->grad_slab) * (int64_t)(mp / TILE) < 256) p->grad_slab /= 2;
-    if (const char* e = getenv("GPRHIP_GRAD_SLAB")) p->grad_slab = std::max(64, atoi(e) / 64 * 64);
+    p->grad_slab = pick_grad_slab((int)p->col_rows(), n, chunk, mp);
     const int64_t gslab = p->grad_slab;
     const int64_t nslab = (chunk + gslab - 1) / gslab;
     p->colpart = p->alloc<double>(nslab * p->col_rows() * mp);
@@ -1893,6 +1996,14 @@ int gprhip_problem_create_ex(int device, int cov_kind, int precision, int64_t n,
     p->kmpart = p->alloc<double>((int64_t)((m + km_slab_rows() - 1) / km_slab_rows()) * p->km_rows() * mp);
     p->ar1 = p->alloc<double>(gprhip_ar1_len(p));
     p->ar2 = p->alloc<double>(gprhip_ar2_len(p));
+    {
+      gprhip_memory_plan_t plan;
+      memory_plan(cov_kind, precision, n, D, d, m, chunk_rows, &plan);
+      p->planned_bytes = plan.total;
+      if (getenv("GPRHIP_VERBOSE") && atoi(getenv("GPRHIP_VERBOSE")) != 0)
+        fprintf(stderr, "gprhip: device %d: allocated %.3f GB at creation, %.3f GB planned without the V store\n", device,
+                p->alloc_bytes / 1e9, (plan.total - plan.v_store) / 1e9);
+    }
     GPR_HIP(hipMemsetAsync(p->y, 0, (size_t)npad * sizeof(double), p->stream));
     // R^-1 is written on its upper tiles only; the fp32 conversion reads the whole square
     GPR_HIP(hipMemsetAsync(p->rfinv, 0, (size_t)mm * sizeof(double), p->stream));
@@ -2000,6 +2111,18 @@ int64_t gprhip_n_hypers(const gprhip_problem* p, int flags) {
   if (p->kind == GPRHIP_COV_SE_ISO) return 2 + (int64_t)p->d * p->m;
   return 1 + (int64_t)p->d * p->m + ((flags & 1) ? (int64_t)p->D * p->d : 0) + ((flags & 2) ? p->m : 0) +
          ((flags & 4) ? (int64_t)p->d * p->m : 0);
+}
+
+int gprhip_memory_plan(int cov_kind, int precision, int64_t n, int D, int d, int m, int64_t chunk_rows,
+                       gprhip_memory_plan_t* plan) {
+  return guarded([&] {
+    if (!plan || n < 1 || D < 1 || d < 1 || m < 1 || (cov_kind != GPRHIP_COV_SE_ISO && cov_kind != GPRHIP_COV_SE_FAT) ||
+        (precision != GPRHIP_F64 && precision != GPRHIP_F32_BULK)) {
+      set_error("gprhip_memory_plan: invalid arguments");
+      throw HipFail{ST_BAD_ARG};
+    }
+    memory_plan(cov_kind, precision, n, D, d, m, chunk_rows, plan);
+  });
 }
 
 int64_t gprhip_exchange_len(int cov_kind, int D, int d, int m, int which) {

@@ -119,4 +119,8 @@ int gemm_row_parts_per_tile();
 // One-time per-process setup (raises the dynamic-LDS limit of the kernels; fixes the engine geometry).
 void gemm_init();
 
+// Workgroups of the engine the device holds at once (two per CU; 512 on MI355X) -- read from the device by gemm_init().
+// The split-K model of the mid-size SYRK launches (gprhip.hip, pick_kslices) takes its residency rounds from this.
+int gemm_resident_slots();
+
 }  // namespace gprhip

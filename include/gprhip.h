@@ -56,6 +56,28 @@ typedef struct gprhip_problem gprhip_problem;
 /* Number of visible HIP devices (does not initialise a device). */
 int gprhip_device_count(int* count);
 
+/* Device memory one shard of a problem holds, in bytes (pure arithmetic, no device): what gprhip_problem_create allocates
+ * plus the resident V = K_nm U^-1 store the first evaluation adds.  gprhip_problem_create compares `total` with the free
+ * memory of its device BEFORE allocating anything and returns GPRHIP_EOOM with these figures in the message when the shard
+ * cannot fit (nothing is spilled to the host); GPRHIP_VERBOSE=1 prints the plan of every problem created.
+ * Replaces: nothing -- the reference allocates Bigarrays as it goes (lib/fitc_gp.ml:105-229) and dies in caml_ba_alloc. */
+typedef struct {
+  int64_t total;            /* sum of the fields below except k_store_optional */
+  int64_t v_store;          /* V = K_nm U^-1 of all rows of the shard (n rounded up to chunks x m rounded up to 128) */
+  int64_t chunk_buffers;    /* two row-chunk temporaries (K / Q' / X~ / X) and the GEMM epilogues' per-row partials */
+  int64_t slices;           /* split-K partial sums of the SYRK-shaped launches */
+  int64_t inputs;           /* training inputs, targets, projected inputs (Cov_se_fat) */
+  int64_t row_vectors;      /* r, 1/s, y/s, w, v (, E row sums) */
+  int64_t mxm;              /* the m x m matrices: K_m, U, U^-1, B~, R~^-1, B~^-1, W~, W, R^-1, scratch */
+  int64_t rest;             /* exchange buffers, gradient / trace partials, result block */
+  int64_t k_store_optional; /* Cov_se_fat: a second n x m matrix (K_nm kept for the gradient pass), taken only while it
+                               leaves 4 GB free and stays below 40 % of the device; not in `total` */
+  int64_t chunk_rows;       /* rows per chunk the problem will use */
+  int64_t kslices;          /* split-K slices reserved */
+} gprhip_memory_plan_t;
+int gprhip_memory_plan(int cov_kind, int precision, int64_t n, int D, int d, int m, int64_t chunk_rows,
+                       gprhip_memory_plan_t* plan);
+
 /* Create the device-resident state for one shard of a FITC problem on HIP device `device`:
  *   n  training points held by this shard, D input dimension, d kernel-space dimension
  *   (d == D for Cov_se_iso; Cov_se_fat: d = Params.d, the tproj target dimension), m inducing points.

@@ -3,10 +3,9 @@ import sys
 
 import pytest
 
-# torch first: it ships its own copy of the HIP runtime (torch/lib/libamdhip64.so), libgprhip.so is linked against the
-# system one (/opt/rocm/lib).  Whichever is loaded first serves both; loaded in the other order (the library first, torch's
-# GPU initialisation later -- e.g. `pytest tests/test_gpu_parity.py -k device_resident` after any other GPU test) torch
-# reports "No HIP GPUs are available".  bench.py imports torch first for the same reason.
+# torch first: it bundles its own HIP runtime, libgprhip.so is linked against the system one, and only this order lets one
+# copy serve both -- INTEGRATION.md, "hosts that also load torch"; the library refuses the other order by name
+# (gprhip_problem_create: "two HIP runtimes are mapped ...", tests/test_abi.py::test_two_hip_runtimes_are_refused_by_name).
 try:
     import torch  # noqa: F401
 except Exception:  # pragma: no cover  (CPU-only tooling without torch)

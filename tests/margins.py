@@ -1,0 +1,116 @@
+"""Parity checks that (i) compare a gradient family by family, each block of the reference's `Hyper.get_all` order against
+ITS OWN largest entry (lib/cov_se_iso.ml:188-202: [Log_ell; Log_sf2; inducing (ind-major)]; lib/cov_se_fat.ml:290-342:
+[Log_sf2; inducing (ind-major); Proj (big_dim-major); Log_hetero_skedasticity; Log_multiscale_m05]) -- one max-norm over the
+whole vector lets the entries of order 1e6 (Log_ell, Log_sf2 at m = 2048) hide percent-level errors in the inducing block --
+and (ii) record every achieved error beside its bound: with GPR_MARGINS_LOG=<file> each check appends one JSON line
+{test, what, err, tol}; tools/parity_margins.py turns the log of a whole `pytest -m gpu` run into the table
+profiles/r06_parity_margins.txt that the tolerances in tests/test_gpu_parity.py are derived from (<= 10 x the worst observed).
+"""
+import json
+import os
+
+import numpy as np
+
+
+def _record(what, err, tol):
+    path = os.environ.get("GPR_MARGINS_LOG")
+    if not path:
+        return
+    test = os.environ.get("PYTEST_CURRENT_TEST", "?").split(" ")[0]
+    with open(path, "a") as f:
+        f.write(json.dumps({"test": test, "what": what, "err": float(err), "tol": float(tol)}) + "\n")
+
+
+def families(kind, d, m, D=0, proj=False, het=False, ms=False):
+    """[(family, slice)] of the gradient vector in the reference's Hyper.get_all order."""
+    out, pos = [], 0
+
+    def take(name, count):
+        nonlocal pos
+        out.append((name, slice(pos, pos + count)))
+        pos += count
+
+    if kind == "iso":
+        take("log_ell", 1)
+        take("log_sf2", 1)
+        take("inducing", d * m)
+    else:
+        take("log_sf2", 1)
+        take("inducing", d * m)
+        if proj:
+            take("proj", D * d)
+        if het:
+            take("hetero", m)
+        if ms:
+            take("multiscale", d * m)
+    return out
+
+
+def families_golden(g):
+    d, m = g["Z"].shape
+    return families(g["kind"], d, m, D=g["X"].shape[0], proj="tproj" in g, het="log_hetero" in g, ms="log_multiscales" in g)
+
+
+def relinf(a, b):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    return float(np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-300))
+
+
+def family_errors(got, ref, fams):
+    """{family: max-abs error relative to that family's largest reference entry}.  A family whose reference entries all
+    vanish to rounding (below 1e-12 of the vector's largest entry: e.g. d-th coordinates that the kernel does not see) is
+    measured against the whole vector's scale instead -- there is no scale of its own to be relative to."""
+    got, ref = np.asarray(got, dtype=np.float64), np.asarray(ref, dtype=np.float64)
+    assert got.shape == ref.shape, (got.shape, ref.shape)
+    assert fams[-1][1].stop == ref.shape[0], (fams, ref.shape)
+    whole = max(float(np.max(np.abs(ref))), 1e-300)
+    out = {}
+    for name, sl in fams:
+        r = ref[sl]
+        if r.size == 0:
+            continue
+        scale = float(np.max(np.abs(r)))
+        if scale < 1e-12 * whole:
+            scale = whole
+        out[name] = float(np.max(np.abs(got[sl] - r))) / scale
+    return out
+
+
+def check_grad(got, ref, fams, tol, what="grad"):
+    errs = family_errors(got, ref, fams)
+    for name, e in errs.items():
+        _record("%s.%s" % (what, name), e, tol)
+    bad = {k: v for k, v in errs.items() if not v <= tol}
+    assert not bad, "%s: families beyond %.1e: %s (all: %s)" % (what, tol, bad, errs)
+    return errs
+
+
+def check_rel(what, got, ref, tol, floor=0.0):
+    """|got - ref| <= tol * max(|ref|, floor)"""
+    err = abs(float(got) - float(ref)) / max(abs(float(ref)), floor, 1e-300)
+    _record(what, err, tol)
+    assert err <= tol, "%s: %.3e > %.1e (got %r, ref %r)" % (what, err, tol, got, ref)
+    return err
+
+
+def check_vec(what, got, ref, tol):
+    err = relinf(got, ref)
+    _record(what, err, tol)
+    assert err <= tol, "%s: relinf %.3e > %.1e" % (what, err, tol)
+    return err
+
+
+# the same three as expressions (for `assert a_ok(...) and b_ok(...)` lines): they assert inside and return True
+def grad_ok(got, ref, fams, tol, what="grad"):
+    check_grad(got, ref, fams, tol, what)
+    return True
+
+
+def rel_ok(what, got, ref, tol, floor=0.0):
+    check_rel(what, got, ref, tol, floor)
+    return True
+
+
+def vec_ok(what, got, ref, tol):
+    check_vec(what, got, ref, tol)
+    return True

@@ -42,6 +42,49 @@ def test_no_device_fails_loudly(gpu_available):
         gpr_amd.Problem(gpr_amd.COV_SE_ISO, 10, 2, 2, 3)
 
 
+def _load_order_probe(first):
+    """A fresh interpreter that loads libgprhip.so and torch in the given order, then calls gprhip_problem_create and
+    gprhip_ctx_create; prints status + message of each and the distinct libamdhip64 files in its link map."""
+    import subprocess
+    import sys
+    code = (
+        "import ctypes as C, sys\n"
+        "sys.path.insert(0, %r)\n"
+        "def lib():\n"
+        "    from gpr_amd import _lib\n"
+        "    return _lib.load()\n"
+        + ("L = lib(); import torch\n" if first == "library" else "import torch; L = lib()\n") +
+        "h = C.c_void_p()\n"
+        "st = L.gprhip_problem_create(0, 0, 100, 2, 2, 5, 0, C.byref(h)); print('P', st, L.gprhip_last_error().decode())\n"
+        "dev = (C.c_int * 1)(0)\n"
+        "st = L.gprhip_ctx_create(dev, 1, C.byref(h)); print('C', st, L.gprhip_last_error().decode())\n"
+        "print('N', len(set(l.split()[-1] for l in open('/proc/self/maps') if 'libamdhip64' in l)))\n") % ROOT
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    return {ln[0]: ln[2:] for ln in out.stdout.splitlines() if ln[:2] in ("P ", "C ", "N ")}
+
+
+def test_two_hip_runtimes_are_refused_by_name(gpu_available):
+    """libgprhip.so is linked against the system HIP runtime, torch bundles its own.  Library first, torch second: two
+    runtimes are mapped and only one can own the devices -- the creation entry points say so, naming both files, instead
+    of leaving the host with "No HIP GPUs are available" from whichever came second.  Torch first: one copy serves both
+    (the supported order; INTEGRATION.md, "hosts that also load torch")."""
+    pytest.importorskip("torch")
+    bad = _load_order_probe("library")
+    if bad["N"] == "2":
+        for key, who in (("P", "gprhip_problem_create"), ("C", "gprhip_ctx_create")):
+            st, msg = bad[key].split(" ", 1)
+            assert st == "3" and msg.startswith(who + ": two HIP runtimes are mapped"), bad[key]
+            assert "torch/lib/libamdhip64" in msg and "/opt/rocm" in msg and "import torch" in msg
+    else:  # an image whose torch uses the system runtime: nothing to refuse
+        assert bad["N"] == "1"
+    good = _load_order_probe("torch")
+    assert good["N"] == "1"
+    assert "two HIP runtimes" not in good["P"] and "two HIP runtimes" not in good["C"]
+    if gpu_available:
+        assert good["P"].split(" ", 1)[0] == "0" and good["C"].split(" ", 1)[0] == "0"
+
+
 def test_product_never_imports_oracle():
     """oracle/ is test infrastructure: nothing under gpr_amd/ may import or execute it."""
     pkg = os.path.join(ROOT, "gpr_amd")
@@ -105,7 +148,7 @@ def test_ocaml_stub_sources_cover_the_abi():
               "gprhip_cov_samples", "gprhip_co_variance_coeffs", "gprhip_load_predictor", "gprhip_eval_pass1",
               "gprhip_eval_pass2", "gprhip_eval_finish", "gprhip_ar1_len", "gprhip_ar2_len", "gprhip_last_error"}
     assert needed <= used, needed - used
-    fields = re.search(r"typedef struct \{(.*?)\} gprhip_hypers;", header, re.S).group(1)
+    fields = re.search(r"typedef struct \{([^}]*)\} gprhip_hypers;", header).group(1)
     names = re.findall(r"(\w+);", fields)
     assert len(names) == 11
     for f in names:

@@ -66,6 +66,67 @@ def test_fat_hypers_and_param_checks():
     assert k2.params.tproj[2, 1] == 9.0 and k.params.tproj[2, 1] == 1.0
 
 
+def test_gradient_family_slices_follow_hyper_get_all():
+    """tests/margins.families (the per-family gradient checks of the parity suite) against the mirrors' Hyper.get_all
+    (lib/cov_se_iso.ml:188-202, lib/cov_se_fat.ml:290-342): every hyper falls into the slice of its own family, and a
+    family-wise error hides nothing a whole-vector max-norm would hide."""
+    from tests import margins as M
+    d, m, D = 2, 3, 4
+    Z = np.zeros((d, m), order="F")
+    kind_of = lambda h: {"Log_ell": "log_ell", "Log_sf2": "log_sf2"}.get(h) if isinstance(h, str) else {
+        "Inducing_hyper": "inducing", "Proj_hyper": "proj", "Log_hetero_skedasticity": "hetero",
+        "Log_multiscale_m05": "multiscale"}[type(h).__name__]
+    hs = cov_se_iso.HyperModule.get_all(cov_se_iso.Kernel.create(cov_se_iso.Params(0.0, 0.0)), Z)
+    fams = M.families("iso", d, m)
+    assert fams[-1][1].stop == len(hs)
+    for name, sl in fams:
+        assert all(kind_of(h) == name for h in hs[sl]), name
+    for proj, het, ms in [(0, 0, 0), (1, 0, 0), (0, 1, 0), (0, 0, 1), (1, 1, 1), (1, 0, 1)]:
+        k = cov_se_fat.Kernel.create(cov_se_fat.Params.create(
+            d, 0.0, np.ones((D, d)) if proj else None, np.zeros(m) if het else None, np.zeros((d, m)) if ms else None))
+        hs = cov_se_fat.HyperModule.get_all(k, Z)
+        fams = M.families("fat", d, m, D=D, proj=bool(proj), het=bool(het), ms=bool(ms))
+        assert fams[-1][1].stop == len(hs), (proj, het, ms)
+        for name, sl in fams:
+            assert all(kind_of(h) == name for h in hs[sl]), (name, proj, het, ms)
+    # a percent-level error in the inducing block next to a huge Log_ell entry: invisible to the whole-vector norm
+    ref = np.concatenate([[1e6, -3e5], np.linspace(1.0, 50.0, d * m)])
+    got = ref.copy()
+    got[4] *= 1.01
+    assert relinf(got, ref) < 1e-6
+    errs = M.family_errors(got, ref, M.families("iso", d, m))
+    assert errs["log_ell"] == 0.0 and errs["inducing"] > 1e-3
+    with pytest.raises(AssertionError, match="inducing"):
+        M.check_grad(got, ref, M.families("iso", d, m), 1e-7)
+
+
+def test_memory_plan_of_the_baseline_configs():
+    """gprhip_memory_plan (device-free): BASELINE.json configs[3] (n = 8M, m = 4096, d = 16, fp64) per shard of its 1 / 2 / 4 /
+    8-way row partition against the 288 GB of an MI355X -- one device cannot hold it, two can (187.5 GB each), the 8-way
+    shard takes 64.6 GB; the headline problem 27 GB.  The parts add up and the V store is rows x padded columns."""
+    import gpr_amd
+    HBM = 288e9
+    tot = {}
+    for nd in (1, 2, 4, 8):
+        lo, hi = shard_rows(8_000_000, nd - 1, nd)
+        plan = gpr_amd.memory_plan(gpr_amd.COV_SE_ISO, hi - lo, 16, 16, 4096)
+        parts = sum(plan[k] for k in ("v_store", "chunk_buffers", "slices", "inputs", "row_vectors", "mxm", "rest"))
+        assert parts == plan["total"]
+        chunks = -(-(hi - lo) // plan["chunk_rows"])
+        assert plan["v_store"] == chunks * plan["chunk_rows"] * 4096 * 8
+        tot[nd] = plan["total"]
+    assert tot[1] > HBM and tot[2] < HBM and tot[8] < 70e9 and tot[8] < tot[4] < tot[2] < tot[1]
+    c2 = gpr_amd.memory_plan(gpr_amd.COV_SE_ISO, 1_000_000, 8, 8, 2048)
+    assert 25e9 < c2["total"] < 30e9
+    c3 = gpr_amd.memory_plan(gpr_amd.COV_SE_FAT, 1_000_000, 32, 32, 4096, precision=gpr_amd.F32_BULK)
+    assert c3["k_store_optional"] == c3["v_store"] == 1_048_576 * 4096 * 4 and c3["total"] + c3["k_store_optional"] < HBM
+    # mid-size shards reserve the split-K factor they will use, not the cap (n = 100 000, m = 1024 used to take 128 slices)
+    mid = gpr_amd.memory_plan(gpr_amd.COV_SE_ISO, 100_000, 8, 8, 1024)
+    assert 8 <= mid["kslices"] < 128 and mid["slices"] < mid["v_store"]
+    with pytest.raises(gpr_amd.GprHipError):
+        gpr_amd.memory_plan(gpr_amd.COV_SE_ISO, 0, 8, 8, 1024)
+
+
 def test_shard_rows_partitions_exactly():
     for n, w in ((1_000_000, 8), (10, 3), (7, 7), (1001, 4)):
         spans = [shard_rows(n, r, w) for r in range(w)]
