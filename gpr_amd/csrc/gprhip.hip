@@ -142,6 +142,9 @@ struct gprhip_problem {
   int k_resident = 1;         // GPRHIP_K_RESIDENT=0 (read at creation): never keep K_nm (ablation)
   // GPRHIP_SMALL_PATH=0 (read at creation): never take the one-kernel passes for at most 64 inducing points (small.hip)
   int small_path = 1;
+  // GPRHIP_MID_PATH=0 (read at creation): never take the one-kernel passes for 65 .. 128 inducing points (mid.hip)
+  int mid_path = 1;
+  double* mid_part = nullptr;    // their per-workgroup partial sums (allocated at first use)
   double* small_part = nullptr;  // their per-workgroup partial sums (allocated at first use)
   double* small_k = nullptr;     // K_nm [rows_p][64] of the small pass 1, read back by the small pass 2
   bool small_k_valid = false;    // ... of the current kernel parameters and inducing points (as have_v)
@@ -233,6 +236,11 @@ struct gprhip_problem {
   int64_t col_rows() const { return d + 1 + dbig() + (kind == GPRHIP_COV_SE_FAT ? d : 0); }
   bool use_small() const {
     return small_path && !f32 && !engine_steps && small_path_fits(m, mp, d, has_proj() ? D : 0, n, has_ms());
+  }
+  // one 128-column tile of inducing points that the small path does not take (65 .. 128 of them, or fewer with more input
+  // dimensions than small.hip stages): the row passes and the finish stage of mid.hip
+  bool use_mid() const {
+    return mid_path && !f32 && !engine_steps && !use_small() && mid_path_fits(m, mp, d, has_proj() ? D : 0, n, has_ms());
   }
 };
 
@@ -698,8 +706,10 @@ void do_pass1(gprhip_problem* p, const gprhip_hypers* h, int want_grad, int64_t 
   TS* const slices = static_cast<TS*>(p->slices);
   // K resident (see Kstore): decided at the first gradient evaluation that can use it, kept for the problem's life
   const bool small = p->use_small();
+  const bool mid = p->use_mid();
   if (small && !p->small_part) p->small_part = p->alloc<double>(small_part_len(p->d, p->D));
-  if (!p->Kstore && !p->kstore_tried && !small && want_grad && p->k_resident && p->kind == GPRHIP_COV_SE_FAT && h->tproj &&
+  if (mid && !p->mid_part) p->mid_part = p->alloc<double>(mid_part_len(p->d, p->D));
+  if (!p->Kstore && !p->kstore_tried && !small && !mid && want_grad && p->k_resident && p->kind == GPRHIP_COV_SE_FAT && h->tproj &&
       !h->log_multiscales_m05 && p->d <= 64 && p->D <= 64 && !p->grad_scalar) {
     p->kstore_tried = true;
     size_t free_b = 0, total_b = 0;
@@ -729,7 +739,7 @@ void do_pass1(gprhip_problem* p, const gprhip_hypers* h, int want_grad, int64_t 
   // K_nm of the first chunk does not depend on U: it is built on the second stream while the (latency-bound, few-CU)
   // factorisation and inversion of K_m run -- 0.4 ms of every evaluation, which is what a chunk's builder takes.
   // (Not under the per-stage timer, whose events sit on the main stream.)
-  const bool cov0_ahead = !reuse && !p->timer.on && !small;
+  const bool cov0_ahead = !reuse && !p->timer.on && !small && !mid;
   if (cov0_ahead) {
     GPR_HIP(hipEventRecord(p->ev_fork, s));  // hypers, inducing points and projections are enqueued on s
     GPR_HIP(hipStreamWaitEvent(p->stream2, p->ev_fork, 0));
@@ -741,7 +751,7 @@ void do_pass1(gprhip_problem* p, const gprhip_hypers* h, int want_grad, int64_t 
   // the factorisation kernels themselves, flags included), and the accumulators of the exchange-1 tail (the small row pass
   // writes them outright)
   if (mp != TILE || p->engine_steps) GPR_HIP(hipMemsetAsync(p->scal, 0, (NSCAL + 2) * sizeof(double), s));
-  if (!small || reuse) GPR_HIP(hipMemsetAsync(ar1_c, 0, (size_t)(mp + A1_TAIL) * sizeof(double), s));
+  if (!(small || mid) || reuse) GPR_HIP(hipMemsetAsync(ar1_c, 0, (size_t)(mp + A1_TAIL) * sizeof(double), s));
   // K_m + (hetero) + jitter goes straight into the factor's buffer (kj is scratch of the finish stage only)
   if (mp == TILE && p->m <= 64 && p->d <= 16 && !p->engine_steps && !p->has_ms() && p->small_path) {
     PotrfKm g;  // few inducing points: the covariance is built inside the factorisation kernel (chol.hip, MODE 2)
@@ -769,6 +779,22 @@ void do_pass1(gprhip_problem* p, const gprhip_hypers* h, int want_grad, int64_t 
       a.Kout = (p->d <= 8 && !p->has_ms()) ? p->small_k : nullptr;
       launch_small_pass1(a, ar1, ar1_c, ar1_tail, s);
       p->small_k_valid = a.Kout != nullptr;
+      tstop(p);
+      p->stage = 1;
+      p->have_v = true;
+      p->have_k = false;
+      return;
+    }
+    if (mid && !reuse) {
+      // one 128-column tile of inducing points: the same in one kernel per 64-row block with the triangular operand
+      // streamed from memory (mid.hip)
+      tstart(p, "p1_mid");
+      MidPass1Args a;
+      a.cp = p->cp; a.pts = p->pts(); a.Z = p->Z; a.uinv = p->uinv; a.y = h->model_only ? nullptr : p->y;
+      a.rows = (int)p->n; a.rows_p = (int)round_up(p->n, TILE); a.m = p->m; a.d = p->d;
+      a.sigma2 = h->sigma2;
+      a.V = Vstore; a.r = p->r; a.is = p->is; a.yis = p->yis; a.part = p->mid_part;
+      launch_mid_pass1(a, ar1, ar1_c, ar1_tail, s);
       tstop(p);
       p->stage = 1;
       p->have_v = true;
@@ -906,7 +932,8 @@ void do_pass2(gprhip_problem* p, const double* ar1, double* ar2) {
   // evidence-only evaluations (multim_f) carry nothing in the second exchange buffer: only its scalar tail is cleared,
   // and the caller need not reduce it
   const bool small = p->use_small();  // its reduction writes every entry of the exchange-2 buffer
-  if (p->want_grad && !small) GPR_HIP(hipMemsetAsync(ar2, 0, (size_t)gprhip_ar2_len(p) * sizeof(double), s));
+  const bool mid = p->use_mid();      // (the same)
+  if (p->want_grad && !small && !mid) GPR_HIP(hipMemsetAsync(ar2, 0, (size_t)gprhip_ar2_len(p) * sizeof(double), s));
   else if (!p->want_grad) GPR_HIP(hipMemsetAsync(ar2_tail, 0, (size_t)A2_TAIL * sizeof(double), s));
   if constexpr (std::is_same<TS, double>::value) {
     if (p->want_grad && small) {
@@ -926,6 +953,32 @@ void do_pass2(gprhip_problem* p, const double* ar1, double* ar2) {
       a.w = p->w; a.v = p->v; a.es = proj ? p->es : nullptr; a.X = p->nchunks == 1 ? bufB : nullptr; a.part = p->small_part;
       launch_small_pass2(a, (int)p->col_rows(), ar2, ar2_col, ar2_proj, ar2_tail, s);
       p->x_last = a.X;
+      tstop(p);
+      p->stage = 2;
+      return;
+    }
+    if (p->want_grad && mid) {
+      // one 128-column tile: Q', the row quantities, X~, X, E = X .* K with its moments and G~ in one kernel (mid.hip);
+      // B~^-1 is formed by the finish kernel, R^-1 is not needed
+      tstart(p, "p2_mid");
+      if (!p->mid_part) p->mid_part = p->alloc<double>(mid_part_len(p->d, p->D));
+      p->merged_x = false;
+      MidPass2Args a;
+      a.cp = p->cp; a.pts = p->pts(); a.Z = p->Z; a.uinv = p->uinv; a.rinv = p->rinv; a.bvec = p->bvec; a.ttil = p->ttil;
+      a.V = Vstore; a.y = mo ? nullptr : p->y; a.is = p->is; a.r = p->r;
+      a.big = proj ? p->X : nullptr; a.D = proj ? p->D : 0;
+      a.rows = (int)p->n; a.rows_p = (int)round_up(p->n, TILE); a.m = p->m; a.d = p->d;
+      a.variational = p->h.variational;
+      a.w = p->w; a.v = p->v; a.es = proj ? p->es : nullptr; a.X = p->nchunks == 1 ? bufB : nullptr; a.part = p->mid_part;
+      launch_mid_pass2(a, (int)p->col_rows(), ar2, ar2_col, ar2_proj, ar2_tail, s);
+      p->x_last = a.X;
+      if (proj) {  // second term of the `Proj derivative from the per-row sums of E the kernel left (as the engine path)
+        for (int c = 0; c < p->nchunks; ++c) {
+          const int64_t rows = p->rows_of(c), base = (int64_t)c * p->chunk;
+          launch_proj_term2(p->X + base * p->D, p->P + base * p->d, p->es + base, 1, (int)rows, p->D, p->d, p->projpart, s);
+          launch_reduce_rows(p->projpart, (int)((rows + 255) / 256), p->D * p->d, ar2_proj, 1, s);
+        }
+      }
       tstop(p);
       p->stage = 2;
       return;
@@ -1136,6 +1189,21 @@ void do_finish_enqueue(gprhip_problem* p, const double* ar2, bool light = false)
     a.wmat = p->wmat; a.kmred = p->kmred; a.wdiag = wdiag ? p->wdiag : nullptr;
     a.gather_from = ar2_col; a.n_gather = n_a2; a.ex = p->ex_dev + A1_TAIL;
     launch_small_finish(a, s);
+    tstop(p);
+    GPR_HIP(hipMemcpyAsync(p->res_host, p->res_dev, (size_t)(p->res_len + A1_TAIL + n_a2) * sizeof(double),
+                           hipMemcpyDeviceToHost, s));
+    return;
+  }
+  if (p->want_grad && p->use_mid()) {
+    // one 128-block: the m x m work in one workgroup, which also gathers the exchange-2 tail behind the result block
+    tstart(p, "finish");
+    MidFinishArgs a;
+    a.uinv = p->uinv; a.rinv = p->rinv; a.ttil = p->ttil; a.km = p->km; a.Z = p->Z; a.g = ar2;
+    a.m = m; a.d = d; a.km_rows = d + 2;
+    a.wmat = p->wmat; a.kmred = p->kmred; a.wdiag = wdiag ? p->wdiag : nullptr;
+    a.ybuf = p->kj;  // (free after the factorisation of K_m)
+    a.gather_from = ar2_col; a.n_gather = n_a2; a.ex = p->ex_dev + A1_TAIL;
+    launch_mid_finish(a, s);
     tstop(p);
     GPR_HIP(hipMemcpyAsync(p->res_host, p->res_dev, (size_t)(p->res_len + A1_TAIL + n_a2) * sizeof(double),
                            hipMemcpyDeviceToHost, s));
@@ -1903,6 +1971,7 @@ int gprhip_problem_create_ex(int device, int cov_kind, int precision, int64_t n,
     if (const char* e = getenv("GPRHIP_K_RESIDENT")) p->k_resident = atoi(e);
     if (const char* e = getenv("GPRHIP_W_AS_WS")) p->w_as_ws = atoi(e);
     if (const char* e = getenv("GPRHIP_SMALL_PATH")) p->small_path = atoi(e);
+    if (const char* e = getenv("GPRHIP_MID_PATH")) p->mid_path = atoi(e);
     if (const char* e = getenv("GPRHIP_F32_COEFF_TOL")) p->f32_coeff_tol = atof(e);
     if (const char* e = getenv("GPRHIP_MERGED_X")) p->merged_x_mode = atoi(e);
     if (const char* e = getenv("GPRHIP_POTRF_ENGINE")) p->engine_steps = atoi(e) != 0;

@@ -1,0 +1,910 @@
+// Row passes and finish stage of problems with 65 .. 128 inducing points (one 128-column tile; d <= 16 point dimensions,
+// 1 + d + D <= 32 with a projection from D input dimensions, no multiscales, fp64, any number of rows) -- the regime the
+// reference's own default lands in: Optim.get_kernel_inducing takes min (n_inputs / 10) 1000 inducing points
+// (lib/fitc_gp.ml:1474-1479), i.e. 65 .. 128 of them for every data set of 650 .. 1280 points.  Through the engine such an
+// evaluation is ~30 dependent launches of 5-35 us each (n = 2000, m = 128: 0.38 ms, profiles/r05_latency.txt): six
+// contraction launches whose 128 x 128 x 128 tiles take 14 us of MFMAs on one CU however few rows there are, their row
+// kernels and reductions, and eight launches of m x m work.  Here, as in small.hip for m <= 64, each pass is ONE kernel
+// per 64-row block plus one fixed-order reduction of the per-workgroup partial sums into the exchange buffers (same
+// buffers, same layout as do_pass1 / do_pass2 write: everything around the passes, sharded evaluations included, is shared):
+//   pass 1: K (lib/cov_se_iso.ml:128-159, lib/cov_se_fat.ml:224-240), V = K U^-1 (lib/fitc_gp.ml:226-227), r, s, 1/s
+//           (:155-166, :222-223), B~ part = V^T diag(is) V, c~ part = V^T (is y)
+//   pass 2: Q' = V R~^-1, q_diag, w, v (:1048, :1092-1108, :1158-1181), X~ = diag(is) Q' R~^-T - diag(v) V - w t~^T,
+//           X = X~ U^-T (:931-939, :1204-1206), E = X .* K and its moments against the points (:975-1003),
+//           G~ part = V^T diag(v) V (:1198-1203)
+//   finish: B~^-1, W~, W = U^-1 W~ U^-T, the trace terms against K_m (:956-973, lib/utils.ml:196-220) in one workgroup
+// What differs from small.hip: a 128 x 128 triangular inverse is 128 KB -- the LDS (160 KB) holds the block's own tiles
+// (V and Q'/X~/X/E: 2 x 66 KB) and NOTHING else, so the triangular operands U^-1 and R~^-1 never enter it: every wavefront
+// fetches the B fragments of its MFMAs straight from memory (the matrices are L2-resident: 128 KB each, read by every
+// workgroup), one k-batch ahead of the MFMAs that use them.  A wavefront owns COLUMN tiles here (16-column tiles w and
+// 7 - w: for an upper-triangular operand the k-ranges of tile j are 16 (j + 1) rows deep, so the pair is 9 batches of 16
+// for every wavefront), all 64 rows of the block; the two Gram accumulations give wavefront w the tile rows w and 7 - w of
+// the upper triangle (8 - w and w + 1 tiles: 9 each).  Everything that depends on w is a template parameter, so that all
+// fragment and accumulator indices are compile-time register names.
+#include <algorithm>
+#include <type_traits>
+
+#include "kernels.h"
+#include "exp_fast.h"
+
+namespace gprhip {
+
+namespace {
+
+constexpr int MP = 128;        // padded inducing points of the mid path = one engine tile
+constexpr int MLD = 130;       // leading dimension of the 64 x 128 LDS tiles (row stride 260 dwords = 4 mod 64: the
+                               //   half-wave fragment reads fall on 64 different banks, as SLD = 66 in small.hip)
+constexpr int MRB = 64;        // training points per block
+constexpr int MCT = 8;         // 16-column tiles
+constexpr int MNTU = 36;       // upper 16 x 16 tiles of a 128 x 128 symmetric accumulation
+constexpr int MGLEN = MNTU * 256;
+constexpr int M1LEN = MGLEN + MP + 4;  // pass-1 partial: B~ upper tiles | c~ part | sum log s, sum y^2/s, sum r/s, -
+// pass-2 partial: G~ upper tiles | moment rows (1, p_k (d), x_big (D)) x 128 | 8 scalars
+__host__ __device__ constexpr int m2len(int d, int D) { return MGLEN + (1 + d + D) * MP + 8; }
+// index of upper tile (it <= jt), row-major over the upper triangle
+__host__ __device__ constexpr int tix(int it, int jt) { return it * MCT - it * (it - 1) / 2 + (jt - it); }
+
+typedef double sd4 __attribute__((ext_vector_type(4)));
+// lane supplies A[lane&15][lane>>4] and B[lane>>4][lane&15]; accumulator element r is D[(lane>>4) + 4r][lane&15]
+__device__ __forceinline__ sd4 mfma_f64(double a, double b, sd4 c) {
+  return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ double sum16(double v) {  // over the 16 lanes that share lane >> 4
+  v += __shfl_xor(v, 1);
+  v += __shfl_xor(v, 2);
+  v += __shfl_xor(v, 4);
+  v += __shfl_xor(v, 8);
+  return v;
+}
+__device__ __forceinline__ double sum64(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+// acc[i][jj] = rows 16 i .. 16 i + 15 of A (LDS, [64][MLD]) times columns of tile J_jj (J_0 = W, J_1 = 7 - W) of the
+// upper-triangular B (memory, row-major [128][128], exact zeros below the diagonal): tile j needs k < 16 (j + 1) only, i.e.
+// the k-batches kb <= j.  The B fragments of batch kb + 1 are requested before the MFMAs of batch kb.  The batch loop stays
+// ROLLED, its operand pointers stepping by one batch: fully unrolled, each of the ~70 fragment loads gets an address
+// register of its own (a k-step is 1 KB of B away from the next, beyond the instruction's immediate offset), all of them
+// loop-invariant and therefore computed in front of the block loop and spilled.
+template <int W>
+__device__ __forceinline__ void tri_nn(const double* A, const double* __restrict__ B, int l15, int lq, sd4 (&acc)[4][2]) {
+  constexpr int J0 = W, J1 = 7 - W;
+  static_assert(J0 < J1, "tile pairing");
+#pragma unroll
+  for (int i = 0; i < 4; ++i) acc[i][0] = acc[i][1] = sd4{0.0, 0.0, 0.0, 0.0};
+  const double* bp = B + lq * MP + l15;   // B[4 s + lq][l15] of batch kb at bp + (16 kb + 4 s) MP
+  const double* ap = A + l15 * MLD + lq;  // A[16 i + l15][4 s + lq] at ap + 16 i MLD + 4 s
+  // fragments of the batch in hand and of the two behind it: a batch is 16-32 MFMAs (1000-2000 cycles), one of them does
+  // not cover a round trip to the L2
+  double cur[4][2], nx1[4][2], nx2[4][2];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    cur[s][1] = bp[4 * s * MP + 16 * J1];
+    cur[s][0] = bp[4 * s * MP + 16 * J0];
+    nx1[s][1] = bp[(16 + 4 * s) * MP + 16 * J1];                 // (J1 >= 4: batch 1 exists)
+    nx1[s][0] = J0 >= 1 ? bp[(16 + 4 * s) * MP + 16 * J0] : 0.0;
+    nx2[s][0] = nx2[s][1] = 0.0;
+  }
+  bp += 32 * MP;
+#pragma unroll 1
+  for (int kb = 0; kb <= J1; ++kb) {
+    if (kb + 2 <= J1) {
+#pragma unroll
+      for (int s = 0; s < 4; ++s) nx2[s][1] = bp[4 * s * MP + 16 * J1];
+      if (kb + 2 <= J0) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) nx2[s][0] = bp[4 * s * MP + 16 * J0];
+      }
+    }
+    bp += 16 * MP;
+    double af[4][4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) af[s][i] = ap[16 * i * MLD + 4 * s];
+    ap += 16;
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[i][1] = mfma_f64(af[s][i], cur[s][1], acc[i][1]);
+    if (kb <= J0) {
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i][0] = mfma_f64(af[s][i], cur[s][0], acc[i][0]);
+    }
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      cur[s][0] = nx1[s][0];
+      cur[s][1] = nx1[s][1];
+      nx1[s][0] = nx2[s][0];
+      nx1[s][1] = nx2[s][1];
+    }
+  }
+}
+
+// ... times B^T: out[r][c] = sum_k A[r][k] B[c][k], B upper triangular: tile j needs k >= 16 j, the batches kb >= j
+template <int W>
+__device__ __forceinline__ void tri_nt(const double* A, const double* __restrict__ B, int l15, int lq, sd4 (&acc)[4][2]) {
+  constexpr int J0 = W, J1 = 7 - W;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) acc[i][0] = acc[i][1] = sd4{0.0, 0.0, 0.0, 0.0};
+  const double* bp = B + l15 * MP + lq + 16 * J0;   // B[16 J + l15][16 kb + 4 s + lq] at bp + 16 J MP + 16 (kb - J0) + 4 s
+  const double* ap = A + l15 * MLD + lq + 16 * J0;
+  double cur[4][2], nx1[4][2], nx2[4][2];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    cur[s][0] = bp[16 * J0 * MP + 4 * s];
+    cur[s][1] = 0.0;                                              // (J0 < J1: tile J1 joins later)
+    nx1[s][0] = bp[16 * J0 * MP + 16 + 4 * s];                    // (J0 <= 3: batch J0 + 1 exists)
+    nx1[s][1] = J0 + 1 >= J1 ? bp[16 * J1 * MP + 16 + 4 * s] : 0.0;
+    nx2[s][0] = nx2[s][1] = 0.0;
+  }
+  bp += 32;
+#pragma unroll 1
+  for (int kb = J0; kb < MCT; ++kb) {
+    if (kb + 2 < MCT) {
+#pragma unroll
+      for (int s = 0; s < 4; ++s) nx2[s][0] = bp[16 * J0 * MP + 4 * s];
+      if (kb + 2 >= J1) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) nx2[s][1] = bp[16 * J1 * MP + 4 * s];
+      }
+    }
+    bp += 16;
+    double af[4][4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) af[s][i] = ap[16 * i * MLD + 4 * s];
+    ap += 16;
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[i][0] = mfma_f64(af[s][i], cur[s][0], acc[i][0]);
+    if (kb >= J1) {
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i][1] = mfma_f64(af[s][i], cur[s][1], acc[i][1]);
+    }
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      cur[s][0] = nx1[s][0];
+      cur[s][1] = nx1[s][1];
+      nx1[s][0] = nx2[s][0];
+      nx1[s][1] = nx2[s][1];
+    }
+  }
+}
+
+// acc[q] += (T^T diag(wt) T) upper tiles of this wavefront over the 64 rows of T (LDS): tile rows I0 = W (q = 0 .. 7 - W:
+// column tiles W .. 7) and I1 = 7 - W (q = 8 - W .. 8: column tiles 7 - W .. 7)
+template <int W>
+__device__ __forceinline__ void gram_update(const double* T, const double* wt, int l15, int lq, sd4 (&acc)[9]) {
+  constexpr int I0 = W, I1 = 7 - W;
+  // (one lane-dependent base per array and compile-time offsets from it: written as T[k * MLD + ...] with k = 4 (..) + lq,
+  //  the compiler turns the sum into an `or`, cannot pull the constant through the multiplication any more, and keeps one
+  //  address register per k -- hundreds of them over this file, all loop-invariant, all spilled)
+  const double* tq = T + lq * MLD + l15;
+  const double* wq = wt + lq;
+#pragma unroll
+  for (int h = 0; h < 4; ++h) {
+    double a0[4], a1[4], bf[4][MCT];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int k4 = 4 * (4 * h + s);
+      const double wk = wq[k4];
+      a0[s] = tq[k4 * MLD + 16 * I0] * wk;
+      a1[s] = tq[k4 * MLD + 16 * I1] * wk;
+#pragma unroll
+      for (int c = I0; c < MCT; ++c) bf[s][c] = tq[k4 * MLD + 16 * c];
+    }
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+#pragma unroll
+      for (int c = I0; c < MCT; ++c) acc[c - I0] = mfma_f64(a0[s], bf[s][c], acc[c - I0]);
+#pragma unroll
+      for (int c = I1; c < MCT; ++c) acc[(MCT - I0) + (c - I1)] = mfma_f64(a1[s], bf[s][c], acc[(MCT - I0) + (c - I1)]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+// this wavefront's nine Gram tiles -> the partial buffer, tile tix(it, jt) as 16 x 16 row-major
+template <int W>
+__device__ __forceinline__ void store_gram(double* part, const sd4 (&acc)[9], int l15, int lq) {
+  constexpr int I0 = W, I1 = 7 - W;
+#pragma unroll
+  for (int q = 0; q < 9; ++q) {
+    const int it = q < MCT - I0 ? I0 : I1;
+    const int jt = q < MCT - I0 ? I0 + q : I1 + (q - (MCT - I0));
+#pragma unroll
+    for (int r = 0; r < 4; ++r) (part + lq * 16 + l15)[tix(it, jt) * 256 + 64 * r] = acc[q][r];
+  }
+}
+
+// sum_g part[g * stride] over the workgroups' partials, in order, sixteen loads in flight at a time
+__device__ __forceinline__ double sum_parts(const double* __restrict__ part, int64_t stride, int ng) {
+  double acc = 0.0;
+  for (int g0 = 0; g0 < ng; g0 += 16) {
+    double v[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) v[j] = (g0 + j < ng) ? part[(int64_t)(g0 + j) * stride] : 0.0;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc += v[j];
+  }
+  return acc;
+}
+
+}  // namespace
+
+// workgroups of a pass at most (each walks blocks b, b + groups, ...): one per CU (pass 2 fills the LDS; the per-workgroup
+// partials are 75 KB each)
+constexpr int MID_GROUPS = 256;
+int64_t mid_part_len(int d, int D) { return (int64_t)MID_GROUPS * std::max(M1LEN, m2len(d, D)); }
+static int mid_groups(int rows_p) { return std::min(MID_GROUPS, rows_p / MRB); }
+
+// ---------------------------------------------------------------------------------------------------------------- pass 1
+template <int DT, int W>
+__device__ __forceinline__ void mid_pass1_body(const MidPass1Args& a, double* lds) {
+  double* const Kt = lds;              // [MRB][MLD] K of the block, then V in place
+  double* const xs = Kt + MRB * MLD;   // [MRB][DT]
+  double* const isr = xs + MRB * DT;   // [MRB] 1/s
+  double* const yisr = isr + MRB;      // [MRB] y/s
+  double* const rsp = yisr + MRB;      // [4][MRB] row sums of V.^2 over each wavefront's columns
+  const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, lq = lane >> 4;
+  const ExpK ek = exp_consts();
+  const int col = tid & (MP - 1), rg = tid >> 7;  // covariance / column-sum phases: thread = (column, half of the rows)
+  const bool live_c = col < a.m;
+  double z[DT];
+#pragma unroll
+  for (int k = 0; k < DT; ++k) z[k] = (k < a.d && live_c) ? a.Z[(int64_t)col * a.d + k] : 0.0;
+  sd4 accB[9];
+#pragma unroll
+  for (int q = 0; q < 9; ++q) accB[q] = sd4{0.0, 0.0, 0.0, 0.0};
+  double csum = 0.0, p_log = 0.0, p_y2 = 0.0, p_isr = 0.0;
+  const int nblk = a.rows_p / MRB;
+  for (int b = blockIdx.x; b < nblk; b += gridDim.x) {
+    const int r0 = b * MRB;
+    __syncthreads();
+    for (int idx = tid; idx < MRB * DT; idx += 256) {
+      const int r = idx / DT, k = idx % DT;
+      xs[idx] = (k < a.d && r0 + r < a.rows) ? a.pts[(int64_t)(r0 + r) * a.d + k] : 0.0;
+    }
+    const double yreg = (tid < MRB && a.y && r0 + tid < a.rows) ? a.y[r0 + tid] : 0.0;  // used by the row phase below
+    __syncthreads();
+    {
+      const double* xq = xs + rg * 32 * DT;
+      double* kq = Kt + rg * 32 * MLD + col;
+      const int rlive = a.rows - r0 - rg * 32;  // rows i < rlive of this half are real
+#pragma unroll 4
+      for (int i = 0; i < 32; ++i) {
+        double acc = 0.0;
+#pragma unroll
+        for (int k = 0; k < DT; ++k) {  // (dimensions beyond d are zero on both sides: they add exactly 0)
+          const double diff = xq[i * DT + k] - z[k];
+          acc = acc + diff * diff;
+        }
+        kq[i * MLD] = (i < rlive && live_c) ? exp_fast(a.cp.log_sf2 + a.cp.inv_ell2_05 * acc, ek) : 0.0;
+      }
+    }
+    __syncthreads();
+    sd4 acc[4][2];
+    // (the operand pointer is laundered per block: left loop-invariant, every B fragment of the product -- 72 loads -- is
+    //  hoisted in front of the block loop and held in registers, in pass 2 -- three products -- spilled to scratch)
+    const double* uinv = a.uinv;
+    asm volatile("" : "+s"(uinv));
+    tri_nn<W>(Kt, uinv, l15, lq, acc);  // V = K U^-1
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const double s = sum16(acc[i][0][r] * acc[i][0][r] + acc[i][1][r] * acc[i][1][r]);
+        if (l15 == 0) (rsp + lq)[W * MRB + 16 * i + 4 * r] = s;
+      }
+    __syncthreads();  // every wavefront is done reading K
+    {
+      double* kq = Kt + lq * MLD + l15;                         // element r of acc[i][jj] is row 16 i + lq + 4 r,
+      double* vq = a.V + (int64_t)(r0 + lq) * MP + l15;         //   column 16 J_jj + l15
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int jj = 0; jj < 2; ++jj) {
+            constexpr int JW[2] = {W, 7 - W};
+            kq[(16 * i + 4 * r) * MLD + 16 * JW[jj]] = acc[i][jj][r];
+            vq[(16 * i + 4 * r) * MP + 16 * JW[jj]] = acc[i][jj][r];
+          }
+    }
+    if (tid < MRB) {  // r, s = r + sigma2, 1/s, sum log s  (as pass1_rows_kernel)
+      const int row = r0 + tid;
+      double rr = 0.0, is = 0.0, yis = 0.0;
+      if (row < a.rows) {
+        rr = a.cp.sf2 - ((rsp[tid] + rsp[MRB + tid]) + (rsp[2 * MRB + tid] + rsp[3 * MRB + tid]));
+        const double s = rr + a.sigma2;
+        is = 1.0 / s;
+        const double y = yreg;
+        yis = is * y;
+        p_log += log(s);
+        p_y2 += is * y * y;
+        p_isr += is * rr;
+      }
+      a.r[row] = rr;
+      a.is[row] = is;
+      a.yis[row] = yis;
+      isr[tid] = is;
+      yisr[tid] = yis;
+    }
+    __syncthreads();
+    gram_update<W>(Kt, isr, l15, lq, accB);
+    {
+      const double* kq = Kt + rg * 32 * MLD + col;
+      const double* yq = yisr + rg * 32;
+#pragma unroll 8
+      for (int i = 0; i < 32; ++i) csum += kq[i * MLD] * yq[i];
+    }
+  }
+  double* part = a.part + (int64_t)blockIdx.x * M1LEN;
+  store_gram<W>(part, accB, l15, lq);
+  __syncthreads();
+  Kt[rg * MLD + col] = csum;
+  __syncthreads();
+  if (tid < MP) part[MGLEN + tid] = Kt[tid] + Kt[MLD + tid];
+  if (W == 0) {
+    p_log = sum64(p_log);
+    p_y2 = sum64(p_y2);
+    p_isr = sum64(p_isr);
+    if (lane == 0) {
+      part[MGLEN + MP + 0] = p_log;
+      part[MGLEN + MP + 1] = p_y2;
+      part[MGLEN + MP + 2] = p_isr;
+      part[MGLEN + MP + 3] = 0.0;
+    }
+  }
+}
+
+template <int DT>
+__global__ __launch_bounds__(256) void mid_pass1_kernel(MidPass1Args a) {
+  extern __shared__ __attribute__((aligned(16))) double mid_lds[];
+  switch (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)) {  // (a scalar: the branch is uniform, no lane masking)
+    case 0: mid_pass1_body<DT, 0>(a, mid_lds); break;
+    case 1: mid_pass1_body<DT, 1>(a, mid_lds); break;
+    case 2: mid_pass1_body<DT, 2>(a, mid_lds); break;
+    default: mid_pass1_body<DT, 3>(a, mid_lds); break;
+  }
+}
+
+// the 128 x 128 tile of an exchange buffer from the workgroups' upper 16 x 16 tiles (zero below the diagonal 16-blocks:
+// every consumer reads upper triangles), summed in workgroup order
+__device__ __forceinline__ double mid_tile_entry(const double* __restrict__ part, int64_t plen, int ng, int r, int c) {
+  const int it = r >> 4, jt = c >> 4;
+  if (it > jt) return 0.0;
+  return sum_parts(part + tix(it, jt) * 256 + (r & 15) * 16 + (c & 15), plen, ng);
+}
+
+__global__ __launch_bounds__(256) void mid_reduce1_kernel(const double* __restrict__ part, int ng, double* __restrict__ tile,
+                                                          double* __restrict__ cvec, double* __restrict__ tail) {
+  const int tid = threadIdx.x;
+  if (blockIdx.x < MP * MP / 256) {
+    const int idx = blockIdx.x * 256 + tid;
+    tile[idx] = mid_tile_entry(part, M1LEN, ng, idx / MP, idx % MP);
+    return;
+  }
+  if (tid < MP) cvec[tid] = sum_parts(part + MGLEN + tid, M1LEN, ng);
+  else if (tid >= 192 && tid < 196) tail[tid - 192] = sum_parts(part + MGLEN + MP + (tid - 192), M1LEN, ng);
+}
+
+// ---------------------------------------------------------------------------------------------------------------- pass 2
+// NMT: 16-row tiles of the moment matrix [1 | p_1 .. p_d | x_big,1 .. x_big,D] (1 + d + D <= 16 NMT, NMT <= 2)
+template <int DT, int NMT, int W>
+__device__ __forceinline__ void mid_pass2_body(const MidPass2Args& a, double* lds) {
+  constexpr int LDM = 16 * NMT + 2;
+  double* const Vt = lds;               // [MRB][MLD] V of the block
+  double* const Qt = Vt + MRB * MLD;    // [MRB][MLD] Q', then X~, then X, then E, each in place
+  double* const Mx = Qt + MRB * MLD;    // [MRB][LDM] moment matrix of the block's rows: column 0 ones, 1 .. d the points
+  double* const isr = Mx + MRB * LDM;   // [MRB] per-row values of the block
+  double* const vr = isr + MRB;
+  double* const wr = vr + MRB;
+  double* const q2p = wr + MRB;         // [4][MRB] row sums of Q'.^2 / Q' b over each wavefront's columns
+  double* const qbp = q2p + 4 * MRB;    // [4][MRB]
+  double* const bv = qbp + 4 * MRB;     // [MP] b
+  double* const tt = bv + MP;           // [MP] t~
+  double* const red = tt + MP;          // [16] scratch of the final scalar reductions
+  const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, lq = lane >> 4;
+  const ExpK ek = exp_consts();
+  const int d = a.d, D = a.D, nmom = 1 + d + D;
+  if (tid < MP) {
+    bv[tid] = a.bvec[tid];
+    tt[tid] = a.ttil[tid];
+  }
+  const int col = tid & (MP - 1), rg = tid >> 7;
+  const bool live_c = col < a.m;
+  double z[DT];
+#pragma unroll
+  for (int k = 0; k < DT; ++k) z[k] = (k < d && live_c) ? a.Z[(int64_t)col * d + k] : 0.0;
+  sd4 accG[9];
+#pragma unroll
+  for (int q = 0; q < 9; ++q) accG[q] = sd4{0.0, 0.0, 0.0, 0.0};
+  sd4 accM[NMT][2];  // moments of E: rows 16 mt .., column tiles W and W + 4
+#pragma unroll
+  for (int mt = 0; mt < NMT; ++mt) accM[mt][0] = accM[mt][1] = sd4{0.0, 0.0, 0.0, 0.0};
+  double sE = 0.0, sED = 0.0;
+  double p_v = 0.0, p_is = 0.0, p_res = 0.0, p_v1 = 0.0;
+  const int nblk = a.rows_p / MRB;
+  for (int b = blockIdx.x; b < nblk; b += gridDim.x) {
+    const int r0 = b * MRB;
+    __syncthreads();
+    for (int idx = tid; idx < MRB * 16 * NMT; idx += 256) {
+      const int r = idx / (16 * NMT), q = idx % (16 * NMT);
+      double v = 0.0;
+      if (r0 + r < a.rows) {
+        if (q == 0) v = 1.0;
+        else if (q <= d) v = a.pts[(int64_t)(r0 + r) * d + (q - 1)];
+        else if (q < nmom) v = a.big[(int64_t)(r0 + r) * D + (q - 1 - d)];
+      }
+      Mx[r * LDM + q] = v;
+    }
+    {  // V of the block: 64 rows x 128 columns, sixteen 16-byte loads per thread, all issued before the first store
+      double2 v[16];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const int idx = tid + 256 * j, r = idx >> 6, c2 = (idx & 63) * 2;
+        v[j] = *reinterpret_cast<const double2*>(a.V + (int64_t)(r0 + r) * MP + c2);
+      }
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const int idx = tid + 256 * j, r = idx >> 6, c2 = (idx & 63) * 2;
+        *reinterpret_cast<double2*>(Vt + r * MLD + c2) = v[j];
+      }
+    }
+    if (tid < MRB) isr[tid] = a.is[r0 + tid];
+    const bool rowlive = tid < MRB && r0 + tid < a.rows;  // the row phase below: one thread per row
+    const double rreg = rowlive ? a.r[r0 + tid] : 0.0;
+    const double yreg = (rowlive && a.y) ? a.y[r0 + tid] : 0.0;
+    __syncthreads();
+    sd4 acc[4][2];
+    const double *uinv = a.uinv, *rinv = a.rinv;  // (laundered per block, see pass 1)
+    asm volatile("" : "+s"(uinv), "+s"(rinv));
+    tri_nn<W>(Vt, rinv, l15, lq, acc);  // Q' = V R~^-1
+    constexpr int JW[2] = {W, 7 - W};
+    double* const qq = Qt + lq * MLD + l15;        // element r of acc[i][jj] is row 16 i + lq + 4 r, column 16 J_jj + l15
+    const double* const vq = Vt + lq * MLD + l15;
+    {
+      const double b0 = bv[16 * JW[0] + l15], b1 = bv[16 * JW[1] + l15];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          qq[(16 * i + 4 * r) * MLD + 16 * JW[0]] = acc[i][0][r];
+          qq[(16 * i + 4 * r) * MLD + 16 * JW[1]] = acc[i][1][r];
+          const double s2 = sum16(acc[i][0][r] * acc[i][0][r] + acc[i][1][r] * acc[i][1][r]);
+          const double sb = sum16(acc[i][0][r] * b0 + acc[i][1][r] * b1);
+          if (l15 == 0) {
+            (q2p + lq)[W * MRB + 16 * i + 4 * r] = s2;
+            (qbp + lq)[W * MRB + 16 * i + 4 * r] = sb;
+          }
+        }
+    }
+    __syncthreads();
+    if (tid < MRB) {  // q_diag, w, v (as pass2_rows_kernel)
+      const int row = r0 + tid;
+      double w = 0.0, v = 0.0, es = 0.0;
+      if (row < a.rows) {
+        const double is = isr[tid], rr = rreg;
+        const double q2 = (q2p[tid] + q2p[MRB + tid]) + (q2p[2 * MRB + tid] + q2p[3 * MRB + tid]);
+        const double sb = (qbp[tid] + qbp[MRB + tid]) + (qbp[2 * MRB + tid] + qbp[3 * MRB + tid]);
+        const double qd = is * q2;
+        const double y = yreg;
+        const double res = a.y ? (y - sb) : 0.0;
+        w = is * res;
+        const double v1 = a.variational ? is * (2.0 - is * rr - qd) : is * (1.0 - qd);
+        v = v1 - w * w;
+        es = qd - v * (a.cp.sf2 - rr) - w * sb;
+        p_v += v;
+        p_is += is;
+        p_res += w * res;
+        p_v1 += v1;
+      }
+      a.w[row] = w;
+      a.v[row] = v;
+      if (a.es) a.es[row] = es;
+      wr[tid] = w;
+      vr[tid] = v;
+    }
+    tri_nt<W>(Qt, rinv, l15, lq, acc);  // Q' R~^-T
+    __syncthreads();  // every wavefront is done reading Q'; the row values are there
+    {
+      const double t0 = tt[16 * JW[0] + l15], t1 = tt[16 * JW[1] + l15];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {  // X~ = diag(is) Q' R~^-T - diag(v) V - w t~^T
+          const double is = (isr + lq)[16 * i + 4 * r], v = (vr + lq)[16 * i + 4 * r], w = (wr + lq)[16 * i + 4 * r];
+          qq[(16 * i + 4 * r) * MLD + 16 * JW[0]] = is * acc[i][0][r] - v * vq[(16 * i + 4 * r) * MLD + 16 * JW[0]] - w * t0;
+          qq[(16 * i + 4 * r) * MLD + 16 * JW[1]] = is * acc[i][1][r] - v * vq[(16 * i + 4 * r) * MLD + 16 * JW[1]] - w * t1;
+        }
+    }
+    __syncthreads();
+    tri_nt<W>(Qt, uinv, l15, lq, acc);  // X = X~ U^-T
+    __syncthreads();
+    {
+      double* xg = a.X ? a.X + (int64_t)(r0 + lq) * MP + l15 : nullptr;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int jj = 0; jj < 2; ++jj) {
+            qq[(16 * i + 4 * r) * MLD + 16 * JW[jj]] = acc[i][jj][r];
+            if (xg) xg[(16 * i + 4 * r) * MP + 16 * JW[jj]] = acc[i][jj][r];
+          }
+    }
+    gram_update<W>(Vt, vr, l15, lq, accG);  // G~ part = V^T diag(v) V
+    __syncthreads();
+    // E = X .* K of the block (K recomputed from the staged points), in place; sum E, sum E |x - z|^2
+    {
+      const double* mq = Mx + rg * 32 * LDM + 1;
+      double* eq = Qt + rg * 32 * MLD + col;
+      const int rlive = a.rows - r0 - rg * 32;
+#pragma unroll 4
+      for (int i = 0; i < 32; ++i) {
+        double dist = 0.0;
+#pragma unroll
+        for (int k = 0; k < DT; ++k) {
+          const double diff = (k < d) ? mq[i * LDM + k] - z[k] : 0.0;  // (uniform test; the points are columns 1 .. d)
+          dist = dist + diff * diff;
+        }
+        const double e = (live_c && i < rlive) ? eq[i * MLD] * exp_fast(a.cp.log_sf2 + a.cp.inv_ell2_05 * dist, ek) : 0.0;
+        eq[i * MLD] = e;
+        sE += e;
+        sED += e * dist;
+      }
+    }
+    __syncthreads();
+    // moments of E against [1 | p | x_big]: accM[mt][jj] += Mx^T E, tile rows 16 mt .., column tiles W and W + 4
+    const double* const mfq = Mx + lq * LDM + l15;
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+      double af[4][NMT], bf[4][2];
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const int k4 = 4 * (4 * h + s);
+#pragma unroll
+        for (int mt = 0; mt < NMT; ++mt) af[s][mt] = mfq[k4 * LDM + 16 * mt];
+        bf[s][0] = qq[k4 * MLD + 16 * W];
+        bf[s][1] = qq[k4 * MLD + 16 * (W + 4)];
+      }
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int mt = 0; mt < NMT; ++mt) {
+          accM[mt][0] = mfma_f64(af[s][mt], bf[s][0], accM[mt][0]);
+          accM[mt][1] = mfma_f64(af[s][mt], bf[s][1], accM[mt][1]);
+        }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  const int plen = m2len(d, D);
+  double* part = a.part + (int64_t)blockIdx.x * plen;
+  store_gram<W>(part, accG, l15, lq);
+  double* pcol = part + MGLEN;
+#pragma unroll
+  for (int mt = 0; mt < NMT; ++mt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int q = 16 * mt + lq + 4 * r;
+      if (q < nmom) {
+        pcol[q * MP + 16 * W + l15] = accM[mt][0][r];
+        pcol[q * MP + 16 * (W + 4) + l15] = accM[mt][1][r];
+      }
+    }
+  double* ptail = pcol + nmom * MP;
+  sE = sum64(sE);
+  sED = sum64(sED);
+  __syncthreads();
+  if (lane == 0) {
+    red[W] = sE;
+    red[4 + W] = sED;
+  }
+  __syncthreads();
+  if (W == 0) {
+    p_v = sum64(p_v);
+    p_is = sum64(p_is);
+    p_res = sum64(p_res);
+    p_v1 = sum64(p_v1);
+    if (lane == 0) {
+      ptail[0] = p_v;
+      ptail[1] = p_is;
+      ptail[2] = p_res;
+      ptail[3] = p_v1;
+      ptail[4] = (red[0] + red[1]) + (red[2] + red[3]);
+      ptail[5] = (red[4] + red[5]) + (red[6] + red[7]);
+      ptail[6] = 0.0;
+      ptail[7] = 0.0;
+    }
+  }
+}
+
+template <int DT, int NMT>
+__global__ __launch_bounds__(256) void mid_pass2_kernel(MidPass2Args a) {
+  extern __shared__ __attribute__((aligned(16))) double mid_lds[];
+  switch (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)) {
+    case 0: mid_pass2_body<DT, NMT, 0>(a, mid_lds); break;
+    case 1: mid_pass2_body<DT, NMT, 1>(a, mid_lds); break;
+    case 2: mid_pass2_body<DT, NMT, 2>(a, mid_lds); break;
+    default: mid_pass2_body<DT, NMT, 3>(a, mid_lds); break;
+  }
+}
+
+// exchange-2 buffer from the pass-2 partials, every entry written: the 128 x 128 tile, the column block (col_rows x 128;
+// rows 0 .. d + D carry sums, the rest -- the multiscale rows of a Cov_se_fat layout -- zero), the `Proj second term
+// (zero: proj_term2_kernel adds it afterwards) and the scalar tail
+__global__ __launch_bounds__(256) void mid_reduce2_kernel(const double* __restrict__ part, int ng, int d, int D, int col_rows,
+                                                          int nproj, double* __restrict__ tile, double* __restrict__ colblk,
+                                                          double* __restrict__ proj, double* __restrict__ tail) {
+  const int plen = m2len(d, D), nmom = 1 + d + D;
+  int idx = blockIdx.x * 256 + threadIdx.x;
+  const int ntile = MP * MP, ncol = col_rows * MP;
+  if (idx < ntile) {
+    tile[idx] = mid_tile_entry(part, plen, ng, idx / MP, idx % MP);
+  } else if ((idx -= ntile) < ncol) {
+    const int q = idx / MP, c = idx % MP;
+    colblk[idx] = q < nmom ? sum_parts(part + MGLEN + q * MP + c, plen, ng) : 0.0;
+  } else if ((idx -= ncol) < nproj) {
+    proj[idx] = 0.0;
+  } else if ((idx -= nproj) < 8) {
+    tail[idx] = sum_parts(part + MGLEN + nmom * MP + idx, plen, ng);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------- finish
+// The m x m work of do_finish_enqueue for one 128-block (as small_finish_kernel for 64 x 64 corners):
+//   B~^-1 = R~^-1 R~^-T (Utils.ichol, lib/utils.ml:110-113),  W~ = I - B~^-1 - t~ t~^T - G~,  W = U^-1 W~ U^-T
+//   (lib/fitc_gp.ml:1196-1203), the trace terms of W against K_m and its derivatives (km_traces_kernel: :956-973,
+//   lib/utils.ml:196-220), diag W, and the tails of both exchange buffers gathered behind the result block.
+// Two launches of eight workgroups, one per 16-row block -- a single workgroup doing all three 128^3 products takes 70 us
+// (18 us of MFMAs on one CU and a memory round trip per k-batch), the eight together a few:
+//   mid_finish1: rows I of B~^-1 -> rows I of W~ (LDS) -> rows I of Y = W~ U^-T (memory)
+//   mid_finish2: rows I of W = U^-1 Y, and -- W and K_m are symmetric -- the trace terms of COLUMNS I from those rows,
+//                so no sum across workgroups is left
+// Wavefront w owns the 16-column tiles w and 7 - w; every fragment that comes from memory is requested before the first
+// MFMA of its product (64 loads per wavefront; nothing here sits in a loop that could hoist them).
+__device__ __forceinline__ void mid_rows_times_tri_t(const double* Arow, const double* __restrict__ B, int kmin_row, int wv,
+                                                      int l15, int lq, sd4 (&acc)[2]) {
+  // acc[jj] = rows of Arow (LDS [16][MLD]) times B^T restricted to k >= 16 max(kmin_row, j): out[i][c] = sum_k A[i][k] B[c][k]
+  const int jt[2] = {wv, 7 - wv};
+  const double* aq = Arow + l15 * MLD + lq;
+  acc[0] = acc[1] = sd4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    double bf[4][4][2];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj) {
+        const int kb = 4 * half + kk;
+        const bool on = kb >= max(kmin_row, jt[jj]);
+        const double* bq = B + (int64_t)(16 * jt[jj] + l15) * MP + 16 * kb + lq;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) bf[kk][s][jj] = on ? bq[4 * s] : 0.0;
+      }
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const int kb = 4 * half + kk;
+      if (kb < min(max(kmin_row, jt[0]), max(kmin_row, jt[1]))) continue;  // (uniform)
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const double af = aq[16 * kb + 4 * s];
+        acc[0] = mfma_f64(af, bf[kk][s][0], acc[0]);
+        acc[1] = mfma_f64(af, bf[kk][s][1], acc[1]);
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void mid_finish1_kernel(MidFinishArgs a) {
+  __shared__ __attribute__((aligned(16))) double Rrow[16 * MLD];  // rows I of R~^-1, then of W~
+  __shared__ double tt[MP];
+  const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6), l15 = lane & 15, lq = lane >> 4;
+  const int I = blockIdx.x;
+  if (tid < MP) tt[tid] = a.ttil[tid];
+  for (int idx = tid; idx < 16 * (MP / 2); idx += 256) {
+    const int r = idx / (MP / 2), c2 = (idx % (MP / 2)) * 2;
+    *reinterpret_cast<double2*>(Rrow + r * MLD + c2) = *reinterpret_cast<const double2*>(a.rinv + (int64_t)(16 * I + r) * MP + c2);
+  }
+  if (I == 0)
+    for (int64_t i = tid; i < a.n_gather; i += 256) a.ex[i] = a.gather_from[i];
+  __syncthreads();
+  sd4 acc[2];
+  mid_rows_times_tri_t(Rrow, a.rinv, I, wv, l15, lq, acc);  // B~^-1[i][j] = sum_{k >= max(i, j)} Ri[i][k] Ri[j][k]
+  __syncthreads();  // every wavefront is done reading the rows of R~^-1
+#pragma unroll
+  for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int li = lq + 4 * r, row = 16 * I + li, c = 16 * (jj == 0 ? wv : 7 - wv) + l15;
+      const int rr = min(row, c), cc = max(row, c);  // G~ is valid in the upper triangle: mirrored, as build_w_kernel
+      Rrow[li * MLD + c] = (row == c ? 1.0 : 0.0) - acc[jj][r] - tt[row] * tt[c] - a.g[rr * MP + cc];
+    }
+  __syncthreads();
+  mid_rows_times_tri_t(Rrow, a.uinv, 0, wv, l15, lq, acc);  // Y[i][j] = sum_{k >= j} W~[i][k] Ui[j][k]
+#pragma unroll
+  for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      a.ybuf[(int64_t)(16 * I + lq + 4 * r) * MP + 16 * (jj == 0 ? wv : 7 - wv) + l15] = acc[jj][r];
+}
+
+template <int DT>
+__global__ __launch_bounds__(256) void mid_finish2_kernel(MidFinishArgs a) {
+  __shared__ __attribute__((aligned(16))) double Urow[16 * MLD];  // rows I of U^-1, then of W
+  __shared__ double zs[MP * DT];
+  const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6), l15 = lane & 15, lq = lane >> 4;
+  const int I = blockIdx.x, d = a.d, m = a.m;
+  for (int idx = tid; idx < 16 * (MP / 2); idx += 256) {
+    const int r = idx / (MP / 2), c2 = (idx % (MP / 2)) * 2;
+    *reinterpret_cast<double2*>(Urow + r * MLD + c2) = *reinterpret_cast<const double2*>(a.uinv + (int64_t)(16 * I + r) * MP + c2);
+  }
+  for (int idx = tid; idx < MP * DT; idx += 256) {
+    const int c = idx / DT, k = idx % DT;
+    zs[idx] = (k < d && c < m) ? a.Z[(int64_t)c * d + k] : 0.0;
+  }
+  // K_m entries of the trace phase (thread = (row i of the block, eight columns)): requested now, used at the end
+  const int ti = tid >> 4, tp = tid & 15, crow = 16 * I + ti;
+  double kreg[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) kreg[j] = (crow < m && 8 * tp + j < m) ? a.km[(int64_t)crow * MP + 8 * tp + j] : 0.0;
+  __syncthreads();
+  // W[i][j] = sum_{k >= i} Ui[i][k] Y[k][j]: the batches kb >= I; column tiles wv and wv + 4
+  sd4 acc[2];
+  acc[0] = acc[1] = sd4{0.0, 0.0, 0.0, 0.0};
+  {
+    const double* aq = Urow + l15 * MLD + lq;
+    const double* yq = a.ybuf + (int64_t)lq * MP + l15;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      double bf[4][4][2];
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        const int kb = 4 * half + kk;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          bf[kk][s][0] = kb >= I ? yq[(16 * kb + 4 * s) * MP + 16 * wv] : 0.0;
+          bf[kk][s][1] = kb >= I ? yq[(16 * kb + 4 * s) * MP + 16 * (wv + 4)] : 0.0;
+        }
+      }
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        const int kb = 4 * half + kk;
+        if (kb < I) continue;  // (uniform)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          const double af = aq[16 * kb + 4 * s];
+          acc[0] = mfma_f64(af, bf[kk][s][0], acc[0]);
+          acc[1] = mfma_f64(af, bf[kk][s][1], acc[1]);
+        }
+      }
+    }
+  }
+  __syncthreads();  // every wavefront is done reading the rows of U^-1
+#pragma unroll
+  for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int li = lq + 4 * r, c = 16 * (wv + 4 * jj) + l15;
+      Urow[li * MLD + c] = acc[jj][r];
+      a.wmat[(int64_t)(16 * I + li) * MP + c] = acc[jj][r];
+    }
+  __syncthreads();
+  // trace terms of column crow (= row crow: W and K_m are symmetric): sum over r of W[crow][r] K_m[crow][r] f(z_r - z_crow)
+  double g[DT], s0 = 0.0, s1 = 0.0;
+#pragma unroll
+  for (int k = 0; k < DT; ++k) g[k] = 0.0;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int r = 8 * tp + j;
+    const double wk = Urow[ti * MLD + r] * kreg[j];  // (0 beyond the real rows and columns)
+    s0 += wk;
+    double dist = 0.0;
+#pragma unroll
+    for (int k = 0; k < DT; ++k) {
+      const double df = zs[r * DT + k] - zs[crow * DT + k];
+      dist += df * df;
+      g[k] += wk * df;
+    }
+    s1 += wk * dist;
+  }
+  s0 = sum16(s0);
+  s1 = sum16(s1);
+#pragma unroll
+  for (int k = 0; k < DT; ++k) g[k] = sum16(g[k]);
+  if (tp == 0) {
+    a.kmred[crow] = s0;
+    a.kmred[MP + crow] = s1;
+#pragma unroll
+    for (int k = 0; k < DT; ++k)
+      if (k < d) a.kmred[(int64_t)(2 + k) * MP + crow] = g[k];
+    for (int q = 2 + d; q < a.km_rows; ++q) a.kmred[(int64_t)q * MP + crow] = 0.0;
+    if (a.wdiag) a.wdiag[crow] = Urow[ti * MLD + crow];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------- host
+static size_t mid_lds1(int DT) { return (size_t)(MRB * MLD + MRB * DT + 2 * MRB + 4 * MRB) * sizeof(double); }
+static size_t mid_lds2(int NMT) {
+  return (size_t)(2 * MRB * MLD + MRB * (16 * NMT + 2) + 3 * MRB + 8 * MRB + 2 * MP + 16) * sizeof(double);
+}
+
+template <typename F>
+static void mid_dispatch(int d, F&& go) {
+  if (d <= 4) go(std::integral_constant<int, 4>{});
+  else if (d <= 8) go(std::integral_constant<int, 8>{});
+  else go(std::integral_constant<int, 16>{});
+}
+
+static void mid_attrs() {
+  static uint64_t done = 0;
+  once_per_device(done, [] {
+    auto set = [](const void* f, size_t bytes) {
+      GPR_HIP(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    };
+#define GPRHIP_MID_SET(DT)                                                               \
+  set(reinterpret_cast<const void*>(&mid_pass1_kernel<DT>), mid_lds1(DT));               \
+  set(reinterpret_cast<const void*>(&mid_pass2_kernel<DT, 1>), mid_lds2(1));             \
+  set(reinterpret_cast<const void*>(&mid_pass2_kernel<DT, 2>), mid_lds2(2));             \
+  (void)0;
+    GPRHIP_MID_SET(4)
+    GPRHIP_MID_SET(8)
+    GPRHIP_MID_SET(16)
+#undef GPRHIP_MID_SET
+  });
+}
+
+bool mid_path_fits(int m, int mp, int d, int D, int64_t rows, bool ms) {
+  // (D: input dimensions in front of a projection, 0 without one; the moment matrix [1 | p | x_big] has at most two 16-row
+  //  tiles -- the two 64 x 128 tiles of pass 2 leave 30 KB of the LDS for it and the row vectors)
+  return m <= MP && mp == MP && d <= 16 && 1 + d + D <= 32 && !ms && rows <= (int64_t(1) << 22);
+}
+
+void launch_mid_pass1(const MidPass1Args& a, double* tile, double* cvec, double* tail, hipStream_t s) {
+  mid_attrs();
+  const int ng = mid_groups(a.rows_p);
+  mid_dispatch(a.d, [&](auto dt) {
+    constexpr int DT = decltype(dt)::value;
+    hipLaunchKernelGGL((mid_pass1_kernel<DT>), dim3(ng), dim3(256), mid_lds1(DT), s, a);
+  });
+  hipLaunchKernelGGL(mid_reduce1_kernel, dim3(MP * MP / 256 + 1), dim3(256), 0, s, a.part, ng, tile, cvec, tail);
+  GPR_HIP(hipGetLastError());
+}
+
+void launch_mid_pass2(const MidPass2Args& a, int col_rows, double* tile, double* colblk, double* proj, double* tail,
+                      hipStream_t s) {
+  mid_attrs();
+  const int ng = mid_groups(a.rows_p);
+  const int nmt = (1 + a.d + a.D + 15) / 16;
+  mid_dispatch(a.d, [&](auto dt) {
+    constexpr int DT = decltype(dt)::value;
+    if (nmt == 1) hipLaunchKernelGGL((mid_pass2_kernel<DT, 1>), dim3(ng), dim3(256), mid_lds2(1), s, a);
+    else hipLaunchKernelGGL((mid_pass2_kernel<DT, 2>), dim3(ng), dim3(256), mid_lds2(2), s, a);
+  });
+  const int nproj = a.D * a.d;
+  const int nout = MP * MP + col_rows * MP + nproj + 8;
+  hipLaunchKernelGGL(mid_reduce2_kernel, dim3((nout + 255) / 256), dim3(256), 0, s, a.part, ng, a.d, a.D, col_rows, nproj, tile,
+                     colblk, proj, tail);
+  GPR_HIP(hipGetLastError());
+}
+
+void launch_mid_finish(const MidFinishArgs& a, hipStream_t s) {
+  hipLaunchKernelGGL(mid_finish1_kernel, dim3(MCT), dim3(256), 0, s, a);
+  mid_dispatch(a.d, [&](auto dt) {
+    constexpr int DT = decltype(dt)::value;
+    hipLaunchKernelGGL((mid_finish2_kernel<DT>), dim3(MCT), dim3(256), 0, s, a);
+  });
+  GPR_HIP(hipGetLastError());
+}
+
+}  // namespace gprhip

@@ -12,13 +12,26 @@ import os
 import numpy as np
 
 
-def _record(what, err, tol):
+_context = {}
+
+
+def note(_reset=True, **kw):
+    """Facts about the case in hand (condition estimate, shape ...) that every following record carries."""
+    if _reset:
+        _context.clear()
+    _context.update(kw)
+
+
+def _record(what, err, tol, **extra):
     path = os.environ.get("GPR_MARGINS_LOG")
     if not path:
         return
     test = os.environ.get("PYTEST_CURRENT_TEST", "?").split(" ")[0]
+    rec = {"test": test, "what": what, "err": float(err), "tol": float(tol)}
+    rec.update(_context)
+    rec.update(extra)
     with open(path, "a") as f:
-        f.write(json.dumps({"test": test, "what": what, "err": float(err), "tol": float(tol)}) + "\n")
+        f.write(json.dumps(rec) + "\n")
 
 
 def families(kind, d, m, D=0, proj=False, het=False, ms=False):
@@ -56,10 +69,21 @@ def relinf(a, b):
     return float(np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-300))
 
 
-def family_errors(got, ref, fams):
+EPS64 = 2.0 ** -53
+EPS32 = 2.0 ** -24
+
+
+def family_errors(got, ref, fams, detail=None, allow=0.0):
     """{family: max-abs error relative to that family's largest reference entry}.  A family whose reference entries all
     vanish to rounding (below 1e-12 of the vector's largest entry: e.g. d-th coordinates that the kernel does not see) is
-    measured against the whole vector's scale instead -- there is no scale of its own to be relative to."""
+    measured against the whole vector's scale instead -- there is no scale of its own to be relative to.
+    allow: the conditioning allowance, as a fraction of the vector's largest entry, taken off every family's absolute error
+    first -- cond(K_m + jitter) x unit roundoff.  The trace terms of a gradient entry sum entries of W = U^-1 W~ U^-T, which
+    are |U^-1|^2 ~ cond times larger than the sum itself (with K_m jitter-dominated -- points on a line, more inducing than
+    training points -- the inducing-point entries of the gradient all but vanish and what is left of them is this rounding
+    error: measured against 80-bit central differences the oracle's own entries are then off by 1e-4 of their family's
+    largest, test/oracle notes in DESIGN section 6); a family-relative bound alone cannot hold there for ANY evaluation
+    order, the reference's included."""
     got, ref = np.asarray(got, dtype=np.float64), np.asarray(ref, dtype=np.float64)
     assert got.shape == ref.shape, (got.shape, ref.shape)
     assert fams[-1][1].stop == ref.shape[0], (fams, ref.shape)
@@ -72,16 +96,22 @@ def family_errors(got, ref, fams):
         scale = float(np.max(np.abs(r)))
         if scale < 1e-12 * whole:
             scale = whole
-        out[name] = float(np.max(np.abs(got[sl] - r))) / scale
+        raw = float(np.max(np.abs(got[sl] - r)))
+        out[name] = max(0.0, raw - allow * whole) / scale
+        if detail is not None:
+            detail[name] = dict(scale=scale, whole=whole, raw=raw / scale, allow=allow)
     return out
 
 
-def check_grad(got, ref, fams, tol, what="grad"):
-    errs = family_errors(got, ref, fams)
+def check_grad(got, ref, fams, tol, what="grad", cond=None, unit=EPS64):
+    """Every family within tol of its own largest entry; cond (the device's 2-norm estimate of cond(K_m + jitter), where the
+    caller has it) adds the conditioning allowance cond x unit relative to the vector's largest entry (see family_errors)."""
+    detail = {}
+    errs = family_errors(got, ref, fams, detail, allow=(cond * unit if cond else 0.0))
     for name, e in errs.items():
-        _record("%s.%s" % (what, name), e, tol)
+        _record("%s.%s" % (what, name), e, tol, **detail[name])
     bad = {k: v for k, v in errs.items() if not v <= tol}
-    assert not bad, "%s: families beyond %.1e: %s (all: %s)" % (what, tol, bad, errs)
+    assert not bad, "%s: families beyond %.1e: %s (all: %s; cond %s)" % (what, tol, bad, errs, cond)
     return errs
 
 
@@ -101,8 +131,8 @@ def check_vec(what, got, ref, tol):
 
 
 # the same three as expressions (for `assert a_ok(...) and b_ok(...)` lines): they assert inside and return True
-def grad_ok(got, ref, fams, tol, what="grad"):
-    check_grad(got, ref, fams, tol, what)
+def grad_ok(got, ref, fams, tol, what="grad", cond=None, unit=EPS64):
+    check_grad(got, ref, fams, tol, what, cond, unit)
     return True
 
 
