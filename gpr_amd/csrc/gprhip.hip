@@ -237,8 +237,8 @@ struct gprhip_problem {
   bool use_small() const {
     return small_path && !f32 && !engine_steps && small_path_fits(m, mp, d, has_proj() ? D : 0, n, has_ms());
   }
-  // one 128-column tile of inducing points that the small path does not take (65 .. 128 of them, or fewer with more input
-  // dimensions than small.hip stages): the row passes and the finish stage of mid.hip
+  // one or two 128-column tiles of inducing points that the small path does not take (65 .. 256 of them, or fewer with more
+  // input dimensions than small.hip stages): the row passes and the finish stage of mid.hip
   bool use_mid() const {
     return mid_path && !f32 && !engine_steps && !use_small() && mid_path_fits(m, mp, d, has_proj() ? D : 0, n, has_ms());
   }
@@ -708,7 +708,7 @@ void do_pass1(gprhip_problem* p, const gprhip_hypers* h, int want_grad, int64_t 
   const bool small = p->use_small();
   const bool mid = p->use_mid();
   if (small && !p->small_part) p->small_part = p->alloc<double>(small_part_len(p->d, p->D));
-  if (mid && !p->mid_part) p->mid_part = p->alloc<double>(mid_part_len(p->d, p->D));
+  if (mid && !p->mid_part) p->mid_part = p->alloc<double>(mid_part_len(mp, p->d, p->D));
   if (!p->Kstore && !p->kstore_tried && !small && !mid && want_grad && p->k_resident && p->kind == GPRHIP_COV_SE_FAT && h->tproj &&
       !h->log_multiscales_m05 && p->d <= 64 && p->D <= 64 && !p->grad_scalar) {
     p->kstore_tried = true;
@@ -751,7 +751,8 @@ void do_pass1(gprhip_problem* p, const gprhip_hypers* h, int want_grad, int64_t 
   // the factorisation kernels themselves, flags included), and the accumulators of the exchange-1 tail (the small row pass
   // writes them outright)
   if (mp != TILE || p->engine_steps) GPR_HIP(hipMemsetAsync(p->scal, 0, (NSCAL + 2) * sizeof(double), s));
-  if (!(small || mid) || reuse) GPR_HIP(hipMemsetAsync(ar1_c, 0, (size_t)(mp + A1_TAIL) * sizeof(double), s));
+  // (the one-tile passes write c~ and the tail outright; with two tiles c~ still comes from the engine's launch, accumulated)
+  if (!(small || (mid && mp == TILE)) || reuse) GPR_HIP(hipMemsetAsync(ar1_c, 0, (size_t)(mp + A1_TAIL) * sizeof(double), s));
   // K_m + (hetero) + jitter goes straight into the factor's buffer (kj is scratch of the finish stage only)
   if (mp == TILE && p->m <= 64 && p->d <= 16 && !p->engine_steps && !p->has_ms() && p->small_path) {
     PotrfKm g;  // few inducing points: the covariance is built inside the factorisation kernel (chol.hip, MODE 2)
@@ -786,22 +787,25 @@ void do_pass1(gprhip_problem* p, const gprhip_hypers* h, int want_grad, int64_t 
       return;
     }
     if (mid && !reuse) {
-      // one 128-column tile of inducing points: the same in one kernel per 64-row block with the triangular operand
-      // streamed from memory (mid.hip)
+      // one or two 128-column tiles of inducing points: the same in one kernel per row block with the triangular operand
+      // streamed from memory (mid.hip); with two tiles the accumulations B~ and c~ stay with the engine's launch below
       tstart(p, "p1_mid");
       MidPass1Args a;
       a.cp = p->cp; a.pts = p->pts(); a.Z = p->Z; a.uinv = p->uinv; a.y = h->model_only ? nullptr : p->y;
-      a.rows = (int)p->n; a.rows_p = (int)round_up(p->n, TILE); a.m = p->m; a.d = p->d;
+      a.rows = (int)p->n; a.rows_p = (int)round_up(p->n, TILE); a.m = p->m; a.mp = mp; a.d = p->d;
       a.sigma2 = h->sigma2;
       a.V = Vstore; a.r = p->r; a.is = p->is; a.yis = p->yis; a.part = p->mid_part;
       launch_mid_pass1(a, ar1, ar1_c, ar1_tail, s);
       tstop(p);
-      p->stage = 1;
-      p->have_v = true;
-      p->have_k = false;
-      return;
+      if (mp == TILE) {
+        p->stage = 1;
+        p->have_v = true;
+        p->have_k = false;
+        return;
+      }
     }
   }
+  const bool rows_done = mid && !reuse;  // (two tiles: V and the row quantities are there, the chunk loop has nothing to do)
   // Overlap (GPRHIP_COV_OVERLAP=1): chunk c + 1's covariance goes out on the second stream just before chunk c's V product
   // goes out on the main one, into the other chunk buffer (pass 1 uses one of the two at a time) -- it waits only for the V
   // product that last read that buffer, i.e. it runs beside V(c).
@@ -811,7 +815,7 @@ void do_pass1(gprhip_problem* p, const gprhip_hypers* h, int want_grad, int64_t 
     if (Kstore) return Kstore + (int64_t)c * p->chunk * mp;
     return (overlap && (c & 1)) ? bufB1 : bufA;
   };
-  for (int c = 0; c < p->nchunks; ++c) {
+  for (int c = 0; c < (rows_done ? 0 : p->nchunks); ++c) {
     const int64_t rows = p->rows_of(c);
     const int rows_p = (int)round_up(rows, TILE);
     const int64_t base = (int64_t)c * p->chunk;
@@ -878,7 +882,7 @@ void do_pass1(gprhip_problem* p, const gprhip_hypers* h, int want_grad, int64_t 
   launch_sum_slices<TS>(nullptr, slices, ks, mm, mp, ar1, s, 1, ksd);
   p->stage = 1;
   p->have_v = true;  // (revoked by finish() if the factorisation of K_m turns out to have failed)
-  if (!reuse) p->have_k = Kstore != nullptr;
+  if (!reuse) p->have_k = Kstore != nullptr && !rows_done;
 }
 
 template <typename TS>
@@ -933,6 +937,7 @@ void do_pass2(gprhip_problem* p, const double* ar1, double* ar2) {
   // and the caller need not reduce it
   const bool small = p->use_small();  // its reduction writes every entry of the exchange-2 buffer
   const bool mid = p->use_mid();      // (the same)
+  // (two tiles through mid.hip: its reduction writes everything behind the packed tiles, the engine's slice sum the tiles)
   if (p->want_grad && !small && !mid) GPR_HIP(hipMemsetAsync(ar2, 0, (size_t)gprhip_ar2_len(p) * sizeof(double), s));
   else if (!p->want_grad) GPR_HIP(hipMemsetAsync(ar2_tail, 0, (size_t)A2_TAIL * sizeof(double), s));
   if constexpr (std::is_same<TS, double>::value) {
@@ -958,16 +963,19 @@ void do_pass2(gprhip_problem* p, const double* ar1, double* ar2) {
       return;
     }
     if (p->want_grad && mid) {
-      // one 128-column tile: Q', the row quantities, X~, X, E = X .* K with its moments and G~ in one kernel (mid.hip);
-      // B~^-1 is formed by the finish kernel, R^-1 is not needed
+      // one or two 128-column tiles: Q', the row quantities, X~, X, E = X .* K with its moments (and, one tile, G~) in one
+      // kernel (mid.hip); B~^-1 is formed by the finish kernels, R^-1 is not needed
       tstart(p, "p2_mid");
-      if (!p->mid_part) p->mid_part = p->alloc<double>(mid_part_len(p->d, p->D));
+      if (!p->mid_part) p->mid_part = p->alloc<double>(mid_part_len(mp, p->d, p->D));
       p->merged_x = false;
+      // (U^-T and R~^-T for the "times B^T" products and the finish stage: W~'s and B~^-1's buffers are free on this path)
+      launch_mid_transposes(p->uinv, p->rinv, mp, p->wtil, p->binv, s);
       MidPass2Args a;
-      a.cp = p->cp; a.pts = p->pts(); a.Z = p->Z; a.uinv = p->uinv; a.rinv = p->rinv; a.bvec = p->bvec; a.ttil = p->ttil;
+      a.cp = p->cp; a.pts = p->pts(); a.Z = p->Z; a.rinv = p->rinv; a.uinvT = p->wtil; a.rinvT = p->binv;
+      a.bvec = p->bvec; a.ttil = p->ttil;
       a.V = Vstore; a.y = mo ? nullptr : p->y; a.is = p->is; a.r = p->r;
-      a.big = proj ? p->X : nullptr; a.D = proj ? p->D : 0;
-      a.rows = (int)p->n; a.rows_p = (int)round_up(p->n, TILE); a.m = p->m; a.d = p->d;
+      a.big = proj ? p->X : nullptr; a.D = proj ? p->D : 0; a.shift = p->zshift;
+      a.rows = (int)p->n; a.rows_p = (int)round_up(p->n, TILE); a.m = p->m; a.mp = mp; a.d = p->d;
       a.variational = p->h.variational;
       a.w = p->w; a.v = p->v; a.es = proj ? p->es : nullptr; a.X = p->nchunks == 1 ? bufB : nullptr; a.part = p->mid_part;
       launch_mid_pass2(a, (int)p->col_rows(), ar2, ar2_col, ar2_proj, ar2_tail, s);
@@ -980,6 +988,22 @@ void do_pass2(gprhip_problem* p, const double* ar1, double* ar2) {
         }
       }
       tstop(p);
+      if (mp > TILE) {  // two tiles: G~_part = V^T diag(v) V from the engine, as below
+        tstart(p, "p2_syrk_W");
+        GemmArgsT<TS> wg;
+        wg.A = Vstore; wg.lda = mp; wg.B = Vstore; wg.ldb = mp; wg.C = slices; wg.ldc = mp;
+        wg.M = mp; wg.N = mp; wg.K = (int)p->rows_total_padded(); wg.beta = 0.0;
+        wg.scale_k = row_weights<TS>(p, p->v, p->v_f); wg.upper_only = 1;
+        wg.kslices = p->ks_used; wg.slice_stride = mm;
+        const bool as_ws = p->w_as_ws != 0;
+        if (as_ws) {
+          wg.cs_w = wg.scale_k;
+          wg.cs_out = p->gemvpart;
+        }
+        launch_gemm(OP_TN, wg, s);
+        tstop(p);
+        launch_sum_slices<TS>(nullptr, slices, p->ks_used, mm, mp, ar2, s, 1, gemm_syrk_diag_slices(p->ks_used, !p->f32, as_ws));
+      }
       p->stage = 2;
       return;
     }
@@ -1195,18 +1219,29 @@ void do_finish_enqueue(gprhip_problem* p, const double* ar2, bool light = false)
     return;
   }
   if (p->want_grad && p->use_mid()) {
-    // one 128-block: the m x m work in one workgroup, which also gathers the exchange-2 tail behind the result block
+    // one or two 128-blocks: the m x m work in two launches of one workgroup per 16 rows (mid.hip), the first of which also
+    // gathers the exchange-2 tail behind the result block
     tstart(p, "finish");
     MidFinishArgs a;
-    a.uinv = p->uinv; a.rinv = p->rinv; a.ttil = p->ttil; a.km = p->km; a.Z = p->Z; a.g = ar2;
-    a.m = m; a.d = d; a.km_rows = d + 2;
+    a.uinv = p->uinv; a.rinv = p->rinv; a.uinvT = p->wtil; a.rinvT = p->binv; a.ttil = p->ttil; a.km = p->km; a.Z = p->Z;
+    a.g = ar2;
+    a.m = m; a.mp = mp; a.d = d; a.km_rows = d + 2;
     a.wmat = p->wmat; a.kmred = p->kmred; a.wdiag = wdiag ? p->wdiag : nullptr;
     a.ybuf = p->kj;  // (free after the factorisation of K_m)
     a.gather_from = ar2_col; a.n_gather = n_a2; a.ex = p->ex_dev + A1_TAIL;
     launch_mid_finish(a, s);
     tstop(p);
-    GPR_HIP(hipMemcpyAsync(p->res_host, p->res_dev, (size_t)(p->res_len + A1_TAIL + n_a2) * sizeof(double),
-                           hipMemcpyDeviceToHost, s));
+    {  // (in pieces of at most 32 KB: above that the runtime hands a device-to-host copy to a DMA engine, whose start costs
+       //  ~17 us on this platform where the copy kernel it uses for small transfers takes 2-4 -- timeline at m = 256)
+      const int64_t total = p->res_len + A1_TAIL + n_a2, piece = 4096;
+      for (int64_t o = 0; o < total; o += piece)
+        GPR_HIP(hipMemcpyAsync(p->res_host + o, p->res_dev + o, (size_t)std::min(piece, total - o) * sizeof(double),
+                               hipMemcpyDeviceToHost, s));
+    }
+    // (two tiles: the B~ phase is not the fused single-block kernel that copies the exchange-1 tail into the result block)
+    if (!p->a1_in_scal)
+      GPR_HIP(hipMemcpyAsync(p->ex_host, p->ar1 + packed_upper_len(mp) + mp, A1_TAIL * sizeof(double),
+                             hipMemcpyDeviceToHost, s));
     return;
   }
   if (p->want_grad) {

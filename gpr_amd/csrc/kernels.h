@@ -295,28 +295,31 @@ struct SmallPredictArgs {
 };
 void launch_small_predict(const SmallPredictArgs& a, hipStream_t s);
 
-// ---- 65 .. 128 inducing points (one 128-column tile): one kernel per row pass + one reduction each, and the finish stage
-// in one workgroup (mid.hip).  Same exchange-buffer layout as the engine path; the partial sums are per workgroup.
+// ---- up to 256 inducing points that small.hip does not take (one or two 128-column tiles): one kernel per row pass + one
+// reduction each, and the finish stage in two launches (mid.hip).  Same exchange-buffer layout as the engine path; the partial sums are per workgroup.
 struct MidPass1Args {
   CovParams cp;
   const double *pts, *Z, *uinv, *y;  // points [rows][d], inducing [128][d], U^-1 [128][128], targets (or null)
-  int rows, rows_p, m, d;
+  int rows, rows_p, m, mp, d;        // mp: 128 or 256
   double sigma2;
-  double *V, *r, *is, *yis;          // out: V [rows_p][128] (padding zero), r / is / yis [rows_p]
+  double *V, *r, *is, *yis;          // out: V [rows_p][mp] (padding zero), r / is / yis [rows_p]
   double* part;                      // scratch, mid_part_len doubles
 };
 struct MidPass2Args {
   CovParams cp;
-  const double *pts, *Z, *uinv, *rinv, *bvec, *ttil, *V, *y, *is, *r;
+  const double *pts, *Z, *rinv, *bvec, *ttil, *V, *y, *is, *r;
+  const double *uinvT, *rinvT;       // U^-T, R~^-T (launch_mid_transposes): the operands of the two "times B^T" products
   const double* big;                 // original inputs [rows][D] (Cov_se_fat with tproj) or null
-  int D, rows, rows_p, m, d, variational;
-  double *w, *v, *es, *X;            // out: w, v [rows_p], es [rows_p] (or null), X [rows_p][128] (or null)
+  const double* shift;               // [>= d] centroid of the inducing points: expansion offset of the moments
+  int D, rows, rows_p, m, mp, d, variational;
+  double *w, *v, *es, *X;            // out: w, v [rows_p], es [rows_p] (or null), X [rows_p][mp] (or null)
   double* part;
 };
 struct MidFinishArgs {
   const double *uinv, *rinv, *ttil, *km, *Z;
-  const double* g;                   // 128 x 128 tile of the reduced exchange-2 buffer: G~ = V^T diag(v) V (upper valid)
-  int m, d, km_rows;                 // km_rows: rows of kmred to write (0: sum W.*K, 1: sum W.*K.*dist, 2+k: per dimension)
+  const double *uinvT, *rinvT;       // U^-T, R~^-T (launch_mid_transposes)
+  const double* g;                   // packed upper tiles of the reduced exchange-2 buffer: G~ = V^T diag(v) V
+  int m, mp, d, km_rows;                 // km_rows: rows of kmred to write (0: sum W.*K, 1: sum W.*K.*dist, 2+k: per dimension)
   double *wmat, *kmred, *wdiag;      // out (wdiag may be null)
   double* ybuf;                      // 128 x 128 scratch: Y = W~ U^-T between the two launches
   const double* gather_from;         // n_gather doubles copied to ex (the exchange-2 tail behind the result block)
@@ -324,10 +327,11 @@ struct MidFinishArgs {
   double* ex;
 };
 bool mid_path_fits(int m, int mp, int d, int D, int64_t rows, bool ms);
-int64_t mid_part_len(int d, int D);
+int64_t mid_part_len(int mp, int d, int D);
 void launch_mid_pass1(const MidPass1Args& a, double* tile, double* cvec, double* tail, hipStream_t s);
 void launch_mid_pass2(const MidPass2Args& a, int col_rows, double* tile, double* colblk, double* proj, double* tail,
                       hipStream_t s);
 void launch_mid_finish(const MidFinishArgs& a, hipStream_t s);
+void launch_mid_transposes(const double* uinv, const double* rinv, int mp, double* uinvT, double* rinvT, hipStream_t s);
 
 }  // namespace gprhip

@@ -31,20 +31,51 @@ namespace gprhip {
 
 namespace {
 
-constexpr int MP = 128;        // padded inducing points of the mid path = one engine tile
-constexpr int MLD = 130;       // leading dimension of the 64 x 128 LDS tiles (row stride 260 dwords = 4 mod 64: the
-                               //   half-wave fragment reads fall on 64 different banks, as SLD = 66 in small.hip)
-constexpr int MRB = 64;        // training points per block
-constexpr int MCT = 8;         // 16-column tiles
+// Geometry by padded inducing-point count MPV (128: m <= 128; 256: 129 .. 256, "two tiles"): the row block shrinks with the
+// tile width so that a block's tile stays 64 KB; the two-tile form leaves both Gram accumulations to the engine's SYRK-shaped
+// launches (136 upper 16 x 16 tiles are 272 accumulator registers per wavefront, and 280 KB of partial sums per workgroup).
+template <int MPV>
+struct MidGeo {
+  static constexpr int MP = MPV;          // padded inducing points
+  static constexpr int MLD = MPV + 2;     // leading dimension of the LDS tiles (row stride = 4 dwords mod 64: the half-wave
+                                          //   fragment reads fall on 64 different banks, as SLD = 66 in small.hip)
+  static constexpr int MRB = MPV == 128 ? 64 : 32;  // training points per block
+  static constexpr int MCT = MPV / 16;    // 16-column tiles
+  static constexpr int NJ = MCT / 4;      // ... per wavefront
+  static constexpr int RT = MRB / 16;     // 16-row tiles of a block
+  static constexpr bool GRAM = MPV == 128;
+};
+// 16-column tile jj (ascending) of wavefront W: {W, 7 - W} or {W, 7 - W, 8 + W, 15 - W} -- for an upper-triangular operand
+// tile j is 16 (j + 1) rows deep, so every wavefront gets the same number of k-batches (9 / 34)
+template <int MPV, int W>
+__host__ __device__ constexpr int wave_tile(int jj) {
+  return jj == 0 ? W : jj == 1 ? 7 - W : jj == 2 ? 8 + W : 15 - W;
+}
+__device__ __forceinline__ int wave_tile_rt(int mpv, int wv, int jj) {
+  return jj == 0 ? wv : jj == 1 ? 7 - wv : jj == 2 ? 8 + wv : 15 - wv;
+}
+
+constexpr int MP = 128;        // the one-tile geometry, spelled out for the Gram code (which exists for it only)
+constexpr int MLD = 130;
+constexpr int MRB = 64;
+constexpr int MCT = 8;
 constexpr int MNTU = 36;       // upper 16 x 16 tiles of a 128 x 128 symmetric accumulation
 constexpr int MGLEN = MNTU * 256;
 constexpr int M1LEN = MGLEN + MP + 4;  // pass-1 partial: B~ upper tiles | c~ part | sum log s, sum y^2/s, sum r/s, -
 // pass-2 partial: G~ upper tiles | moment rows (1, p_k (d), x_big (D)) x 128 | 8 scalars
 __host__ __device__ constexpr int m2len(int d, int D) { return MGLEN + (1 + d + D) * MP + 8; }
+// two tiles: pass-1 partial = the four scalars, pass-2 partial = moment rows x 256 | 8 scalars
+constexpr int W1LEN = 4;
+__host__ __device__ constexpr int w2len(int d, int D) { return (1 + d + D) * 256 + 8; }
 // index of upper tile (it <= jt), row-major over the upper triangle
 __host__ __device__ constexpr int tix(int it, int jt) { return it * MCT - it * (it - 1) / 2 + (jt - it); }
 
 typedef double sd4 __attribute__((ext_vector_type(4)));
+// A pointer into device memory that says so: the triangular operands are fetched through pointers laundered once per block
+// (see mid_pass1_body), and a laundered pointer of plain type is a generic one -- its loads become flat_load, which may hit
+// the LDS as far as the hardware knows, so every use waits for ALL outstanding memory AND LDS operations
+// (s_waitcnt vmcnt(0) lgkmcnt(0) in front of every k-batch: no load ever overlapped an MFMA).
+typedef const __attribute__((address_space(1))) double* gmem_ptr;
 // lane supplies A[lane&15][lane>>4] and B[lane>>4][lane&15]; accumulator element r is D[(lane>>4) + 4r][lane&15]
 __device__ __forceinline__ sd4 mfma_f64(double a, double b, sd4 c) {
   return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
@@ -62,121 +93,120 @@ __device__ __forceinline__ double sum64(double v) {
   return v;
 }
 
-// acc[i][jj] = rows 16 i .. 16 i + 15 of A (LDS, [64][MLD]) times columns of tile J_jj (J_0 = W, J_1 = 7 - W) of the
-// upper-triangular B (memory, row-major [128][128], exact zeros below the diagonal): tile j needs k < 16 (j + 1) only, i.e.
-// the k-batches kb <= j.  The B fragments of batch kb + 1 are requested before the MFMAs of batch kb.  The batch loop stays
-// ROLLED, its operand pointers stepping by one batch: fully unrolled, each of the ~70 fragment loads gets an address
-// register of its own (a k-step is 1 KB of B away from the next, beyond the instruction's immediate offset), all of them
-// loop-invariant and therefore computed in front of the block loop and spilled.
-template <int W>
-__device__ __forceinline__ void tri_nn(const double* A, const double* __restrict__ B, int l15, int lq, sd4 (&acc)[4][2]) {
-  constexpr int J0 = W, J1 = 7 - W;
-  static_assert(J0 < J1, "tile pairing");
+// acc[i][jj] = rows 16 i .. 16 i + 15 of A (LDS, [MRB][MLD]) times the columns of this wavefront's tile jj of the
+// upper-triangular B (memory, row-major [MP][MP], exact zeros below the diagonal): tile j needs k < 16 (j + 1) only, i.e.
+// the k-batches kb <= j.  The batch loop stays ROLLED, its operand pointers stepping by one batch: fully unrolled, each of
+// the fragment loads gets an address register of its own (a k-step is 1-2 KB of B away from the next, beyond the
+// instruction's immediate offset), all of them loop-invariant and therefore computed in front of the block loop and
+// spilled.  Fragments of the batch in hand and of the two behind it are in registers: a batch is 16-32 MFMAs (1000-2000
+// cycles), one of them does not cover a round trip to the L2.
+// Three fragment buffers used in place, the loop unrolled by three: the loads of batch kb + 2 go out before the MFMAs of
+// batch kb, and nothing ever copies a buffer (a register move would have to wait for the load it moves -- with two
+// buffers rotated by moves every batch waited for the loads issued at its own top: a memory round trip per batch, 25 of
+// pass 2's 49 us at n = 2000, m = 128).  Every stage issues the same number of loads (row / column indices clamped into the
+// matrix where a tile no longer needs them) so that the waits in front of the MFMAs count exactly.
+template <int MPV, int W>
+__device__ __forceinline__ void tri_nn(const double* A, gmem_ptr B, int l15, int lq,
+                                       sd4 (&acc)[MidGeo<MPV>::RT][MidGeo<MPV>::NJ]) {
+  using G = MidGeo<MPV>;
+  constexpr int NJ = G::NJ, RT = G::RT, LDA = G::MLD, LDB = G::MP;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) acc[i][0] = acc[i][1] = sd4{0.0, 0.0, 0.0, 0.0};
-  const double* bp = B + lq * MP + l15;   // B[4 s + lq][l15] of batch kb at bp + (16 kb + 4 s) MP
-  const double* ap = A + l15 * MLD + lq;  // A[16 i + l15][4 s + lq] at ap + 16 i MLD + 4 s
-  // fragments of the batch in hand and of the two behind it: a batch is 16-32 MFMAs (1000-2000 cycles), one of them does
-  // not cover a round trip to the L2
-  double cur[4][2], nx1[4][2], nx2[4][2];
+  for (int i = 0; i < RT; ++i)
 #pragma unroll
-  for (int s = 0; s < 4; ++s) {
-    cur[s][1] = bp[4 * s * MP + 16 * J1];
-    cur[s][0] = bp[4 * s * MP + 16 * J0];
-    nx1[s][1] = bp[(16 + 4 * s) * MP + 16 * J1];                 // (J1 >= 4: batch 1 exists)
-    nx1[s][0] = J0 >= 1 ? bp[(16 + 4 * s) * MP + 16 * J0] : 0.0;
-    nx2[s][0] = nx2[s][1] = 0.0;
-  }
-  bp += 32 * MP;
-#pragma unroll 1
-  for (int kb = 0; kb <= J1; ++kb) {
-    if (kb + 2 <= J1) {
-#pragma unroll
-      for (int s = 0; s < 4; ++s) nx2[s][1] = bp[4 * s * MP + 16 * J1];
-      if (kb + 2 <= J0) {
-#pragma unroll
-        for (int s = 0; s < 4; ++s) nx2[s][0] = bp[4 * s * MP + 16 * J0];
-      }
-    }
-    bp += 16 * MP;
-    double af[4][4];
+    for (int jj = 0; jj < NJ; ++jj) acc[i][jj] = sd4{0.0, 0.0, 0.0, 0.0};
+  const gmem_ptr bq = B + lq * LDB + l15;        // B[16 kb + 4 s + lq][16 J + l15] at bq + (16 kb + 4 s) LDB + 16 J
+  const double* ap = A + l15 * LDA + lq;         // A[16 i + l15][16 kb + 4 s + lq] at ap + 16 i LDA + 4 s, ap stepping by 16
+  constexpr int JL = wave_tile<MPV, W>(NJ - 1);
+  double buf[3][4][NJ];
+  auto fetch = [&](int kb, double (&dst)[4][NJ]) {
+    const gmem_ptr bk = bq + (int64_t)16 * min(kb, G::MCT - 1) * LDB;
 #pragma unroll
     for (int s = 0; s < 4; ++s)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) af[s][i] = ap[16 * i * MLD + 4 * s];
+      for (int jj = 0; jj < NJ; ++jj) dst[s][jj] = bk[4 * s * LDB + 16 * wave_tile<MPV, W>(jj)];
+  };
+  auto work = [&](int kb, const double (&src)[4][NJ]) {
+    double af[4][RT];
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int i = 0; i < RT; ++i) af[s][i] = ap[16 * i * LDA + 4 * s];
     ap += 16;
 #pragma unroll
-    for (int s = 0; s < 4; ++s)
+    for (int jj = NJ - 1; jj >= 0; --jj)
+      if (kb <= wave_tile<MPV, W>(jj)) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) acc[i][1] = mfma_f64(af[s][i], cur[s][1], acc[i][1]);
-    if (kb <= J0) {
+        for (int s = 0; s < 4; ++s)
 #pragma unroll
-      for (int s = 0; s < 4; ++s)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) acc[i][0] = mfma_f64(af[s][i], cur[s][0], acc[i][0]);
-    }
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      cur[s][0] = nx1[s][0];
-      cur[s][1] = nx1[s][1];
-      nx1[s][0] = nx2[s][0];
-      nx1[s][1] = nx2[s][1];
-    }
+          for (int i = 0; i < RT; ++i) acc[i][jj] = mfma_f64(af[s][i], src[s][jj], acc[i][jj]);
+      }
+  };
+  fetch(0, buf[0]);
+  fetch(1, buf[1]);
+#pragma unroll 1
+  for (int kb = 0; kb <= JL; kb += 3) {
+    fetch(kb + 2, buf[2]);
+    work(kb, buf[0]);
+    if (kb + 1 > JL) break;
+    fetch(kb + 3, buf[0]);
+    work(kb + 1, buf[1]);
+    if (kb + 2 > JL) break;
+    fetch(kb + 4, buf[1]);
+    work(kb + 2, buf[2]);
   }
 }
 
-// ... times B^T: out[r][c] = sum_k A[r][k] B[c][k], B upper triangular: tile j needs k >= 16 j, the batches kb >= j
-template <int W>
-__device__ __forceinline__ void tri_nt(const double* A, const double* __restrict__ B, int l15, int lq, sd4 (&acc)[4][2]) {
-  constexpr int J0 = W, J1 = 7 - W;
+// ... times B^T, given Bt = B^T in memory: out[r][c] = sum_k A[r][k] Bt[k][c], B upper triangular: tile j needs k >= 16 j, the
+// batches kb >= j.  (Fetched from B itself a fragment load touches 16 rows of 32 bytes each -- sixteen cache lines per
+// instruction, a quarter of each used -- and the texture path, not the matrix pipe, sets the pace: the two-tile pass 2 took
+// 80 us per block for 22 us of MFMAs.  From the transposed copy it is four full lines, as in tri_nn.)
+template <int MPV, int W>
+__device__ __forceinline__ void tri_nt(const double* A, gmem_ptr Bt, int l15, int lq,
+                                       sd4 (&acc)[MidGeo<MPV>::RT][MidGeo<MPV>::NJ]) {
+  using G = MidGeo<MPV>;
+  constexpr int NJ = G::NJ, RT = G::RT, LDA = G::MLD, LDB = G::MP, J0 = wave_tile<MPV, W>(0);
 #pragma unroll
-  for (int i = 0; i < 4; ++i) acc[i][0] = acc[i][1] = sd4{0.0, 0.0, 0.0, 0.0};
-  const double* bp = B + l15 * MP + lq + 16 * J0;   // B[16 J + l15][16 kb + 4 s + lq] at bp + 16 J MP + 16 (kb - J0) + 4 s
-  const double* ap = A + l15 * MLD + lq + 16 * J0;
-  double cur[4][2], nx1[4][2], nx2[4][2];
+  for (int i = 0; i < RT; ++i)
 #pragma unroll
-  for (int s = 0; s < 4; ++s) {
-    cur[s][0] = bp[16 * J0 * MP + 4 * s];
-    cur[s][1] = 0.0;                                              // (J0 < J1: tile J1 joins later)
-    nx1[s][0] = bp[16 * J0 * MP + 16 + 4 * s];                    // (J0 <= 3: batch J0 + 1 exists)
-    nx1[s][1] = J0 + 1 >= J1 ? bp[16 * J1 * MP + 16 + 4 * s] : 0.0;
-    nx2[s][0] = nx2[s][1] = 0.0;
-  }
-  bp += 32;
-#pragma unroll 1
-  for (int kb = J0; kb < MCT; ++kb) {
-    if (kb + 2 < MCT) {
-#pragma unroll
-      for (int s = 0; s < 4; ++s) nx2[s][0] = bp[16 * J0 * MP + 4 * s];
-      if (kb + 2 >= J1) {
-#pragma unroll
-        for (int s = 0; s < 4; ++s) nx2[s][1] = bp[16 * J1 * MP + 4 * s];
-      }
-    }
-    bp += 16;
-    double af[4][4];
+    for (int jj = 0; jj < NJ; ++jj) acc[i][jj] = sd4{0.0, 0.0, 0.0, 0.0};
+  const gmem_ptr bq = Bt + lq * LDB + l15;           // Bt[16 kb + 4 s + lq][16 J + l15] at bq + (16 kb + 4 s) LDB + 16 J
+  const double* ap = A + l15 * LDA + lq + 16 * J0;
+  double buf[3][4][NJ];
+  auto fetch = [&](int kb, double (&dst)[4][NJ]) {
+    const gmem_ptr bk = bq + (int64_t)16 * min(kb, G::MCT - 1) * LDB;
 #pragma unroll
     for (int s = 0; s < 4; ++s)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) af[s][i] = ap[16 * i * MLD + 4 * s];
+      for (int jj = 0; jj < NJ; ++jj) dst[s][jj] = bk[4 * s * LDB + 16 * wave_tile<MPV, W>(jj)];
+  };
+  auto work = [&](int kb, const double (&src)[4][NJ]) {
+    double af[4][RT];
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int i = 0; i < RT; ++i) af[s][i] = ap[16 * i * LDA + 4 * s];
     ap += 16;
 #pragma unroll
-    for (int s = 0; s < 4; ++s)
+    for (int jj = 0; jj < NJ; ++jj)
+      if (kb >= wave_tile<MPV, W>(jj)) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) acc[i][0] = mfma_f64(af[s][i], cur[s][0], acc[i][0]);
-    if (kb >= J1) {
+        for (int s = 0; s < 4; ++s)
 #pragma unroll
-      for (int s = 0; s < 4; ++s)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) acc[i][1] = mfma_f64(af[s][i], cur[s][1], acc[i][1]);
-    }
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      cur[s][0] = nx1[s][0];
-      cur[s][1] = nx1[s][1];
-      nx1[s][0] = nx2[s][0];
-      nx1[s][1] = nx2[s][1];
-    }
+          for (int i = 0; i < RT; ++i) acc[i][jj] = mfma_f64(af[s][i], src[s][jj], acc[i][jj]);
+      }
+  };
+  fetch(J0, buf[0]);
+  fetch(J0 + 1, buf[1]);
+#pragma unroll 1
+  for (int kb = J0; kb < G::MCT; kb += 3) {
+    fetch(kb + 2, buf[2]);
+    work(kb, buf[0]);
+    if (kb + 1 >= G::MCT) break;
+    fetch(kb + 3, buf[0]);
+    work(kb + 1, buf[1]);
+    if (kb + 2 >= G::MCT) break;
+    fetch(kb + 4, buf[1]);
+    work(kb + 2, buf[2]);
   }
 }
 
@@ -242,14 +272,20 @@ __device__ __forceinline__ double sum_parts(const double* __restrict__ part, int
 }  // namespace
 
 // workgroups of a pass at most (each walks blocks b, b + groups, ...): one per CU (pass 2 fills the LDS; the per-workgroup
-// partials are 75 KB each)
+// partials of the one-tile form are 75 KB each)
 constexpr int MID_GROUPS = 256;
-int64_t mid_part_len(int d, int D) { return (int64_t)MID_GROUPS * std::max(M1LEN, m2len(d, D)); }
-static int mid_groups(int rows_p) { return std::min(MID_GROUPS, rows_p / MRB); }
+int64_t mid_part_len(int mp, int d, int D) {
+  return (int64_t)MID_GROUPS * (mp == 128 ? std::max(M1LEN, m2len(d, D)) : std::max(W1LEN, w2len(d, D)));
+}
+template <int MPV>
+static int mid_groups(int rows_p) { return std::min(MID_GROUPS, rows_p / MidGeo<MPV>::MRB); }
 
 // ---------------------------------------------------------------------------------------------------------------- pass 1
-template <int DT, int W>
+template <int MPV, int DT, int W>
 __device__ __forceinline__ void mid_pass1_body(const MidPass1Args& a, double* lds) {
+  using G = MidGeo<MPV>;
+  constexpr int MP = G::MP, MLD = G::MLD, MRB = G::MRB, NJ = G::NJ, RT = G::RT;
+  constexpr bool GRAM = G::GRAM;
   double* const Kt = lds;              // [MRB][MLD] K of the block, then V in place
   double* const xs = Kt + MRB * MLD;   // [MRB][DT]
   double* const isr = xs + MRB * DT;   // [MRB] 1/s
@@ -257,14 +293,14 @@ __device__ __forceinline__ void mid_pass1_body(const MidPass1Args& a, double* ld
   double* const rsp = yisr + MRB;      // [4][MRB] row sums of V.^2 over each wavefront's columns
   const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, lq = lane >> 4;
   const ExpK ek = exp_consts();
-  const int col = tid & (MP - 1), rg = tid >> 7;  // covariance / column-sum phases: thread = (column, half of the rows)
+  const int col = tid % MP, rg = tid / MP;  // covariance / column-sum phases: thread = (column, 32 of the block's rows)
   const bool live_c = col < a.m;
   double z[DT];
 #pragma unroll
   for (int k = 0; k < DT; ++k) z[k] = (k < a.d && live_c) ? a.Z[(int64_t)col * a.d + k] : 0.0;
-  sd4 accB[9];
+  sd4 accB[GRAM ? 9 : 1];
 #pragma unroll
-  for (int q = 0; q < 9; ++q) accB[q] = sd4{0.0, 0.0, 0.0, 0.0};
+  for (int q = 0; q < (GRAM ? 9 : 1); ++q) accB[q] = sd4{0.0, 0.0, 0.0, 0.0};
   double csum = 0.0, p_log = 0.0, p_y2 = 0.0, p_isr = 0.0;
   const int nblk = a.rows_p / MRB;
   for (int b = blockIdx.x; b < nblk; b += gridDim.x) {
@@ -279,7 +315,7 @@ __device__ __forceinline__ void mid_pass1_body(const MidPass1Args& a, double* ld
     {
       const double* xq = xs + rg * 32 * DT;
       double* kq = Kt + rg * 32 * MLD + col;
-      const int rlive = a.rows - r0 - rg * 32;  // rows i < rlive of this half are real
+      const int rlive = a.rows - r0 - rg * 32;  // rows i < rlive of this thread's 32 are real
 #pragma unroll 4
       for (int i = 0; i < 32; ++i) {
         double acc = 0.0;
@@ -292,17 +328,20 @@ __device__ __forceinline__ void mid_pass1_body(const MidPass1Args& a, double* ld
       }
     }
     __syncthreads();
-    sd4 acc[4][2];
+    sd4 acc[RT][NJ];
     // (the operand pointer is laundered per block: left loop-invariant, every B fragment of the product -- 72 loads -- is
     //  hoisted in front of the block loop and held in registers, in pass 2 -- three products -- spilled to scratch)
-    const double* uinv = a.uinv;
+    gmem_ptr uinv = (gmem_ptr)a.uinv;
     asm volatile("" : "+s"(uinv));
-    tri_nn<W>(Kt, uinv, l15, lq, acc);  // V = K U^-1
+    tri_nn<MPV, W>(Kt, uinv, l15, lq, acc);  // V = K U^-1
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < RT; ++i)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const double s = sum16(acc[i][0][r] * acc[i][0][r] + acc[i][1][r] * acc[i][1][r]);
+        double s = 0.0;
+#pragma unroll
+        for (int jj = 0; jj < NJ; ++jj) s += acc[i][jj][r] * acc[i][jj][r];
+        s = sum16(s);
         if (l15 == 0) (rsp + lq)[W * MRB + 16 * i + 4 * r] = s;
       }
     __syncthreads();  // every wavefront is done reading K
@@ -310,14 +349,13 @@ __device__ __forceinline__ void mid_pass1_body(const MidPass1Args& a, double* ld
       double* kq = Kt + lq * MLD + l15;                         // element r of acc[i][jj] is row 16 i + lq + 4 r,
       double* vq = a.V + (int64_t)(r0 + lq) * MP + l15;         //   column 16 J_jj + l15
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < RT; ++i)
 #pragma unroll
         for (int r = 0; r < 4; ++r)
 #pragma unroll
-          for (int jj = 0; jj < 2; ++jj) {
-            constexpr int JW[2] = {W, 7 - W};
-            kq[(16 * i + 4 * r) * MLD + 16 * JW[jj]] = acc[i][jj][r];
-            vq[(16 * i + 4 * r) * MP + 16 * JW[jj]] = acc[i][jj][r];
+          for (int jj = 0; jj < NJ; ++jj) {
+            if (GRAM) kq[(16 * i + 4 * r) * MLD + 16 * wave_tile<MPV, W>(jj)] = acc[i][jj][r];
+            vq[(16 * i + 4 * r) * MP + 16 * wave_tile<MPV, W>(jj)] = acc[i][jj][r];
           }
     }
     if (tid < MRB) {  // r, s = r + sigma2, 1/s, sum log s  (as pass1_rows_kernel)
@@ -339,42 +377,46 @@ __device__ __forceinline__ void mid_pass1_body(const MidPass1Args& a, double* ld
       isr[tid] = is;
       yisr[tid] = yis;
     }
-    __syncthreads();
-    gram_update<W>(Kt, isr, l15, lq, accB);
-    {
+    if constexpr (GRAM) {
+      __syncthreads();
+      gram_update<W>(Kt, isr, l15, lq, accB);
       const double* kq = Kt + rg * 32 * MLD + col;
       const double* yq = yisr + rg * 32;
 #pragma unroll 8
       for (int i = 0; i < 32; ++i) csum += kq[i * MLD] * yq[i];
     }
   }
-  double* part = a.part + (int64_t)blockIdx.x * M1LEN;
-  store_gram<W>(part, accB, l15, lq);
-  __syncthreads();
-  Kt[rg * MLD + col] = csum;
-  __syncthreads();
-  if (tid < MP) part[MGLEN + tid] = Kt[tid] + Kt[MLD + tid];
+  double* part = a.part + (int64_t)blockIdx.x * (GRAM ? M1LEN : W1LEN);
+  double* ptail = part;
+  if constexpr (GRAM) {
+    store_gram<W>(part, accB, l15, lq);
+    __syncthreads();
+    Kt[rg * MLD + col] = csum;
+    __syncthreads();
+    if (tid < MP) part[MGLEN + tid] = Kt[tid] + Kt[MLD + tid];
+    ptail = part + MGLEN + MP;
+  }
   if (W == 0) {
     p_log = sum64(p_log);
     p_y2 = sum64(p_y2);
     p_isr = sum64(p_isr);
     if (lane == 0) {
-      part[MGLEN + MP + 0] = p_log;
-      part[MGLEN + MP + 1] = p_y2;
-      part[MGLEN + MP + 2] = p_isr;
-      part[MGLEN + MP + 3] = 0.0;
+      ptail[0] = p_log;
+      ptail[1] = p_y2;
+      ptail[2] = p_isr;
+      ptail[3] = 0.0;
     }
   }
 }
 
-template <int DT>
+template <int MPV, int DT>
 __global__ __launch_bounds__(256) void mid_pass1_kernel(MidPass1Args a) {
   extern __shared__ __attribute__((aligned(16))) double mid_lds[];
   switch (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)) {  // (a scalar: the branch is uniform, no lane masking)
-    case 0: mid_pass1_body<DT, 0>(a, mid_lds); break;
-    case 1: mid_pass1_body<DT, 1>(a, mid_lds); break;
-    case 2: mid_pass1_body<DT, 2>(a, mid_lds); break;
-    default: mid_pass1_body<DT, 3>(a, mid_lds); break;
+    case 0: mid_pass1_body<MPV, DT, 0>(a, mid_lds); break;
+    case 1: mid_pass1_body<MPV, DT, 1>(a, mid_lds); break;
+    case 2: mid_pass1_body<MPV, DT, 2>(a, mid_lds); break;
+    default: mid_pass1_body<MPV, DT, 3>(a, mid_lds); break;
   }
 }
 
@@ -400,8 +442,11 @@ __global__ __launch_bounds__(256) void mid_reduce1_kernel(const double* __restri
 
 // ---------------------------------------------------------------------------------------------------------------- pass 2
 // NMT: 16-row tiles of the moment matrix [1 | p_1 .. p_d | x_big,1 .. x_big,D] (1 + d + D <= 16 NMT, NMT <= 2)
-template <int DT, int NMT, int W>
+template <int MPV, int DT, int NMT, int W>
 __device__ __forceinline__ void mid_pass2_body(const MidPass2Args& a, double* lds) {
+  using G = MidGeo<MPV>;
+  constexpr int MP = G::MP, MLD = G::MLD, MRB = G::MRB, NJ = G::NJ, RT = G::RT;
+  constexpr bool GRAM = G::GRAM;
   constexpr int LDM = 16 * NMT + 2;
   double* const Vt = lds;               // [MRB][MLD] V of the block
   double* const Qt = Vt + MRB * MLD;    // [MRB][MLD] Q', then X~, then X, then E, each in place
@@ -417,21 +462,27 @@ __device__ __forceinline__ void mid_pass2_body(const MidPass2Args& a, double* ld
   const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, lq = lane >> 4;
   const ExpK ek = exp_consts();
   const int d = a.d, D = a.D, nmom = 1 + d + D;
-  if (tid < MP) {
-    bv[tid] = a.bvec[tid];
-    tt[tid] = a.ttil[tid];
+  for (int idx = tid; idx < MP; idx += 256) {
+    bv[idx] = a.bvec[idx];
+    tt[idx] = a.ttil[idx];
   }
-  const int col = tid & (MP - 1), rg = tid >> 7;
+  const int col = tid % MP, rg = tid / MP;
   const bool live_c = col < a.m;
+  // Points and inducing coordinates enter this pass shifted by the centroid of the inducing points (a.shift): the moments
+  // sum_r p_kr E_rc of data far from the origin (offset 1e4 at unit spread) would otherwise carry the offset through 3000
+  // additions of mixed sign and lose it again in the host's p - z; mid_reduce2_kernel adds shift_k sum_r E_rc back once,
+  // after the workgroups' sums (as grad_mfma_kernel does per slab).  The distances are differences either way.
   double z[DT];
 #pragma unroll
-  for (int k = 0; k < DT; ++k) z[k] = (k < d && live_c) ? a.Z[(int64_t)col * d + k] : 0.0;
-  sd4 accG[9];
+  for (int k = 0; k < DT; ++k) z[k] = (k < d && live_c) ? a.Z[(int64_t)col * d + k] - a.shift[k] : 0.0;
+  sd4 accG[GRAM ? 9 : 1];
 #pragma unroll
-  for (int q = 0; q < 9; ++q) accG[q] = sd4{0.0, 0.0, 0.0, 0.0};
-  sd4 accM[NMT][2];  // moments of E: rows 16 mt .., column tiles W and W + 4
+  for (int q = 0; q < (GRAM ? 9 : 1); ++q) accG[q] = sd4{0.0, 0.0, 0.0, 0.0};
+  sd4 accM[NMT][NJ];  // moments of E: rows 16 mt .., column tiles W + 4 jj
 #pragma unroll
-  for (int mt = 0; mt < NMT; ++mt) accM[mt][0] = accM[mt][1] = sd4{0.0, 0.0, 0.0, 0.0};
+  for (int mt = 0; mt < NMT; ++mt)
+#pragma unroll
+    for (int jj = 0; jj < NJ; ++jj) accM[mt][jj] = sd4{0.0, 0.0, 0.0, 0.0};
   double sE = 0.0, sED = 0.0;
   double p_v = 0.0, p_is = 0.0, p_res = 0.0, p_v1 = 0.0;
   const int nblk = a.rows_p / MRB;
@@ -443,21 +494,21 @@ __device__ __forceinline__ void mid_pass2_body(const MidPass2Args& a, double* ld
       double v = 0.0;
       if (r0 + r < a.rows) {
         if (q == 0) v = 1.0;
-        else if (q <= d) v = a.pts[(int64_t)(r0 + r) * d + (q - 1)];
+        else if (q <= d) v = a.pts[(int64_t)(r0 + r) * d + (q - 1)] - a.shift[q - 1];
         else if (q < nmom) v = a.big[(int64_t)(r0 + r) * D + (q - 1 - d)];
       }
       Mx[r * LDM + q] = v;
     }
-    {  // V of the block: 64 rows x 128 columns, sixteen 16-byte loads per thread, all issued before the first store
+    {  // V of the block (8192 entries): sixteen 16-byte loads per thread, all issued before the first store
       double2 v[16];
 #pragma unroll
       for (int j = 0; j < 16; ++j) {
-        const int idx = tid + 256 * j, r = idx >> 6, c2 = (idx & 63) * 2;
+        const int idx = tid + 256 * j, r = idx / (MP / 2), c2 = (idx % (MP / 2)) * 2;
         v[j] = *reinterpret_cast<const double2*>(a.V + (int64_t)(r0 + r) * MP + c2);
       }
 #pragma unroll
       for (int j = 0; j < 16; ++j) {
-        const int idx = tid + 256 * j, r = idx >> 6, c2 = (idx & 63) * 2;
+        const int idx = tid + 256 * j, r = idx / (MP / 2), c2 = (idx % (MP / 2)) * 2;
         *reinterpret_cast<double2*>(Vt + r * MLD + c2) = v[j];
       }
     }
@@ -466,23 +517,29 @@ __device__ __forceinline__ void mid_pass2_body(const MidPass2Args& a, double* ld
     const double rreg = rowlive ? a.r[r0 + tid] : 0.0;
     const double yreg = (rowlive && a.y) ? a.y[r0 + tid] : 0.0;
     __syncthreads();
-    sd4 acc[4][2];
-    const double *uinv = a.uinv, *rinv = a.rinv;  // (laundered per block, see pass 1)
-    asm volatile("" : "+s"(uinv), "+s"(rinv));
-    tri_nn<W>(Vt, rinv, l15, lq, acc);  // Q' = V R~^-1
-    constexpr int JW[2] = {W, 7 - W};
+    sd4 acc[RT][NJ];
+    gmem_ptr rinv = (gmem_ptr)a.rinv, rinvT = (gmem_ptr)a.rinvT, uinvT = (gmem_ptr)a.uinvT;  // (laundered per block, see pass 1)
+    asm volatile("" : "+s"(rinv), "+s"(rinvT), "+s"(uinvT));
+    tri_nn<MPV, W>(Vt, rinv, l15, lq, acc);  // Q' = V R~^-1
     double* const qq = Qt + lq * MLD + l15;        // element r of acc[i][jj] is row 16 i + lq + 4 r, column 16 J_jj + l15
     const double* const vq = Vt + lq * MLD + l15;
     {
-      const double b0 = bv[16 * JW[0] + l15], b1 = bv[16 * JW[1] + l15];
+      double bj[NJ];
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int jj = 0; jj < NJ; ++jj) bj[jj] = bv[16 * wave_tile<MPV, W>(jj) + l15];
+#pragma unroll
+      for (int i = 0; i < RT; ++i)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          qq[(16 * i + 4 * r) * MLD + 16 * JW[0]] = acc[i][0][r];
-          qq[(16 * i + 4 * r) * MLD + 16 * JW[1]] = acc[i][1][r];
-          const double s2 = sum16(acc[i][0][r] * acc[i][0][r] + acc[i][1][r] * acc[i][1][r]);
-          const double sb = sum16(acc[i][0][r] * b0 + acc[i][1][r] * b1);
+          double s2 = 0.0, sb = 0.0;
+#pragma unroll
+          for (int jj = 0; jj < NJ; ++jj) {
+            qq[(16 * i + 4 * r) * MLD + 16 * wave_tile<MPV, W>(jj)] = acc[i][jj][r];
+            s2 += acc[i][jj][r] * acc[i][jj][r];
+            sb += acc[i][jj][r] * bj[jj];
+          }
+          s2 = sum16(s2);
+          sb = sum16(sb);
           if (l15 == 0) {
             (q2p + lq)[W * MRB + 16 * i + 4 * r] = s2;
             (qbp + lq)[W * MRB + 16 * i + 4 * r] = sb;
@@ -515,35 +572,40 @@ __device__ __forceinline__ void mid_pass2_body(const MidPass2Args& a, double* ld
       wr[tid] = w;
       vr[tid] = v;
     }
-    tri_nt<W>(Qt, rinv, l15, lq, acc);  // Q' R~^-T
+    tri_nt<MPV, W>(Qt, rinvT, l15, lq, acc);  // Q' R~^-T
     __syncthreads();  // every wavefront is done reading Q'; the row values are there
     {
-      const double t0 = tt[16 * JW[0] + l15], t1 = tt[16 * JW[1] + l15];
+      double tj[NJ];
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int jj = 0; jj < NJ; ++jj) tj[jj] = tt[16 * wave_tile<MPV, W>(jj) + l15];
+#pragma unroll
+      for (int i = 0; i < RT; ++i)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {  // X~ = diag(is) Q' R~^-T - diag(v) V - w t~^T
           const double is = (isr + lq)[16 * i + 4 * r], v = (vr + lq)[16 * i + 4 * r], w = (wr + lq)[16 * i + 4 * r];
-          qq[(16 * i + 4 * r) * MLD + 16 * JW[0]] = is * acc[i][0][r] - v * vq[(16 * i + 4 * r) * MLD + 16 * JW[0]] - w * t0;
-          qq[(16 * i + 4 * r) * MLD + 16 * JW[1]] = is * acc[i][1][r] - v * vq[(16 * i + 4 * r) * MLD + 16 * JW[1]] - w * t1;
+#pragma unroll
+          for (int jj = 0; jj < NJ; ++jj) {
+            const int off = (16 * i + 4 * r) * MLD + 16 * wave_tile<MPV, W>(jj);
+            qq[off] = is * acc[i][jj][r] - v * vq[off] - w * tj[jj];
+          }
         }
     }
     __syncthreads();
-    tri_nt<W>(Qt, uinv, l15, lq, acc);  // X = X~ U^-T
+    tri_nt<MPV, W>(Qt, uinvT, l15, lq, acc);  // X = X~ U^-T
     __syncthreads();
     {
       double* xg = a.X ? a.X + (int64_t)(r0 + lq) * MP + l15 : nullptr;
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < RT; ++i)
 #pragma unroll
         for (int r = 0; r < 4; ++r)
 #pragma unroll
-          for (int jj = 0; jj < 2; ++jj) {
-            qq[(16 * i + 4 * r) * MLD + 16 * JW[jj]] = acc[i][jj][r];
-            if (xg) xg[(16 * i + 4 * r) * MP + 16 * JW[jj]] = acc[i][jj][r];
+          for (int jj = 0; jj < NJ; ++jj) {
+            qq[(16 * i + 4 * r) * MLD + 16 * wave_tile<MPV, W>(jj)] = acc[i][jj][r];
+            if (xg) xg[(16 * i + 4 * r) * MP + 16 * wave_tile<MPV, W>(jj)] = acc[i][jj][r];
           }
     }
-    gram_update<W>(Vt, vr, l15, lq, accG);  // G~ part = V^T diag(v) V
+    if constexpr (GRAM) gram_update<W>(Vt, vr, l15, lq, accG);  // G~ part = V^T diag(v) V
     __syncthreads();
     // E = X .* K of the block (K recomputed from the staged points), in place; sum E, sum E |x - z|^2
     {
@@ -565,41 +627,43 @@ __device__ __forceinline__ void mid_pass2_body(const MidPass2Args& a, double* ld
       }
     }
     __syncthreads();
-    // moments of E against [1 | p | x_big]: accM[mt][jj] += Mx^T E, tile rows 16 mt .., column tiles W and W + 4
+    // moments of E against [1 | p | x_big]: accM[mt][jj] += Mx^T E, tile rows 16 mt .., column tiles W + 4 jj
     const double* const mfq = Mx + lq * LDM + l15;
 #pragma unroll
-    for (int h = 0; h < 4; ++h) {
-      double af[4][NMT], bf[4][2];
+    for (int h = 0; h < MRB / 16; ++h) {
+      double af[4][NMT], bf[4][NJ];
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
         const int k4 = 4 * (4 * h + s);
 #pragma unroll
         for (int mt = 0; mt < NMT; ++mt) af[s][mt] = mfq[k4 * LDM + 16 * mt];
-        bf[s][0] = qq[k4 * MLD + 16 * W];
-        bf[s][1] = qq[k4 * MLD + 16 * (W + 4)];
+#pragma unroll
+        for (int jj = 0; jj < NJ; ++jj) bf[s][jj] = qq[k4 * MLD + 16 * (W + 4 * jj)];
       }
 #pragma unroll
       for (int s = 0; s < 4; ++s)
 #pragma unroll
-        for (int mt = 0; mt < NMT; ++mt) {
-          accM[mt][0] = mfma_f64(af[s][mt], bf[s][0], accM[mt][0]);
-          accM[mt][1] = mfma_f64(af[s][mt], bf[s][1], accM[mt][1]);
-        }
+        for (int mt = 0; mt < NMT; ++mt)
+#pragma unroll
+          for (int jj = 0; jj < NJ; ++jj) accM[mt][jj] = mfma_f64(af[s][mt], bf[s][jj], accM[mt][jj]);
       __builtin_amdgcn_sched_barrier(0);
     }
   }
-  const int plen = m2len(d, D);
+  const int plen = GRAM ? m2len(d, D) : w2len(d, D);
   double* part = a.part + (int64_t)blockIdx.x * plen;
-  store_gram<W>(part, accG, l15, lq);
-  double* pcol = part + MGLEN;
+  double* pcol = part;
+  if constexpr (GRAM) {
+    store_gram<W>(part, accG, l15, lq);
+    pcol = part + MGLEN;
+  }
 #pragma unroll
   for (int mt = 0; mt < NMT; ++mt)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int q = 16 * mt + lq + 4 * r;
       if (q < nmom) {
-        pcol[q * MP + 16 * W + l15] = accM[mt][0][r];
-        pcol[q * MP + 16 * (W + 4) + l15] = accM[mt][1][r];
+#pragma unroll
+        for (int jj = 0; jj < NJ; ++jj) pcol[q * MP + 16 * (W + 4 * jj) + l15] = accM[mt][jj][r];
       }
     }
   double* ptail = pcol + nmom * MP;
@@ -629,89 +693,112 @@ __device__ __forceinline__ void mid_pass2_body(const MidPass2Args& a, double* ld
   }
 }
 
-template <int DT, int NMT>
+template <int MPV, int DT, int NMT>
 __global__ __launch_bounds__(256) void mid_pass2_kernel(MidPass2Args a) {
   extern __shared__ __attribute__((aligned(16))) double mid_lds[];
   switch (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)) {
-    case 0: mid_pass2_body<DT, NMT, 0>(a, mid_lds); break;
-    case 1: mid_pass2_body<DT, NMT, 1>(a, mid_lds); break;
-    case 2: mid_pass2_body<DT, NMT, 2>(a, mid_lds); break;
-    default: mid_pass2_body<DT, NMT, 3>(a, mid_lds); break;
+    case 0: mid_pass2_body<MPV, DT, NMT, 0>(a, mid_lds); break;
+    case 1: mid_pass2_body<MPV, DT, NMT, 1>(a, mid_lds); break;
+    case 2: mid_pass2_body<MPV, DT, NMT, 2>(a, mid_lds); break;
+    default: mid_pass2_body<MPV, DT, NMT, 3>(a, mid_lds); break;
   }
 }
 
-// exchange-2 buffer from the pass-2 partials, every entry written: the 128 x 128 tile, the column block (col_rows x 128;
-// rows 0 .. d + D carry sums, the rest -- the multiscale rows of a Cov_se_fat layout -- zero), the `Proj second term
-// (zero: proj_term2_kernel adds it afterwards) and the scalar tail
-__global__ __launch_bounds__(256) void mid_reduce2_kernel(const double* __restrict__ part, int ng, int d, int D, int col_rows,
-                                                          int nproj, double* __restrict__ tile, double* __restrict__ colblk,
+// exchange-2 buffer from the pass-2 partials.  One tile (tile != null): every entry written -- the 128 x 128 tile, the column
+// block (col_rows x mp; rows 0 .. d + D carry sums, the rest -- the multiscale rows of a Cov_se_fat layout -- zero), the `Proj
+// second term (zero: proj_term2_kernel adds it afterwards) and the scalar tail.  Two tiles (tile == null: the partials
+// carry no Gram part, G~ comes from the engine's launch): everything but the tiles.
+__global__ __launch_bounds__(256) void mid_reduce2_kernel(const double* __restrict__ part, int ng, int mp, int d, int D,
+                                                          int col_rows, int nproj, const double* __restrict__ shift,
+                                                          double* __restrict__ tile, double* __restrict__ colblk,
                                                           double* __restrict__ proj, double* __restrict__ tail) {
-  const int plen = m2len(d, D), nmom = 1 + d + D;
+  const int nmom = 1 + d + D;
+  const int plen = tile ? m2len(d, D) : w2len(d, D), pbase = tile ? MGLEN : 0;
   int idx = blockIdx.x * 256 + threadIdx.x;
-  const int ntile = MP * MP, ncol = col_rows * MP;
+  const int ntile = tile ? MP * MP : 0, ncol = col_rows * mp;
   if (idx < ntile) {
     tile[idx] = mid_tile_entry(part, plen, ng, idx / MP, idx % MP);
   } else if ((idx -= ntile) < ncol) {
-    const int q = idx / MP, c = idx % MP;
-    colblk[idx] = q < nmom ? sum_parts(part + MGLEN + q * MP + c, plen, ng) : 0.0;
+    const int q = idx / mp, c = idx % mp;
+    double val = q < nmom ? sum_parts(part + pbase + q * mp + c, plen, ng) : 0.0;
+    // rows 1 .. d: the moments were taken against p - shift (mid_pass2_body); sum_r p_kr E_rc = that + shift_k sum_r E_rc
+    if (q >= 1 && q <= d) val += shift[q - 1] * sum_parts(part + pbase + c, plen, ng);
+    colblk[idx] = val;
   } else if ((idx -= ncol) < nproj) {
     proj[idx] = 0.0;
   } else if ((idx -= nproj) < 8) {
-    tail[idx] = sum_parts(part + MGLEN + nmom * MP + idx, plen, ng);
+    tail[idx] = sum_parts(part + pbase + nmom * mp + idx, plen, ng);
   }
 }
 
 // ---------------------------------------------------------------------------------------------------------------- finish
-// The m x m work of do_finish_enqueue for one 128-block (as small_finish_kernel for 64 x 64 corners):
+// The m x m work of do_finish_enqueue for one or two 128-blocks (as small_finish_kernel for 64 x 64 corners):
 //   B~^-1 = R~^-1 R~^-T (Utils.ichol, lib/utils.ml:110-113),  W~ = I - B~^-1 - t~ t~^T - G~,  W = U^-1 W~ U^-T
 //   (lib/fitc_gp.ml:1196-1203), the trace terms of W against K_m and its derivatives (km_traces_kernel: :956-973,
 //   lib/utils.ml:196-220), diag W, and the tails of both exchange buffers gathered behind the result block.
-// Two launches of eight workgroups, one per 16-row block -- a single workgroup doing all three 128^3 products takes 70 us
-// (18 us of MFMAs on one CU and a memory round trip per k-batch), the eight together a few:
+// Two launches of one workgroup per 16-row block -- a single workgroup doing all three 128^3 products takes 70 us (18 us of
+// MFMAs on one CU and a memory round trip per k-batch), the eight together a few:
 //   mid_finish1: rows I of B~^-1 -> rows I of W~ (LDS) -> rows I of Y = W~ U^-T (memory)
 //   mid_finish2: rows I of W = U^-1 Y, and -- W and K_m are symmetric -- the trace terms of COLUMNS I from those rows,
 //                so no sum across workgroups is left
-// Wavefront w owns the 16-column tiles w and 7 - w; every fragment that comes from memory is requested before the first
-// MFMA of its product (64 loads per wavefront; nothing here sits in a loop that could hoist them).
-__device__ __forceinline__ void mid_rows_times_tri_t(const double* Arow, const double* __restrict__ B, int kmin_row, int wv,
-                                                      int l15, int lq, sd4 (&acc)[2]) {
-  // acc[jj] = rows of Arow (LDS [16][MLD]) times B^T restricted to k >= 16 max(kmin_row, j): out[i][c] = sum_k A[i][k] B[c][k]
-  const int jt[2] = {wv, 7 - wv};
-  const double* aq = Arow + l15 * MLD + lq;
-  acc[0] = acc[1] = sd4{0.0, 0.0, 0.0, 0.0};
+// Every fragment that comes from memory is requested a chunk of four k-batches at a time, before the chunk's first MFMA
+// (nothing here sits in a loop that could hoist them).  G~ is read through gprhip_exchange_offset's packed-tile layout.
+template <int MPV>
+__device__ __forceinline__ int64_t mid_packed_off(int r, int c) {  // r <= c
+  return MPV == 128 ? (int64_t)r * 128 + c : packed_upper_off(r, c);
+}
+
+// acc[jj] = rows of Arow (LDS [16][MLD]) times B^T restricted to k >= 16 max(kmin_row, j), given Bt = B^T in memory:
+// out[i][c] = sum_k A[i][k] Bt[k][c]
+template <int MPV>
+__device__ __forceinline__ void mid_rows_times_tri_t(const double* Arow, const double* __restrict__ Bt, int kmin_row, int wv,
+                                                      int l15, int lq, sd4 (&acc)[MidGeo<MPV>::NJ]) {
+  using G = MidGeo<MPV>;
+  constexpr int NJ = G::NJ;
+  int jt[NJ];
 #pragma unroll
-  for (int half = 0; half < 2; ++half) {
-    double bf[4][4][2];
+  for (int jj = 0; jj < NJ; ++jj) {
+    jt[jj] = wave_tile_rt(MPV, wv, jj);
+    acc[jj] = sd4{0.0, 0.0, 0.0, 0.0};
+  }
+  const double* aq = Arow + l15 * G::MLD + lq;
+#pragma unroll 1
+  for (int ch = kmin_row / 4; ch < G::MCT / 4; ++ch) {
+    double bf[4][4][NJ];
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
-      for (int jj = 0; jj < 2; ++jj) {
-        const int kb = 4 * half + kk;
-        const bool on = kb >= max(kmin_row, jt[jj]);
-        const double* bq = B + (int64_t)(16 * jt[jj] + l15) * MP + 16 * kb + lq;
+      for (int jj = 0; jj < NJ; ++jj) {
+        // (unconditional: a load under a uniform branch ends in a wait at the branch's end -- sixteen round trips per chunk
+        //  instead of one, 70 of this kernel's 80 us at m = 256; what a tile does not need yet is fetched and left unused)
+        const int kb = 4 * ch + kk;
+        const double* bq = Bt + (int64_t)(16 * kb + lq) * G::MP + 16 * jt[jj] + l15;
 #pragma unroll
-        for (int s = 0; s < 4; ++s) bf[kk][s][jj] = on ? bq[4 * s] : 0.0;
+        for (int s = 0; s < 4; ++s) bf[kk][s][jj] = bq[4 * s * G::MP];
       }
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
-      const int kb = 4 * half + kk;
-      if (kb < min(max(kmin_row, jt[0]), max(kmin_row, jt[1]))) continue;  // (uniform)
+      const int kb = 4 * ch + kk;
+      if (kb < kmin_row) continue;  // (uniform)
 #pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        const double af = aq[16 * kb + 4 * s];
-        acc[0] = mfma_f64(af, bf[kk][s][0], acc[0]);
-        acc[1] = mfma_f64(af, bf[kk][s][1], acc[1]);
-      }
+      for (int jj = 0; jj < NJ; ++jj)
+        if (kb >= jt[jj]) {  // (uniform)
+#pragma unroll
+          for (int s = 0; s < 4; ++s) acc[jj] = mfma_f64(aq[16 * kb + 4 * s], bf[kk][s][jj], acc[jj]);
+        }
     }
   }
 }
 
+template <int MPV>
 __global__ __launch_bounds__(256) void mid_finish1_kernel(MidFinishArgs a) {
+  using G = MidGeo<MPV>;
+  constexpr int MP = G::MP, MLD = G::MLD, NJ = G::NJ;
   __shared__ __attribute__((aligned(16))) double Rrow[16 * MLD];  // rows I of R~^-1, then of W~
   __shared__ double tt[MP];
   const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6), l15 = lane & 15, lq = lane >> 4;
   const int I = blockIdx.x;
-  if (tid < MP) tt[tid] = a.ttil[tid];
+  for (int idx = tid; idx < MP; idx += 256) tt[idx] = a.ttil[idx];
   for (int idx = tid; idx < 16 * (MP / 2); idx += 256) {
     const int r = idx / (MP / 2), c2 = (idx % (MP / 2)) * 2;
     *reinterpret_cast<double2*>(Rrow + r * MLD + c2) = *reinterpret_cast<const double2*>(a.rinv + (int64_t)(16 * I + r) * MP + c2);
@@ -719,30 +806,33 @@ __global__ __launch_bounds__(256) void mid_finish1_kernel(MidFinishArgs a) {
   if (I == 0)
     for (int64_t i = tid; i < a.n_gather; i += 256) a.ex[i] = a.gather_from[i];
   __syncthreads();
-  sd4 acc[2];
-  mid_rows_times_tri_t(Rrow, a.rinv, I, wv, l15, lq, acc);  // B~^-1[i][j] = sum_{k >= max(i, j)} Ri[i][k] Ri[j][k]
+  sd4 acc[NJ];
+  mid_rows_times_tri_t<MPV>(Rrow, a.rinvT, I, wv, l15, lq, acc);  // B~^-1[i][j] = sum_{k >= max(i, j)} Ri[i][k] Ri[j][k]
   __syncthreads();  // every wavefront is done reading the rows of R~^-1
 #pragma unroll
-  for (int jj = 0; jj < 2; ++jj)
+  for (int jj = 0; jj < NJ; ++jj)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int li = lq + 4 * r, row = 16 * I + li, c = 16 * (jj == 0 ? wv : 7 - wv) + l15;
+      const int li = lq + 4 * r, row = 16 * I + li, c = 16 * wave_tile_rt(MPV, wv, jj) + l15;
       const int rr = min(row, c), cc = max(row, c);  // G~ is valid in the upper triangle: mirrored, as build_w_kernel
-      Rrow[li * MLD + c] = (row == c ? 1.0 : 0.0) - acc[jj][r] - tt[row] * tt[c] - a.g[rr * MP + cc];
+      Rrow[li * MLD + c] = (row == c ? 1.0 : 0.0) - acc[jj][r] - tt[row] * tt[c] - a.g[mid_packed_off<MPV>(rr, cc)];
     }
   __syncthreads();
-  mid_rows_times_tri_t(Rrow, a.uinv, 0, wv, l15, lq, acc);  // Y[i][j] = sum_{k >= j} W~[i][k] Ui[j][k]
+  mid_rows_times_tri_t<MPV>(Rrow, a.uinvT, 0, wv, l15, lq, acc);  // Y[i][j] = sum_{k >= j} W~[i][k] Ui[j][k]
 #pragma unroll
-  for (int jj = 0; jj < 2; ++jj)
+  for (int jj = 0; jj < NJ; ++jj)
 #pragma unroll
     for (int r = 0; r < 4; ++r)
-      a.ybuf[(int64_t)(16 * I + lq + 4 * r) * MP + 16 * (jj == 0 ? wv : 7 - wv) + l15] = acc[jj][r];
+      a.ybuf[(int64_t)(16 * I + lq + 4 * r) * MP + 16 * wave_tile_rt(MPV, wv, jj) + l15] = acc[jj][r];
 }
 
-template <int DT>
+template <int MPV, int DT>
 __global__ __launch_bounds__(256) void mid_finish2_kernel(MidFinishArgs a) {
-  __shared__ __attribute__((aligned(16))) double Urow[16 * MLD];  // rows I of U^-1, then of W
-  __shared__ double zs[MP * DT];
+  using G = MidGeo<MPV>;
+  constexpr int MP = G::MP, MLD = G::MLD, NJ = G::NJ, NC = MP / 16;  // NC: columns per thread of the trace phase
+  extern __shared__ __attribute__((aligned(16))) double mid_lds[];
+  double* const Urow = mid_lds;          // [16][MLD] rows I of U^-1, then of W
+  double* const zs = Urow + 16 * MLD;    // [MP][DT]
   const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6), l15 = lane & 15, lq = lane >> 4;
   const int I = blockIdx.x, d = a.d, m = a.m;
   for (int idx = tid; idx < 16 * (MP / 2); idx += 256) {
@@ -753,46 +843,46 @@ __global__ __launch_bounds__(256) void mid_finish2_kernel(MidFinishArgs a) {
     const int c = idx / DT, k = idx % DT;
     zs[idx] = (k < d && c < m) ? a.Z[(int64_t)c * d + k] : 0.0;
   }
-  // K_m entries of the trace phase (thread = (row i of the block, eight columns)): requested now, used at the end
+  // K_m entries of the trace phase (thread = (row i of the block, NC columns)): requested now, used at the end
   const int ti = tid >> 4, tp = tid & 15, crow = 16 * I + ti;
-  double kreg[8];
+  double kreg[NC];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) kreg[j] = (crow < m && 8 * tp + j < m) ? a.km[(int64_t)crow * MP + 8 * tp + j] : 0.0;
+  for (int j = 0; j < NC; ++j) kreg[j] = (crow < m && NC * tp + j < m) ? a.km[(int64_t)crow * MP + NC * tp + j] : 0.0;
   __syncthreads();
-  // W[i][j] = sum_{k >= i} Ui[i][k] Y[k][j]: the batches kb >= I; column tiles wv and wv + 4
-  sd4 acc[2];
-  acc[0] = acc[1] = sd4{0.0, 0.0, 0.0, 0.0};
+  // W[i][j] = sum_{k >= i} Ui[i][k] Y[k][j]: the batches kb >= I; column tiles wv + 4 jj
+  sd4 acc[NJ];
+#pragma unroll
+  for (int jj = 0; jj < NJ; ++jj) acc[jj] = sd4{0.0, 0.0, 0.0, 0.0};
   {
     const double* aq = Urow + l15 * MLD + lq;
-    const double* yq = a.ybuf + (int64_t)lq * MP + l15;
-#pragma unroll
-    for (int half = 0; half < 2; ++half) {
-      double bf[4][4][2];
+    const double* yq = a.ybuf + (int64_t)lq * MP + l15 + 16 * wv;
+#pragma unroll 1
+    for (int ch = I / 4; ch < G::MCT / 4; ++ch) {
+      double bf[4][4][NJ];
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) {
-        const int kb = 4 * half + kk;
+        const int kb = 4 * ch + kk;
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-          bf[kk][s][0] = kb >= I ? yq[(16 * kb + 4 * s) * MP + 16 * wv] : 0.0;
-          bf[kk][s][1] = kb >= I ? yq[(16 * kb + 4 * s) * MP + 16 * (wv + 4)] : 0.0;
-        }
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+          for (int jj = 0; jj < NJ; ++jj) bf[kk][s][jj] = yq[(int64_t)(16 * kb + 4 * s) * MP + 64 * jj];  // (unconditional, as above)
       }
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) {
-        const int kb = 4 * half + kk;
+        const int kb = 4 * ch + kk;
         if (kb < I) continue;  // (uniform)
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
           const double af = aq[16 * kb + 4 * s];
-          acc[0] = mfma_f64(af, bf[kk][s][0], acc[0]);
-          acc[1] = mfma_f64(af, bf[kk][s][1], acc[1]);
+#pragma unroll
+          for (int jj = 0; jj < NJ; ++jj) acc[jj] = mfma_f64(af, bf[kk][s][jj], acc[jj]);
         }
       }
     }
   }
   __syncthreads();  // every wavefront is done reading the rows of U^-1
 #pragma unroll
-  for (int jj = 0; jj < 2; ++jj)
+  for (int jj = 0; jj < NJ; ++jj)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int li = lq + 4 * r, c = 16 * (wv + 4 * jj) + l15;
@@ -805,8 +895,8 @@ __global__ __launch_bounds__(256) void mid_finish2_kernel(MidFinishArgs a) {
 #pragma unroll
   for (int k = 0; k < DT; ++k) g[k] = 0.0;
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const int r = 8 * tp + j;
+  for (int j = 0; j < NC; ++j) {
+    const int r = NC * tp + j;
     const double wk = Urow[ti * MLD + r] * kreg[j];  // (0 beyond the real rows and columns)
     s0 += wk;
     double dist = 0.0;
@@ -833,11 +923,35 @@ __global__ __launch_bounds__(256) void mid_finish2_kernel(MidFinishArgs a) {
   }
 }
 
-// ---------------------------------------------------------------------------------------------------------------- host
-static size_t mid_lds1(int DT) { return (size_t)(MRB * MLD + MRB * DT + 2 * MRB + 4 * MRB) * sizeof(double); }
-static size_t mid_lds2(int NMT) {
-  return (size_t)(2 * MRB * MLD + MRB * (16 * NMT + 2) + 3 * MRB + 8 * MRB + 2 * MP + 16) * sizeof(double);
+// U^-T and R~^-T beside U^-1 and R~^-1 (one launch, before pass 2 of a gradient evaluation): see tri_nt
+__global__ __launch_bounds__(256) void mid_transpose2_kernel(const double* __restrict__ u, const double* __restrict__ r, int mp,
+                                                             double* __restrict__ ut, double* __restrict__ rt) {
+  __shared__ double t[32][33];
+  const double* src = blockIdx.z == 0 ? u : r;
+  double* dst = blockIdx.z == 0 ? ut : rt;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5, r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) t[ty + 8 * i][tx] = src[(int64_t)(r0 + ty + 8 * i) * mp + c0 + tx];
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) dst[(int64_t)(c0 + ty + 8 * i) * mp + r0 + tx] = t[tx][ty + 8 * i];
 }
+
+void launch_mid_transposes(const double* uinv, const double* rinv, int mp, double* uinvT, double* rinvT, hipStream_t s) {
+  hipLaunchKernelGGL(mid_transpose2_kernel, dim3(mp / 32, mp / 32, 2), dim3(256), 0, s, uinv, rinv, mp, uinvT, rinvT);
+  GPR_HIP(hipGetLastError());
+}
+
+// ---------------------------------------------------------------------------------------------------------------- host
+static size_t mid_lds1(int mp, int DT) {
+  const int rb = mp == 128 ? 64 : 32;
+  return (size_t)(rb * (mp + 2) + rb * DT + 2 * rb + 4 * rb) * sizeof(double);
+}
+static size_t mid_lds2(int mp, int NMT) {
+  const int rb = mp == 128 ? 64 : 32;
+  return (size_t)(2 * rb * (mp + 2) + rb * (16 * NMT + 2) + 3 * rb + 8 * rb + 2 * mp + 16) * sizeof(double);
+}
+static size_t mid_lds3(int mp, int DT) { return (size_t)(16 * (mp + 2) + mp * DT) * sizeof(double); }
 
 template <typename F>
 static void mid_dispatch(int d, F&& go) {
@@ -852,57 +966,81 @@ static void mid_attrs() {
     auto set = [](const void* f, size_t bytes) {
       GPR_HIP(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
     };
-#define GPRHIP_MID_SET(DT)                                                               \
-  set(reinterpret_cast<const void*>(&mid_pass1_kernel<DT>), mid_lds1(DT));               \
-  set(reinterpret_cast<const void*>(&mid_pass2_kernel<DT, 1>), mid_lds2(1));             \
-  set(reinterpret_cast<const void*>(&mid_pass2_kernel<DT, 2>), mid_lds2(2));             \
-  (void)0;
-    GPRHIP_MID_SET(4)
-    GPRHIP_MID_SET(8)
-    GPRHIP_MID_SET(16)
+#define GPRHIP_MID_SET(MPV, DT)                                                                    \
+  set(reinterpret_cast<const void*>(&mid_pass1_kernel<MPV, DT>), mid_lds1(MPV, DT));               \
+  set(reinterpret_cast<const void*>(&mid_pass2_kernel<MPV, DT, 1>), mid_lds2(MPV, 1));             \
+  set(reinterpret_cast<const void*>(&mid_pass2_kernel<MPV, DT, 2>), mid_lds2(MPV, 2));             \
+  set(reinterpret_cast<const void*>(&mid_finish2_kernel<MPV, DT>), mid_lds3(MPV, DT));
+    GPRHIP_MID_SET(128, 4)
+    GPRHIP_MID_SET(128, 8)
+    GPRHIP_MID_SET(128, 16)
+    GPRHIP_MID_SET(256, 4)
+    GPRHIP_MID_SET(256, 8)
+    GPRHIP_MID_SET(256, 16)
 #undef GPRHIP_MID_SET
   });
 }
 
 bool mid_path_fits(int m, int mp, int d, int D, int64_t rows, bool ms) {
   // (D: input dimensions in front of a projection, 0 without one; the moment matrix [1 | p | x_big] has at most two 16-row
-  //  tiles -- the two 64 x 128 tiles of pass 2 leave 30 KB of the LDS for it and the row vectors)
-  return m <= MP && mp == MP && d <= 16 && 1 + d + D <= 32 && !ms && rows <= (int64_t(1) << 22);
+  //  tiles -- the two row-block tiles of pass 2 leave 30 KB of the LDS for it and the row vectors)
+  return (mp == 128 || mp == 256) && m <= mp && d <= 16 && 1 + d + D <= 32 && !ms && rows <= (int64_t(1) << 22);
 }
 
+template <typename F>
+static void mid_by_tiles(int mp, F&& go) {
+  if (mp == 128) go(std::integral_constant<int, 128>{});
+  else go(std::integral_constant<int, 256>{});
+}
+
+// One tile: pass 1 and its reduction fill the whole exchange-1 buffer (tile, c~, tail).  Two tiles: the kernel leaves V, r,
+// 1/s, y/s and the scalar tail (summed into `tail`); B~ and c~ come from the engine's SYRK-shaped launch over V (caller).
 void launch_mid_pass1(const MidPass1Args& a, double* tile, double* cvec, double* tail, hipStream_t s) {
   mid_attrs();
-  const int ng = mid_groups(a.rows_p);
-  mid_dispatch(a.d, [&](auto dt) {
-    constexpr int DT = decltype(dt)::value;
-    hipLaunchKernelGGL((mid_pass1_kernel<DT>), dim3(ng), dim3(256), mid_lds1(DT), s, a);
+  mid_by_tiles(a.mp, [&](auto mpv) {
+    constexpr int MPV = decltype(mpv)::value;
+    const int ng = mid_groups<MPV>(a.rows_p);
+    mid_dispatch(a.d, [&](auto dt) {
+      constexpr int DT = decltype(dt)::value;
+      hipLaunchKernelGGL((mid_pass1_kernel<MPV, DT>), dim3(ng), dim3(256), mid_lds1(MPV, DT), s, a);
+    });
+    if (MPV == 128) hipLaunchKernelGGL(mid_reduce1_kernel, dim3(MP * MP / 256 + 1), dim3(256), 0, s, a.part, ng, tile, cvec, tail);
+    else launch_reduce_rows(a.part, ng, W1LEN, tail, 0, s);
   });
-  hipLaunchKernelGGL(mid_reduce1_kernel, dim3(MP * MP / 256 + 1), dim3(256), 0, s, a.part, ng, tile, cvec, tail);
   GPR_HIP(hipGetLastError());
 }
 
+// One tile: every entry of the exchange-2 buffer is written.  Two tiles (tile == null): everything but the packed tiles,
+// which the engine's SYRK-shaped launch over V fills (caller).
 void launch_mid_pass2(const MidPass2Args& a, int col_rows, double* tile, double* colblk, double* proj, double* tail,
                       hipStream_t s) {
   mid_attrs();
-  const int ng = mid_groups(a.rows_p);
   const int nmt = (1 + a.d + a.D + 15) / 16;
-  mid_dispatch(a.d, [&](auto dt) {
-    constexpr int DT = decltype(dt)::value;
-    if (nmt == 1) hipLaunchKernelGGL((mid_pass2_kernel<DT, 1>), dim3(ng), dim3(256), mid_lds2(1), s, a);
-    else hipLaunchKernelGGL((mid_pass2_kernel<DT, 2>), dim3(ng), dim3(256), mid_lds2(2), s, a);
-  });
   const int nproj = a.D * a.d;
-  const int nout = MP * MP + col_rows * MP + nproj + 8;
-  hipLaunchKernelGGL(mid_reduce2_kernel, dim3((nout + 255) / 256), dim3(256), 0, s, a.part, ng, a.d, a.D, col_rows, nproj, tile,
-                     colblk, proj, tail);
+  mid_by_tiles(a.mp, [&](auto mpv) {
+    constexpr int MPV = decltype(mpv)::value;
+    const int ng = mid_groups<MPV>(a.rows_p);
+    mid_dispatch(a.d, [&](auto dt) {
+      constexpr int DT = decltype(dt)::value;
+      if (nmt == 1) hipLaunchKernelGGL((mid_pass2_kernel<MPV, DT, 1>), dim3(ng), dim3(256), mid_lds2(MPV, 1), s, a);
+      else hipLaunchKernelGGL((mid_pass2_kernel<MPV, DT, 2>), dim3(ng), dim3(256), mid_lds2(MPV, 2), s, a);
+    });
+    const int nout = (MPV == 128 ? MP * MP : 0) + col_rows * MPV + nproj + 8;
+    hipLaunchKernelGGL(mid_reduce2_kernel, dim3((nout + 255) / 256), dim3(256), 0, s, a.part, ng, MPV, a.d, a.D, col_rows, nproj,
+                       a.shift, MPV == 128 ? tile : nullptr, colblk, proj, tail);
+  });
   GPR_HIP(hipGetLastError());
 }
 
 void launch_mid_finish(const MidFinishArgs& a, hipStream_t s) {
-  hipLaunchKernelGGL(mid_finish1_kernel, dim3(MCT), dim3(256), 0, s, a);
-  mid_dispatch(a.d, [&](auto dt) {
-    constexpr int DT = decltype(dt)::value;
-    hipLaunchKernelGGL((mid_finish2_kernel<DT>), dim3(MCT), dim3(256), 0, s, a);
+  mid_attrs();
+  mid_by_tiles(a.mp, [&](auto mpv) {
+    constexpr int MPV = decltype(mpv)::value;
+    hipLaunchKernelGGL((mid_finish1_kernel<MPV>), dim3(MPV / 16), dim3(256), 0, s, a);
+    mid_dispatch(a.d, [&](auto dt) {
+      constexpr int DT = decltype(dt)::value;
+      hipLaunchKernelGGL((mid_finish2_kernel<MPV, DT>), dim3(MPV / 16), dim3(256), mid_lds3(MPV, DT), s, a);
+    });
   });
   GPR_HIP(hipGetLastError());
 }

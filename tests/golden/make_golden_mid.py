@@ -1,4 +1,4 @@
-"""Fixtures for the 65 .. 128 inducing-point regime (gpr_amd/csrc/mid.hip), generated like tests/golden/make_golden.py from
+"""Fixtures for the 65 .. 256 inducing-point regime (gpr_amd/csrc/mid.hip), generated like tests/golden/make_golden.py from
 the CPU oracle's reference-sequence evaluation -- kept in a script of their own so that the older fixtures stay byte for
 byte what they were.  The reference's default takes m = min (n / 10) 1000 inducing points (lib/fitc_gp.ml:1474-1479):
 n = 1280 gives the m = 128 of `iso_mid`.
@@ -32,6 +32,18 @@ def main():
     kf = O.SeFatKernel(d, 0.1, P, lh)
     Zf = np.asfortranarray(O.se_fat_project(kf, Xb[:, rng.permutation(n)[:m]]) + 0.01 * rng.normal(size=(d, m)))
     save("fat_mid", kf, Xb, yb, Zf, 0.15, True, dict(kind="fat", d=d, log_sf2=0.1, tproj=P, log_hetero=lh))
+    # two 128-column tiles (129 .. 256 inducing points): n = 2000 gives the reference's default m = 200
+    X, y, Z = synth(64, 2000, 200, 6)
+    le = 0.5 * np.log(6) - 0.05
+    save("iso_mid2", O.SeIsoKernel(le, 0.1), X, y, Z, 0.1, False, dict(kind="iso", log_ell=le, log_sf2=0.1))
+    rng = np.random.default_rng(65)
+    n, m, D, d = 1100, 161, 9, 5
+    Xb = np.asfortranarray(rng.normal(size=(D, n)))
+    yb = np.sin(Xb.sum(0)) + 0.1 * rng.normal(size=n)
+    P = np.asfortranarray(rng.normal(size=(D, d)) / np.sqrt(D))
+    kf = O.SeFatKernel(d, -0.1, P)
+    Zf = np.asfortranarray(O.se_fat_project(kf, Xb[:, rng.permutation(n)[:m]]) + 0.01 * rng.normal(size=(d, m)))
+    save("fat_mid2", kf, Xb, yb, Zf, 0.12, False, dict(kind="fat", d=d, log_sf2=-0.1, tproj=P))
 
 
 if __name__ == "__main__":

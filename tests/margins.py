@@ -71,6 +71,10 @@ def relinf(a, b):
 
 EPS64 = 2.0 ** -53
 EPS32 = 2.0 ** -24
+# conditioning allowance = ALLOW_FACTOR x cond(K_m + jitter) x unit roundoff, relative to the gradient's largest entry.  Over
+# 4700 fp64 family checks with a condition estimate (profiles/r06_parity_margins.txt) the absolute error of a family reached
+# 5.3 x cond x 2^-53 of the largest entry (seed 9698: 108 inducing points on a line, cond 6e7); 8 covers it with margin 1.5.
+ALLOW_FACTOR = 8.0
 
 
 def family_errors(got, ref, fams, detail=None, allow=0.0):
@@ -105,9 +109,10 @@ def family_errors(got, ref, fams, detail=None, allow=0.0):
 
 def check_grad(got, ref, fams, tol, what="grad", cond=None, unit=EPS64):
     """Every family within tol of its own largest entry; cond (the device's 2-norm estimate of cond(K_m + jitter), where the
-    caller has it) adds the conditioning allowance cond x unit relative to the vector's largest entry (see family_errors)."""
+    caller has it) adds the conditioning allowance ALLOW_FACTOR x cond x unit relative to the vector's largest entry (see
+    family_errors)."""
     detail = {}
-    errs = family_errors(got, ref, fams, detail, allow=(cond * unit if cond else 0.0))
+    errs = family_errors(got, ref, fams, detail, allow=(ALLOW_FACTOR * cond * unit if cond else 0.0))
     for name, e in errs.items():
         _record("%s.%s" % (what, name), e, tol, **detail[name])
     bad = {k: v for k, v in errs.items() if not v <= tol}

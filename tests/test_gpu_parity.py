@@ -18,13 +18,22 @@ from tests.util import (STAT_KEYS, golden_names, illcond_golden_names, load_gold
 
 pytestmark = pytest.mark.gpu
 
-TOL_L = 1e-9        # |l - l_ref| <= TOL_L * |l_ref|   (also l1)
-TOL_DS2 = 1e-8      # dl/dsigma2, relative
-TOL_GRAD = 1e-7     # gradient, max-abs error relative to max-abs entry
-TOL_COEFF = 1e-7    # mean coefficients t, same norm
-TOL_ROW = 1e-10     # per-row intermediates r, 1/s
-TOL_COEFF_LINE = 3e-7   # ... for training points on a line (d = 1): K_m is jitter-dominated, see test_mean_coefficients_against_an_80_bit_evaluation
-TOL_SHARD = 1e-9    # two different row partitions of the same problem (different summation order)
+# Stated fp64 bounds, each <= 10 x the worst error observed over the suite and the long random-shape sweeps of round 6 (5000
+# gradient checks, 1500 evidence checks; table with every test's achieved errors: profiles/r06_parity_margins.txt):
+TOL_L = 7e-10       # |l - l_ref| <= TOL_L * |l_ref|   (also l1)                                        worst seen 7.6e-11
+TOL_DS2 = 4e-10     # dl/dsigma2, relative                                                             worst seen 4.0e-11
+TOL_GRAD = 1e-8     # gradient, PER FAMILY of the reference's Hyper.get_all order (log_ell | log_sf2 | inducing | Proj |
+                    # hetero | multiscale), each against its own largest entry (tests/margins.py); where the case's
+                    # cond(K_m + jitter) is known, plus the conditioning allowance 8 cond 2^-53 of the largest entry
+                    #                                                                                  worst seen 9.6e-10
+TOL_COEFF = 1e-7    # mean coefficients t, max-abs error relative to max-abs entry                     worst seen 3.0e-8
+TOL_COEFF_LINE = 3e-7   # ... for training points on a line (d = 1): K_m is jitter-dominated, see
+                        # test_mean_coefficients_against_an_80_bit_evaluation                          worst seen 5.1e-8
+TOL_ROW = 1e-10     # per-row intermediates r, 1/s                                                     worst seen 1.2e-11
+TOL_ROWVW = 2e-10   # per-row v, w                                                                     worst seen 1.9e-11
+TOL_SHARD = 2e-14   # l, dl/dsigma2 of two row partitions of one problem (summation order only)        worst seen 1.4e-15
+TOL_SHARD_GRAD = 1e-9  # ... their gradient families and coefficients                                  worst seen 9.4e-11
+TOL_BENCH = 1e-9    # bench.py's last evaluation across launch modes (l, dl/dsigma2, |grad|; relative to max(1, |.|))
 
 
 def _problem_for(g, chunk_rows=0):
@@ -62,15 +71,15 @@ def _small_path_applies(g):
 
 
 def _mid_path_applies(g):
-    """gpr_amd/csrc/mid.hip: one-kernel row passes for one 128-column tile of inducing points (m <= 128) that the small path
-    does not take: d <= 16, 1 + d + D <= 32 with a projection, no multiscales."""
+    """gpr_amd/csrc/mid.hip: one-kernel row passes for one or two 128-column tiles of inducing points (m <= 256) that the
+    small path does not take: d <= 16, 1 + d + D <= 32 with a projection, no multiscales."""
     d, m = g["Z"].shape
     D = g["X"].shape[0] if "tproj" in g else 0
-    return m <= 128 and d <= 16 and 1 + d + D <= 32 and "log_multiscales" not in g
+    return m <= 256 and d <= 16 and 1 + d + D <= 32 and "log_multiscales" not in g
 
 
 def _golden_cases(names):
-    """(fixture, row-pass path).  "default" is what the library picks: small.hip for m <= 64, mid.hip for 65 .. 128, else the
+    """(fixture, row-pass path).  "default" is what the library picks: small.hip for m <= 64, mid.hip for 65 .. 256, else the
     engine; fixtures the small path takes also run through mid.hip ("mid": GPRHIP_SMALL_PATH=0) where that applies, and
     every fixture a one-kernel path takes also runs through the engine ("engine": both switched off)."""
     out = []
@@ -122,8 +131,8 @@ def test_golden_iso(name, path, monkeypatch):
     assert M.vec_ok("coeffs", ev.coeffs, g["coeffs"], TOL_COEFF)
     assert M.vec_ok("row_r", p.debug_fetch("r"), g["r_vec"], TOL_ROW)
     assert M.vec_ok("row_is", p.debug_fetch("is"), g["is_vec"], TOL_ROW)
-    assert M.vec_ok("row_v", p.debug_fetch("v"), g["v_vec"], TOL_GRAD)
-    assert M.vec_ok("row_w", p.debug_fetch("w"), g["w_vec"], TOL_GRAD)
+    assert M.vec_ok("row_v", p.debug_fetch("v"), g["v_vec"], TOL_ROWVW)
+    assert M.vec_ok("row_w", p.debug_fetch("w"), g["w_vec"], TOL_ROWVW)
     # evidence-only entry point (multim_f) agrees with the gradient one
     ev0 = _eval_golden(p, g, want_grad=False)
     assert M.rel_ok("l", ev0.l, ev.l, 1e-12)
@@ -182,7 +191,7 @@ def test_chunking_does_not_change_results():
     p1, p2 = _problem_for(g), _problem_for(g, chunk_rows=256)
     a, b = _eval_golden(p1, g), _eval_golden(p2, g)
     assert abs(a.l - b.l) <= TOL_SHARD * abs(a.l)
-    assert M.grad_ok(a.grad, b.grad, M.families_golden(g), 100 * TOL_SHARD)
+    assert M.grad_ok(a.grad, b.grad, M.families_golden(g), TOL_SHARD_GRAD)
     p1.close()
     p2.close()
 
@@ -223,7 +232,7 @@ def test_odd_block_counts_of_the_triangular_inverse(m):
 # fp64 oracle" within these stated tolerances (n x m data and contractions in fp32; everything
 # m x m, the covariance evaluation and every accumulation across training points in fp64)
 TOL32_L = 1e-4
-TOL32_DS2 = 1e-3
+TOL32_DS2 = 8e-4
 TOL32_GRAD = 5e-3
 TOL32_COEFF = 5e-3
 
@@ -505,7 +514,7 @@ def test_two_shards_on_one_device_equal_the_whole():
     for ev in evs:
         assert M.rel_ok("l", ev.l, ref.l, TOL_SHARD)
         assert M.rel_ok("dl_dsigma2", ev.dl_dsigma2, ref.dl_dsigma2, TOL_SHARD)
-        assert M.grad_ok(ev.grad, ref.grad, M.families("iso", d, m), 100 * TOL_SHARD)
+        assert M.grad_ok(ev.grad, ref.grad, M.families("iso", d, m), TOL_SHARD_GRAD)
     for p in shards + [whole]:
         p.close()
 
@@ -541,7 +550,7 @@ def test_error_behaviour():
     with pytest.raises(gpr_amd.GprHipError, match="holds no V"):
         sp.eval(log_ell=0.0, log_sf2=0.0, sigma2=0.1, inducing=Zdup, reuse_v=True)
     after = sp.eval(log_ell=0.0, log_sf2=0.0, sigma2=0.1, inducing=Z)
-    assert M.rel_ok("l", after.l, good.l, TOL_SHARD) and M.grad_ok(after.grad, good.grad, M.families("iso", 2, 4), 100 * TOL_SHARD)
+    assert M.rel_ok("l", after.l, good.l, TOL_SHARD) and M.grad_ok(after.grad, good.grad, M.families("iso", 2, 4), TOL_SHARD_GRAD)
     sp.close()
     ctx.close()
     Xb, yb, Zb = synth(3, 900, 300, 3)
@@ -648,7 +657,7 @@ def test_bench_two_ranks_on_one_device_match_single_rank():
     assert two["n_gpus"] == 2 and two["scaling"] == "strong"
     for k in ("l", "dl_dsigma2", "grad_norm"):
         a, b = one["last_eval"][k], two["last_eval"][k]
-        assert abs(a - b) <= TOL_SHARD * max(1.0, abs(a)), (k, a, b)
+        assert abs(a - b) <= TOL_BENCH * max(1.0, abs(a)), (k, a, b)
 
 
 def test_bench_single_process_eight_way_matches_one_gpu_and_torchrun():
@@ -671,7 +680,7 @@ def test_bench_single_process_eight_way_matches_one_gpu_and_torchrun():
     for other in (ctx8, two):
         for k in ("l", "dl_dsigma2", "grad_norm"):
             a, b = one["last_eval"][k], other["last_eval"][k]
-            assert abs(a - b) <= TOL_SHARD * max(1.0, abs(a)), (k, a, b)
+            assert abs(a - b) <= TOL_BENCH * max(1.0, abs(a)), (k, a, b)
     # more devices asked for than the box has, without --same-device: a message naming both counts, non-zero exit
     visible = gpr_amd.device_count()
     out = _run_bench(["--expect-failure"], visible + 1)
@@ -1808,10 +1817,10 @@ def test_small_path_with_several_blocks_per_workgroup(kind, n, m, d, D, monkeypa
 @pytest.mark.gpu
 @pytest.mark.parametrize("seed", range(5000, 5032))
 def test_random_mid_shapes_against_oracle(seed):
-    """The shapes of gpr_amd/csrc/mid.hip -- 65 .. 128 inducing points, the regime of the reference's default
-    m = min (n / 10) 1000 (lib/fitc_gp.ml:1474-1479) for data sets of 650 .. 1280 points -- and both of its thresholds
-    (m = 64 | 65: small.hip | mid.hip; m = 128 | 129: mid.hip | engine): every fourth seed sits exactly on one, the rest are
-    drawn from 60 .. 133; projections either side of the moment-matrix limit, multiscales and d > 16 falling back to the
+    """The shapes of gpr_amd/csrc/mid.hip -- 65 .. 256 inducing points, the regime of the reference's default
+    m = min (n / 10) 1000 (lib/fitc_gp.ml:1474-1479) for data sets of 650 .. 2560 points -- and its thresholds (m = 64 | 65:
+    small.hip | mid.hip; 128 | 129: one tile | two tiles; 256 | 257: mid.hip | engine): every fourth seed sits exactly on one,
+    the rest are drawn from 60 .. 261; projections either side of the moment-matrix limit, multiscales and d > 16 falling back to the
     engine; each followed by a reuse_v re-evaluation on the state the path left."""
     _random_shape_case(seed, mid=True)
 
@@ -1824,10 +1833,11 @@ def test_random_mid_shapes_through_the_context(seed):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("m", [64, 65, 128, 129])
+@pytest.mark.parametrize("m", [64, 65, 128, 129, 256, 257])
 def test_row_path_thresholds_agree_with_their_neighbours(m, monkeypatch):
-    """The same problem through every row-pass family that can take it (m = 64: small.hip, mid.hip, engine; 65 and 128:
-    mid.hip, engine; 129: engine only): each against the oracle, and against each other far inside that bound."""
+    """The same problem through every row-pass family that can take it (m = 64: small.hip, mid.hip, engine; 65 .. 256:
+    mid.hip -- one 128-column tile up to 128, two from 129 --, engine; 257: engine only): each against the oracle, and
+    against each other far inside that bound."""
     n, d = 1500, 3
     X, y, Z = synth(70 + m, n, m, d)
     hyp = dict(log_ell=0.5 * np.log(d) + 0.05, log_sf2=0.1, sigma2=0.12, inducing=Z, variational=True)
@@ -1836,7 +1846,7 @@ def test_row_path_thresholds_agree_with_their_neighbours(m, monkeypatch):
     paths = [("default", {})]
     if m <= 64:
         paths.append(("mid", {"GPRHIP_SMALL_PATH": "0"}))
-    if m <= 128:
+    if m <= 256:
         paths.append(("engine", {"GPRHIP_SMALL_PATH": "0", "GPRHIP_MID_PATH": "0"}))
     out = {}
     for name, env in paths:
@@ -1850,7 +1860,7 @@ def test_row_path_thresholds_agree_with_their_neighbours(m, monkeypatch):
         stages = set(p.last_timings())
         p.close()
         taken = "small" if "p1_small" in stages else ("mid" if "p1_mid" in stages else "engine")
-        expect = {"default": "small" if m <= 64 else ("mid" if m <= 128 else "engine"), "mid": "mid", "engine": "engine"}[name]
+        expect = {"default": "small" if m <= 64 else ("mid" if m <= 256 else "engine"), "mid": "mid", "engine": "engine"}[name]
         assert taken == expect, (name, stages)
         assert M.rel_ok("l", ev.l, ref["l"], TOL_L) and M.rel_ok("dl_dsigma2", ev.dl_dsigma2, ref["dl_dsigma2"], TOL_DS2)
         assert M.grad_ok(ev.grad, ref["grad"], fams, TOL_GRAD) and M.vec_ok("coeffs", ev.coeffs, ref["coeffs"], TOL_COEFF)
@@ -1937,7 +1947,7 @@ def _random_shape_case(seed, shards=0, small=False, mid=False):
             n = max(n, 200)
     if mid:  # the shapes of gpr_amd/csrc/mid.hip (65 .. 128 inducing points) and both of its thresholds: 64 | 65, 128 | 129
         n = int(rng.integers(1, 5000 if iso else 2500))
-        m = int(rng.choice([64, 65, 128, 129])) if seed % 4 == 0 else int(rng.integers(60, 134))
+        m = int(rng.choice([64, 65, 128, 129, 256, 257])) if seed % 4 == 0 else int(rng.integers(60, 262))
         d = int(rng.choice([1, 2, 3, 4, 5, 8, 9, 13, 16, 20] if iso else [1, 2, 3, 5, 8, 11, 13]))
         chunk_rows = int(rng.choice([0, 0, 1024]))
         if not iso:
@@ -1992,7 +2002,7 @@ def _random_shape_case(seed, shards=0, small=False, mid=False):
     if mid and not shards:
         stages = set(p.last_timings())
         Dp = D if (not iso and "tproj" in args) else 0
-        want_mid = 64 < m <= 128 and d <= 16 and 1 + d + Dp <= 32 and "log_multiscales_m05" not in args
+        want_mid = 64 < m <= 256 and d <= 16 and 1 + d + Dp <= 32 and "log_multiscales_m05" not in args
         want_small = m <= 64 and d <= (8 if "log_multiscales_m05" in args else 16) and Dp <= 64
         assert ("p1_mid" in stages) == (want_mid or (m <= 64 and not want_small and d <= 16 and 1 + d + Dp <= 32
                                                    and "log_multiscales_m05" not in args)), (stages, m, d, Dp)
@@ -2257,8 +2267,8 @@ def test_context_shards_on_one_device_equal_the_whole(ndev):
     assert M.rel_ok("l", ev.l, ref.l, TOL_SHARD)
     assert M.rel_ok("l", ev0.l, ref.l, TOL_SHARD)
     assert M.rel_ok("dl_dsigma2", ev.dl_dsigma2, ref.dl_dsigma2, TOL_SHARD)
-    assert M.grad_ok(ev.grad, ref.grad, M.families_golden(g), 100 * TOL_SHARD)
-    assert M.vec_ok("coeffs", ev.coeffs, ref.coeffs, 100 * TOL_SHARD)
+    assert M.grad_ok(ev.grad, ref.grad, M.families_golden(g), TOL_SHARD_GRAD)
+    assert M.vec_ok("coeffs", ev.coeffs, ref.coeffs, TOL_SHARD_GRAD)
     assert M.grad_ok(ev.grad, g["grad"], M.families_golden(g), TOL_GRAD)
 
 
@@ -2290,8 +2300,8 @@ def test_context_eight_way_partition_at_4096_inducing_points():
     assert a1 == packed + m + 4 and a2 == packed + (d + 1) * m + 8
     assert st["collectives"] == 2 and st["bytes"] == [a1 * 8, a2 * 8]
     assert M.rel_ok("l", ev.l, ref.l, TOL_SHARD)
-    assert abs(ev.dl_dsigma2 - ref.dl_dsigma2) <= 10 * TOL_SHARD * abs(ref.dl_dsigma2)
-    assert M.grad_ok(ev.grad, ref.grad, M.families("iso", d, m), 100 * TOL_SHARD)
+    assert M.rel_ok("dl_dsigma2", ev.dl_dsigma2, ref.dl_dsigma2, 1e-11)
+    assert M.grad_ok(ev.grad, ref.grad, M.families("iso", d, m), TOL_SHARD_GRAD)
     assert M.vec_ok("coeffs", ev.coeffs, ref.coeffs, 1e-6)  # cond(K_m) at m = 4096, d = 16 amplifies the summation-order difference
 
 
@@ -2317,20 +2327,20 @@ def test_context_posterior_paths_from_any_shard():
     for i in range(3):
         q = sp.problem(i)
         mi, vi = q.predict(Xt)
-        assert M.vec_ok("pred_mean", mi, mean, 100 * TOL_SHARD) and M.vec_ok("pred_var", vi, var, 100 * TOL_SHARD)
+        assert M.vec_ok("pred_mean", mi, mean, TOL_SHARD_GRAD) and M.vec_ok("pred_var", vi, var, TOL_SHARD_GRAD)
         si, _ = q.train_stats()
         acc[[0, 1, 3]] += si[[0, 1, 3]]
         acc[2] = max(acc[2], si[2])
-    assert M.vec_ok("stats", acc, sums, 100 * TOL_SHARD)
+    assert M.vec_ok("stats", acc, sums, TOL_SHARD_GRAD)
     ui, ri = sp.problem(2).co_variance_coeffs()
-    assert M.vec_ok("u", ui, u, 100 * TOL_SHARD) and M.vec_ok("r", ri, r, 100 * TOL_SHARD)
+    assert M.vec_ok("u", ui, u, TOL_SHARD_GRAD) and M.vec_ok("r", ri, r, TOL_SHARD_GRAD)
     # the sharded entry points: test points split over the devices, statistics combined by the library
     ms, vs = sp.predict(Xt)
-    assert M.vec_ok("pred_mean", ms, mean, 100 * TOL_SHARD) and M.vec_ok("pred_var", vs, var, 100 * TOL_SHARD)
+    assert M.vec_ok("pred_mean", ms, mean, TOL_SHARD_GRAD) and M.vec_ok("pred_var", vs, var, TOL_SHARD_GRAD)
     m1, v1 = sp.predict(Xt[:, :2], want_variances=False)  # fewer points than shards
-    assert v1 is None and M.vec_ok("pred_mean", m1, mean[:2], 100 * TOL_SHARD)
+    assert v1 is None and M.vec_ok("pred_mean", m1, mean[:2], TOL_SHARD_GRAD)
     ss, tm = sp.train_stats(want_means=True)
-    assert M.vec_ok("stats", ss, sums, 100 * TOL_SHARD) and M.vec_ok("pred_mean", tm, g["train_means"], 1e-7)
+    assert M.vec_ok("stats", ss, sums, TOL_SHARD_GRAD) and M.vec_ok("pred_mean", tm, g["train_means"], 1e-7)
     sp.close()
     ctx.close()
 
@@ -2495,7 +2505,8 @@ def test_fp32_bulk_refuses_coefficients_it_cannot_stand_behind(monkeypatch):
     p32.set_inputs(X)
     p32.set_targets(y)
     e32 = p32.eval(**hyp)
-    assert M.rel_ok("l", e32.l, e64.l, 3e-4) and M.grad_ok(e32.grad, e64.grad, M.families("iso", d, m), 1e-2)
+    # (few dimensions, hundreds of inducing points: outside the mode's regime -- the gradient as one family, as the sweeps do)
+    assert M.rel_ok("l", e32.l, e64.l, 3e-4) and M.grad_ok(e32.grad, e64.grad, [("whole", slice(0, e64.grad.shape[0]))], 1e-2)
     cond32, bound32 = p32.condition()
     assert abs(cond32 - cond64) <= 1e-3 * cond64 and bound32 > 0.25
     with pytest.raises(gpr_amd.UntrustworthyCoefficients) as ei:
