@@ -996,9 +996,26 @@ module Make_variant
   end
 end
 
-(* Fitc_gp.Make_deriv (lib/fitc_gp.mli:83-135): the four model families over one covariance spec.  (The sharing
-   constraints of the reference's signature -- FIC.Eval.Model = FITC.Eval.Model and so on -- are not reproduced: each
-   family is its own application of Make_variant, so a value built by one family is used with that family.) *)
+(* Fitc_gp.Make_deriv (lib/fitc_gp.mli:83-135): the four model families over one covariance spec.
+
+   The sharing constraints of the reference's signature (lib/fitc_gp.mli:87-135: FIC.Eval.Model = FITC.Eval.Model,
+   FIC.Eval.Means = FITC.Eval.Means, Variational_FITC.Eval.Inputs = FITC.Eval.Inputs ...) are NOT reproduced: each family
+   is its own application of Make_variant, sealed with Sigs.Deriv, so its Inducing / Inputs / Model / Trained / Means types
+   are abstract and distinct from the other families'.  Which of the reference's own programs that affects, precisely:
+     - bin/ocaml_gpr.ml uses one family throughout (module FIC = GP.Variational_FIC.Eval, :177; the trainer of the same
+       family, :340): type-checks as it is.  (:343 matches GP.FIC.Deriv.Optim.Gsl.Optim_exception, another family's
+       exception constructor: legal here as there, and as there it never matches what Variational_FIC's trainer raises.)
+     - test/test_derivatives.ml uses GP.FITC only (:22-60): type-checks as it is.
+     - test/save_data.ml:136-146 does NOT type-check: it passes a FITC model to FIC.Covariances.calc_model_inputs (:136)
+       and FITC means to FIC.Cov_sampler.calc (:138), i.e. it needs FIC.Eval.Model = FITC.Eval.Model and
+       FIC.Eval.Means = FITC.Eval.Means.  With this module the FIC block of that program evaluates under its own family:
+         let fic_inputs = FIC.Inputs.calc training_inputs (FIC.Inducing.calc kernel inducing_points) in
+         let fic_model = FIC.Model.calc fic_inputs ~sigma2 in
+         let fic_means = FIC.Means.calc (FIC.Mean_predictor.calc_trained (FIC.Trained.calc fic_model ~targets)) fic_inputs in
+       (one more evaluation on the device, same numbers: the families differ in Covariances only, lib/fitc_gp.ml:565-627).
+   Building FIC by [include]-ing FITC's modules (the reference's own construction: Make_FITC_deriv / Make_FIC_deriv over one Make_common_deriv, lib/fitc_gp.ml:2056-2108) needs
+   Make_variant split into an unsealed base and two covariance flavours over it; without a compiler in the build image that
+   refactoring of 1000 unchecked lines was judged more likely to break the module than to help a caller. *)
 module Make_deriv (S : Device_spec) (C : Config) = struct
   module type Sig = Gpr.Interfaces.Sigs.Deriv with module Eval.Spec = S.Deriv.Eval and module Deriv.Spec = S.Deriv
 

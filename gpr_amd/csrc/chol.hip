@@ -338,8 +338,31 @@ __device__ __forceinline__ void potrf_diag_body(double* __restrict__ A, int mp, 
     // K_m (lib/cov_se_iso.ml:56-87, lib/cov_se_fat.ml:85-100) + heteroskedastic noise + jitter on the real diagonal
     // (lib/fitc_gp.ml:54-55), 1 on the padded one; g.km = the covariance alone, full and symmetric, padding 0
     const ExpK ek = exp_consts();
-    double* zs = T1;  // [64][d] (d <= 16: the scratch of the inversion, free until then)
+    double* zs = T1;  // [m][d] (m <= 128, d <= 16: the scratch of the inversion, free until then)
     for (int idx = tid; idx < g.m * g.d; idx += PT) zs[idx] = g.Z[idx];
+    if (g.m > 64) {  // 65 .. 128 inducing points (round 6): every entry of the block, 32 per thread
+      __syncthreads();
+      for (int idx = tid; idx < NB * NB; idx += PT) {
+        const int r = idx / NB, c = idx % NB;
+        double val = 0.0, valj = (r == c) ? 1.0 : 0.0;
+        if (r < g.m && c < g.m) {
+          if (r == c) {
+            val = g.cp.sf2;
+            valj = (g.het ? g.cp.sf2 + g.het[c] : g.cp.sf2) + g.jitter;
+          } else {
+            double acc = 0.0;
+            for (int k = 0; k < g.d; ++k) {
+              const double diff = zs[c * g.d + k] - zs[r * g.d + k];
+              acc = acc + diff * diff;
+            }
+            val = exp_fast(g.cp.log_sf2 + g.cp.inv_ell2_05 * acc, ek);
+            valj = val;
+          }
+        }
+        g.km[idx] = val;
+        if (c >= r) T[r * LDT + c] = valj;
+      }
+    } else {
     for (int idx = tid; idx < NB * NB; idx += PT) {  // everything outside the 64 x 64 corner
       const int r = idx / NB, c = idx % NB;
       if (r < 64 && c < 64) continue;
@@ -366,6 +389,7 @@ __device__ __forceinline__ void potrf_diag_body(double* __restrict__ A, int mp, 
       }
       g.km[r * NB + c] = val;
       if (c >= r) T[r * LDT + c] = valj;
+    }
     }
   } else {
     for (int idx = tid; idx < NB * NB / 2; idx += PT) {

@@ -754,8 +754,8 @@ void do_pass1(gprhip_problem* p, const gprhip_hypers* h, int want_grad, int64_t 
   // (the one-tile passes write c~ and the tail outright; with two tiles c~ still comes from the engine's launch, accumulated)
   if (!(small || (mid && mp == TILE)) || reuse) GPR_HIP(hipMemsetAsync(ar1_c, 0, (size_t)(mp + A1_TAIL) * sizeof(double), s));
   // K_m + (hetero) + jitter goes straight into the factor's buffer (kj is scratch of the finish stage only)
-  if (mp == TILE && p->m <= 64 && p->d <= 16 && !p->engine_steps && !p->has_ms() && p->small_path) {
-    PotrfKm g;  // few inducing points: the covariance is built inside the factorisation kernel (chol.hip, MODE 2)
+  if (mp == TILE && p->d <= 16 && !p->engine_steps && !p->has_ms() && (p->m <= 64 ? p->small_path : p->mid_path)) {
+    PotrfKm g;  // one block of inducing points: the covariance is built inside the factorisation kernel (chol.hip, MODE 2)
     g.cp = p->cp; g.Z = p->Z; g.m = p->m; g.d = p->d; g.jitter = h->jitter;
     g.het = p->has_het() ? p->het : nullptr; g.km = p->km;
     launch_potrf_km(g, p->umat, p->uinv, p->info, s);

@@ -33,6 +33,8 @@ TOL_ROW = 1e-10     # per-row intermediates r, 1/s                              
 TOL_ROWVW = 2e-10   # per-row v, w                                                                     worst seen 1.9e-11
 TOL_SHARD = 2e-14   # l, dl/dsigma2 of two row partitions of one problem (summation order only)        worst seen 1.4e-15
 TOL_SHARD_GRAD = 1e-9  # ... their gradient families and coefficients                                  worst seen 9.4e-11
+TOL_POST = 3e-10    # posterior means / variances / training means / statistics / samples against the oracle   worst seen 3.2e-11
+TOL_FACTOR = 1e-11  # exported factors chol_km, r_mat                                                   worst seen 1.2e-12
 TOL_BENCH = 1e-9    # bench.py's last evaluation across launch modes (l, dl/dsigma2, |grad|; relative to max(1, |.|))
 
 
@@ -335,7 +337,7 @@ def test_prediction_means_and_variances():
     p.set_targets(y)
     p.eval(log_ell=0.4, log_sf2=0.2, sigma2=0.15, inducing=Z, want_grad=False)
     mean, var = p.predict(Xt, predictive=False)
-    assert M.vec_ok("pred_mean", mean, mean_ref, 1e-8)
+    assert M.vec_ok("pred_mean", mean, mean_ref, TOL_POST)
     assert np.max(np.abs(var - var_ref)) <= 1e-8 * np.max(np.abs(var_ref))
     _, varp = p.predict(Xt, predictive=True)
     assert np.allclose(varp, var + 0.15, rtol=0, atol=1e-12)
@@ -349,9 +351,9 @@ def test_prediction_means_and_variances():
     test_inputs = F.Eval.Inputs.calc(Xt, inducing)
     means = F.Eval.Means.get(F.Eval.Means.calc(F.Eval.Mean_predictor.calc_trained(trained), test_inputs))
     variances = F.Eval.Variances.calc(F.Eval.Co_variance_predictor.calc_model(model), 0.15, test_inputs)
-    assert M.vec_ok("pred_mean", means, mean_ref, 1e-8)
-    assert M.vec_ok("pred_var", F.Eval.Variances.get(variances, predictive=False), var_ref, 1e-8)
-    assert M.vec_ok("pred_var", F.Eval.Variances.get(variances), var_ref + 0.15, 1e-8)
+    assert M.vec_ok("pred_mean", means, mean_ref, TOL_POST)
+    assert M.vec_ok("pred_var", F.Eval.Variances.get(variances, predictive=False), var_ref, TOL_POST)
+    assert M.vec_ok("pred_var", F.Eval.Variances.get(variances), var_ref + 0.15, TOL_POST)
     other = F.Eval.Inputs.calc(Xt, F.Eval.Inducing.calc(kernel, Z.copy()))
     with pytest.raises(ValueError, match="disagree about inducing points"):   # lib/fitc_gp.ml:419-424
         F.Eval.Means.calc(trained, other)
@@ -386,7 +388,7 @@ def test_prediction_of_far_more_test_points_than_training_points(kind, n, m, d, 
     mean, var = p.predict(Xt, predictive=False)
     sample = rng.permutation(nt)[:3000]
     Xs = np.asfortranarray(Xt[:, sample])
-    assert M.vec_ok("pred_mean", mean[sample], O.predict_means(k, Z, ref["coeffs"], Xs), 1e-8)
+    assert M.vec_ok("pred_mean", mean[sample], O.predict_means(k, Z, ref["coeffs"], Xs), TOL_POST)
     vref = O.predict_variances(k, Z, ref["model"], Xs, predictive=False)
     assert np.max(np.abs(var[sample] - vref)) <= 1e-8 * np.max(np.abs(vref))
     # the same points in pieces no larger than the training chunk
@@ -777,7 +779,7 @@ def test_stats_covariances_and_samplers():
     p.set_targets(y)
     p.eval(log_ell=0.35, log_sf2=0.15, sigma2=s2, inducing=Z, want_grad=False)
     sums, tm = p.train_stats(want_means=True)
-    assert M.vec_ok("train_means", tm, tm_ref, 1e-8)
+    assert M.vec_ok("train_means", tm, tm_ref, TOL_POST)
     assert abs(sums[0] - st_ref["sse"]) <= 1e-8 * st_ref["sse"]
     assert abs(sums[1] / n - st_ref["mad"]) <= 1e-8 * st_ref["mad"]
     assert abs(sums[2] - st_ref["maxad"]) <= 1e-8 * st_ref["maxad"]
@@ -818,7 +820,7 @@ def test_stats_covariances_and_samplers():
         for key in ("target_variance", "sse", "mse", "rmse", "smse", "msll", "mad", "maxad"):
             assert abs(getattr(st, key) - st_ref[key]) <= 1e-8 * abs(st_ref[key]), key
         assert st.n_samples == n and abs(E.Stats.calc_rmse(trained) - st_ref["rmse"]) <= 1e-8
-        assert M.vec_ok("pred_mean", E.Trained.calc_means(trained), tm_ref, 1e-8)
+        assert M.vec_ok("pred_mean", E.Trained.calc_means(trained), tm_ref, TOL_POST)
         tin = E.Inputs.calc(Xt, inducing)
         covs = E.Covariances.calc(E.Co_variance_predictor.calc_model(model), s2, tin)
         assert np.max(np.abs(np.triu(E.Covariances.get(covs, predictive=False)) - cref)) <= 1e-8 * scale
@@ -869,8 +871,8 @@ def test_calc_model_inputs_family_and_inducing_choice():
         assert M.rel_ok("l", E.Trained.calc_log_evidence(trained), ref["l"], 1e-9)
         var_ref = O.variances_model_inputs(ref["model"])
         v = E.Variances.calc_model_inputs(model)
-        assert M.vec_ok("pred_var", E.Variances.get(v, predictive=False), var_ref, 1e-8)
-        assert M.vec_ok("pred_var", E.Variances.get(v), var_ref + s2, 1e-8)
+        assert M.vec_ok("pred_var", E.Variances.get(v, predictive=False), var_ref, TOL_POST)
+        assert M.vec_ok("pred_var", E.Variances.get(v), var_ref + s2, TOL_POST)
         cref = O.fic_covariances_model_inputs(ref["model"]) if fic else O.fitc_covariances_model_inputs(k, ref["model"], X)
         c = E.Covariances.calc_model_inputs(model)
         got = E.Covariances.get(c, predictive=False)
@@ -906,8 +908,8 @@ def test_golden_posterior(name):
     assert M.rel_ok("l", ev.l, g["l"], TOL_L)
     s2 = float(g["sigma2"])
     means, var = p.predict(g["Xt"], predictive=False)
-    assert M.vec_ok("pred_mean", means, g["means"], 1e-8)
-    assert M.vec_ok("pred_var", var, g["variances"], 1e-8)
+    assert M.vec_ok("pred_mean", means, g["means"], TOL_POST)
+    assert M.vec_ok("pred_var", var, g["variances"], TOL_POST)
     scale = max(np.max(np.abs(g["fitc_cov"])), np.max(np.abs(g["fic_cov"])))
     cov = p.covariances(g["Xt"], kind="FITC", predictive=False)
     assert np.max(np.abs(np.triu(cov) - g["fitc_cov"])) <= 1e-8 * scale
@@ -915,7 +917,7 @@ def test_golden_posterior(name):
     S = p.cov_samples(cov, means, g["z"], add_diag=s2)
     assert np.max(np.abs(S - g["samples"])) <= 1e-8 * np.max(np.abs(g["samples"]))
     sums, tm = p.train_stats(want_means=True)
-    assert M.vec_ok("pred_mean", tm, g["train_means"], 1e-8)
+    assert M.vec_ok("pred_mean", tm, g["train_means"], TOL_POST)
     st = dict(zip(STAT_KEYS, g["stats"]))
     n = int(st["n_samples"])
     assert abs(sums[0] - st["sse"]) <= 1e-8 * st["sse"] and abs(sums[1] / n - st["mad"]) <= 1e-8 * st["mad"]
@@ -1048,8 +1050,8 @@ def test_model_export_import_and_file_flow(tmp_path):
     p = _problem_for(g)
     _eval_golden(p, g, want_grad=True)        # a gradient evaluation must leave R~ intact as well
     chol_km, r_mat = p.co_variance_coeffs()
-    assert M.vec_ok("chol_km", np.triu(chol_km), np.triu(ref["model"]["inducing"]["chol_km"]), 1e-9)
-    assert M.vec_ok("r_mat", np.triu(r_mat), np.triu(ref["model"]["r_mat"]), 1e-9)
+    assert M.vec_ok("chol_km", np.triu(chol_km), np.triu(ref["model"]["inducing"]["chol_km"]), TOL_FACTOR)
+    assert M.vec_ok("r_mat", np.triu(r_mat), np.triu(ref["model"]["r_mat"]), TOL_FACTOR)
     assert np.all(np.tril(chol_km, -1) == 0.0) and np.all(np.tril(r_mat, -1) == 0.0)
     means, var = p.predict(g["Xt"], predictive=False)
     cov = p.covariances(g["Xt"], kind="FIC", predictive=False)
@@ -1063,8 +1065,8 @@ def test_model_export_import_and_file_flow(tmp_path):
                 log_hetero_skedasticity=g["log_hetero"], log_multiscales_m05=g["log_multiscales"])
     q.load_predictor(coeffs=coeffs, co_variance_coeffs=(chol_km, r_mat), **args)
     means2, var2 = q.predict(g["Xt"], predictive=False)
-    assert M.vec_ok("pred_mean", means2, g["means"], 1e-8) and M.vec_ok("pred_mean", means2, means, 1e-10)
-    assert M.vec_ok("pred_var", var2, g["variances"], 1e-8) and M.vec_ok("pred_var", var2, var, 1e-9)
+    assert M.vec_ok("pred_mean", means2, g["means"], TOL_POST) and M.vec_ok("pred_mean", means2, means, 1e-10)
+    assert M.vec_ok("pred_var", var2, g["variances"], TOL_POST) and M.vec_ok("pred_var", var2, var, 1e-9)
     assert M.vec_ok("pred_var", q.covariances(g["Xt"], kind="FIC", predictive=False), cov, 1e-9)
     u2, r2 = q.co_variance_coeffs()            # what was loaded comes back out
     assert M.vec_ok("chol_km", u2, chol_km, 1e-12) and M.vec_ok("r_mat", r2, r_mat, 1e-10)
@@ -1245,26 +1247,26 @@ def test_cpp_host_mirror(tmp_path, name):
     knm, _ = O.spec_calc_shared_cross(k, g["X"], g["Z"])
     tm = knm @ ref["coeffs"]
     st = O.stats_calc(g["y"], tm, ref["l"])
-    assert M.vec_ok("pred_mean", res["train_means"], tm, 1e-8)
-    assert M.vec_ok("stats", res["stats"], [st[key] for key in STAT_KEYS], 1e-8)
-    assert M.vec_ok("pred_mean", res["means"], O.predict_means(k, g["Z"], ref["coeffs"], Xt), 1e-8)
+    assert M.vec_ok("pred_mean", res["train_means"], tm, TOL_POST)
+    assert M.vec_ok("stats", res["stats"], [st[key] for key in STAT_KEYS], TOL_POST)
+    assert M.vec_ok("pred_mean", res["means"], O.predict_means(k, g["Z"], ref["coeffs"], Xt), TOL_POST)
     var = O.predict_variances(k, g["Z"], ref["model"], Xt, predictive=False)
-    assert M.vec_ok("pred_var", res["variances"], var, 1e-8) and M.vec_ok("pred_var", res["variances_predictive"], var + s2, 1e-8)
+    assert M.vec_ok("pred_var", res["variances"], var, TOL_POST) and M.vec_ok("pred_var", res["variances_predictive"], var + s2, TOL_POST)
     nt = Xt.shape[1]
     cref = (O.fitc_covariances if g["kind"] == "iso" else O.fic_covariances)(k, g["Z"], ref["model"], Xt)
     cov = res["cov"].reshape(nt, nt)
     assert np.max(np.abs(np.triu(cov) - cref)) <= 1e-8 * np.max(np.abs(cref))
     m = g["Z"].shape[1]
-    assert M.vec_ok("chol_km", np.triu(res["chol_km"].reshape(m, m).T), np.triu(ref["model"]["inducing"]["chol_km"]), 1e-9)
-    assert M.vec_ok("r_mat", np.triu(res["r_mat"].reshape(m, m).T), np.triu(ref["model"]["r_mat"]), 1e-9)
+    assert M.vec_ok("chol_km", np.triu(res["chol_km"].reshape(m, m).T), np.triu(ref["model"]["inducing"]["chol_km"]), TOL_FACTOR)
+    assert M.vec_ok("r_mat", np.triu(res["r_mat"].reshape(m, m).T), np.triu(ref["model"]["r_mat"]), TOL_FACTOR)
     ref2 = O.evaluate(k, g["Z"], g["X"], g["y"], 2 * s2, variational=variational, want_grad=False)
     assert M.rel_ok("l", res["l_sigma2x2"][0], ref2["l"], TOL_L)
     mean_ref = O.predict_means(k, g["Z"], ref["coeffs"], Xt)
-    assert M.vec_ok("pred_mean", res["standalone_means"], mean_ref, 1e-8)
-    assert M.vec_ok("pred_var", res["standalone_variances"], var, 1e-8)
+    assert M.vec_ok("pred_mean", res["standalone_means"], mean_ref, TOL_POST)
+    assert M.vec_ok("pred_var", res["standalone_variances"], var, TOL_POST)
     zz = np.stack([np.sin(1.0 + np.arange(nt)), np.cos(2.0 * np.arange(nt))], axis=1)
     smp = O.cov_sampler_calc(mean_ref, O.fitc_covariances(k, g["Z"], ref["model"], Xt), s2, predictive=True)
-    assert M.vec_ok("samples", res["samples"].reshape(2, nt).T, O.cov_sampler_samples(smp, zz), 1e-8)
+    assert M.vec_ok("samples", res["samples"].reshape(2, nt).T, O.cov_sampler_samples(smp, zz), TOL_POST)
     assert res["phys_equal_check"][0] == 1.0 and res["self_test"][0] == 1.0
     assert np.array_equal(res["error_checks"], [1.0, 1.0])
 
@@ -1306,11 +1308,11 @@ def test_ill_conditioned_regime(name):
     assert M.rel_ok("l", ev.l, float(g["l"]), 1e-10)
     assert M.rel_ok("dl_dsigma2", ev.dl_dsigma2, float(g["dl_dsigma2"]), 1e-9)
     assert M.grad_ok(ev.grad, g["grad"], M.families_golden(g), 1e-8)
-    assert M.vec_ok("coeffs", ev.coeffs, g["coeffs"], 1e-8)
+    assert M.vec_ok("coeffs", ev.coeffs, g["coeffs"], 5e-9)
     if "mp_l1" in g:
         assert M.rel_ok("l1", ev.l1, float(g["mp_l1"]), 1e-10)
         assert M.rel_ok("l2", ev.l2, float(g["mp_l2"]), 1e-10)
-        assert M.vec_ok("coeffs", ev.coeffs, g["mp_coeffs"], 1e-8)
+        assert M.vec_ok("coeffs", ev.coeffs, g["mp_coeffs"], 5e-9)
     print("illcond %s: l %.2e  ds2 %.2e  grad %.2e  coeffs %.2e" % (
         name, abs(ev.l - float(g["l"])) / abs(float(g["l"])),
         abs(ev.dl_dsigma2 - float(g["dl_dsigma2"])) / abs(float(g["dl_dsigma2"])), relinf(ev.grad, g["grad"]),
@@ -1612,7 +1614,11 @@ def test_inputs_with_a_large_common_offset():
     X, y, Z = synth(31, n, m, d)
     X = np.asfortranarray(X + 1.0e4)
     Z = np.asfortranarray(Z + 1.0e4)
-    ref = O.evaluate_fast(O.SeIsoKernel(0.3, 0.0), Z, X, y, 0.1)
+    # The expected values come from the oracle on the SAME points moved back to the origin (the subtraction is exact): the
+    # kernel only sees differences, and evaluated on the offset data the oracle itself -- the reference's operation sequence --
+    # differs from this by 2.6e-7 of the largest inducing-point entry (the sums sum_r x_kr E_rc carry the offset), which a
+    # per-family bound of 1e-8 would then charge to the device.
+    ref = O.evaluate_fast(O.SeIsoKernel(0.3, 0.0), np.asfortranarray(Z - 1.0e4), np.asfortranarray(X - 1.0e4), y, 0.1)
     p = gpr_amd.Problem(gpr_amd.COV_SE_ISO, n, d, d, m)
     p.set_inputs(X)
     p.set_targets(y)
@@ -1693,9 +1699,9 @@ def test_point_dimensions_above_64():
     assert M.grad_ok(ev.grad, ref["grad"], M.families("fat", d, m, D=D, proj=True), TOL_GRAD) and M.vec_ok("coeffs", ev.coeffs, ref["coeffs"], TOL_COEFF)
     Xt = np.asfortranarray(rng.normal(size=(D, 77)))
     mean, var = p.predict(Xt, predictive=False)
-    assert M.vec_ok("pred_mean", mean, O.predict_means(k, Z, ref["coeffs"], Xt), 1e-8)
+    assert M.vec_ok("pred_mean", mean, O.predict_means(k, Z, ref["coeffs"], Xt), TOL_POST)
     model = O.evaluate(k, Z, X, y, 0.1, want_grad=False, keep=True)["model"]
-    assert M.vec_ok("pred_var", var, O.predict_variances(k, Z, model, Xt, predictive=False), 1e-8)
+    assert M.vec_ok("pred_var", var, O.predict_variances(k, Z, model, Xt, predictive=False), TOL_POST)
     p.close()
     n, m, d = 2500, 130, 100
     X, y, Z = synth(23, n, m, d)
@@ -1858,12 +1864,13 @@ def test_row_path_thresholds_agree_with_their_neighbours(m, monkeypatch):
         p.set_timing(2)
         ev = p.eval(**hyp)
         stages = set(p.last_timings())
+        cond = p.condition()[0]
         p.close()
         taken = "small" if "p1_small" in stages else ("mid" if "p1_mid" in stages else "engine")
         expect = {"default": "small" if m <= 64 else ("mid" if m <= 256 else "engine"), "mid": "mid", "engine": "engine"}[name]
         assert taken == expect, (name, stages)
         assert M.rel_ok("l", ev.l, ref["l"], TOL_L) and M.rel_ok("dl_dsigma2", ev.dl_dsigma2, ref["dl_dsigma2"], TOL_DS2)
-        assert M.grad_ok(ev.grad, ref["grad"], fams, TOL_GRAD) and M.vec_ok("coeffs", ev.coeffs, ref["coeffs"], TOL_COEFF)
+        assert M.grad_ok(ev.grad, ref["grad"], fams, TOL_GRAD, cond=cond) and M.vec_ok("coeffs", ev.coeffs, ref["coeffs"], TOL_COEFF)
         out[name] = ev
     for name in out:
         assert M.rel_ok("l", out[name].l, out["default"].l, 1e-10)
