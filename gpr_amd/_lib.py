@@ -10,7 +10,10 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgprhip.so")
+# GPRHIP_LIBRARY=lab selects the lab build (`make -C gpr_amd/csrc lab`: the production code plus the measured-slower variants
+# kept for A/B runs -- GPRHIP_POTRF_CHAIN, GPRHIP_POTRF_LOOKAHEAD, GPRHIP_ROUND_SYNC_US, GPRHIP_COV_OVERLAP; the production
+# library ignores those switches).  Read once, when the library is first loaded.
+LIB_PATH = os.path.join(_HERE, "libgprhip_lab.so" if os.environ.get("GPRHIP_LIBRARY") == "lab" else "libgprhip.so")
 
 OK, EBADARG, ENOTPOSDEF, EHIP, EOOM, ESTATE, ECOMM, EPRECISION = range(8)
 COMM_NONE, COMM_RCCL, COMM_SAME_DEVICE = 0, 1, 2

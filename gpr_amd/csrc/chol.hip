@@ -338,31 +338,8 @@ __device__ __forceinline__ void potrf_diag_body(double* __restrict__ A, int mp, 
     // K_m (lib/cov_se_iso.ml:56-87, lib/cov_se_fat.ml:85-100) + heteroskedastic noise + jitter on the real diagonal
     // (lib/fitc_gp.ml:54-55), 1 on the padded one; g.km = the covariance alone, full and symmetric, padding 0
     const ExpK ek = exp_consts();
-    double* zs = T1;  // [m][d] (m <= 128, d <= 16: the scratch of the inversion, free until then)
+    double* zs = T1;  // [64][d] (d <= 16: the scratch of the inversion, free until then)
     for (int idx = tid; idx < g.m * g.d; idx += PT) zs[idx] = g.Z[idx];
-    if (g.m > 64) {  // 65 .. 128 inducing points (round 6): every entry of the block, 32 per thread
-      __syncthreads();
-      for (int idx = tid; idx < NB * NB; idx += PT) {
-        const int r = idx / NB, c = idx % NB;
-        double val = 0.0, valj = (r == c) ? 1.0 : 0.0;
-        if (r < g.m && c < g.m) {
-          if (r == c) {
-            val = g.cp.sf2;
-            valj = (g.het ? g.cp.sf2 + g.het[c] : g.cp.sf2) + g.jitter;
-          } else {
-            double acc = 0.0;
-            for (int k = 0; k < g.d; ++k) {
-              const double diff = zs[c * g.d + k] - zs[r * g.d + k];
-              acc = acc + diff * diff;
-            }
-            val = exp_fast(g.cp.log_sf2 + g.cp.inv_ell2_05 * acc, ek);
-            valj = val;
-          }
-        }
-        g.km[idx] = val;
-        if (c >= r) T[r * LDT + c] = valj;
-      }
-    } else {
     for (int idx = tid; idx < NB * NB; idx += PT) {  // everything outside the 64 x 64 corner
       const int r = idx / NB, c = idx % NB;
       if (r < 64 && c < 64) continue;
@@ -389,7 +366,6 @@ __device__ __forceinline__ void potrf_diag_body(double* __restrict__ A, int mp, 
       }
       g.km[r * NB + c] = val;
       if (c >= r) T[r * LDT + c] = valj;
-    }
     }
   } else {
     for (int idx = tid; idx < NB * NB / 2; idx += PT) {
@@ -843,6 +819,7 @@ __global__ __launch_bounds__(256) void triu_matvec_kernel(const double* __restri
   if (lane == 0) y[i] = s;
 }
 
+#ifdef GPRHIP_LAB  // (measured 1.4 - 2.8 x slower than the step launches, DESIGN section 4: lab build only)
 // ---- the whole factorisation + carried inverse as ONE launch with device-side dependencies (round 5) ---------------
 //
 // potrf_upper_blocked above is a chain of three launches per 128-row step (diagonal block -> panel -> trailing update),
@@ -1173,6 +1150,8 @@ __global__ __launch_bounds__(PT) void potrf_chain_kernel(ChainArgs g) {
   }
 }
 
+#endif  // GPRHIP_LAB
+
 // dynamic-LDS opt-in of the two step kernels, once per device
 static void potrf_attrs() {
   static uint64_t done = 0;
@@ -1185,8 +1164,10 @@ static void potrf_attrs() {
                                 hipFuncAttributeMaxDynamicSharedMemorySize, POTRF_LDS));
     GPR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&potrf_panel_kernel),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, PANEL_LDS));
+#ifdef GPRHIP_LAB
     GPR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&potrf_chain_kernel),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, POTRF_LDS));
+#endif
   });
 }
 void launch_potrf_km(const PotrfKm& g, double* A, double* Xinv, int* info, hipStream_t s) {
@@ -1271,7 +1252,11 @@ void potrf_upper_blocked(hipStream_t s, double* A, int mp, double* dinv, int* in
     if (rest > 0) {
       const int nsym = ns * (ns + 1) / 2, ny = ns * nrhs, tiles = nsym + ny;
       const int csym = std::min(nsym, 2 * ns - 1), cy = std::min(ny, 2 * nrhs);  // block row j + 1
+#ifdef GPRHIP_LAB  // (two-stream look-ahead: measured slower wherever it engages, lab build only)
       const bool split = aux && aux->side && la_min > 0 && (nsym - csym) + (ny - cy) >= la_min;
+#else
+      const bool split = false;
+#endif
       if (pending) {  // this step's update writes the tiles the previous step's rest is still writing
         GPR_HIP(hipStreamWaitEvent(s, aux->ev_rest[(j - 1) & 1], 0));
         pending = false;
@@ -1293,6 +1278,7 @@ void potrf_upper_blocked(hipStream_t s, double* A, int mp, double* dinv, int* in
   GPR_HIP(hipGetLastError());
 }
 
+#ifdef GPRHIP_LAB
 struct PotrfChain {
   int device = 0, mp = 0, nb = 0, ntasks = 0, epoch = 0, grid = 0;
   int* sync = nullptr;
@@ -1385,6 +1371,8 @@ void potrf_upper_chain(hipStream_t s, PotrfChain* ch, double* A, int mp, double*
   hipLaunchKernelGGL(potrf_chain_kernel, dim3(ch->grid), dim3(PT), POTRF_LDS, s, g);
   GPR_HIP(hipGetLastError());
 }
+
+#endif  // GPRHIP_LAB
 
 void launch_zero_strict_lower(double* A, int mp, hipStream_t s) {
   hipLaunchKernelGGL(zero_strict_lower_kernel, dim3((mp + 255) / 256, mp), dim3(256), 0, s, A, mp);

@@ -158,7 +158,9 @@ struct gprhip_problem {
   // ONE persistent launch with device-side dependencies (chol.hip, potrf_upper_chain) instead of three launches per step.
   // Built in round 5, bit-identical, and measured 1.4 - 2.8 x SLOWER than the launches: kept for A/B
   int potrf_chain_mode = 0;
+#ifdef GPRHIP_LAB
   PotrfChain* chain = nullptr;  // its task list and flag words (created at the first factorisation)
+#endif
   // n x m storage: double, or float in the fp32-bulk mode (element size `esz`)
   void *bufA = nullptr, *bufB = nullptr, *Vstore = nullptr;
   // Cov_se_fat with projection hypers: K_nm of all rows, kept from pass 1 for the gradient kernel of pass 2 (which then
@@ -427,6 +429,7 @@ void potrf_trtri(gprhip_problem* p, double* A, double* X, double* tmp, int* info
     trtri_upper(p, A, X, tmp);
     return;
   }
+#ifdef GPRHIP_LAB
   if (p->potrf_chain_mode && p->mp >= 2 * TILE) {
     if (!p->chain) p->chain = potrf_chain_create(p->mp);
     if (p->chain) {
@@ -434,6 +437,7 @@ void potrf_trtri(gprhip_problem* p, double* A, double* X, double* tmp, int* info
       return;
     }
   }
+#endif
   potrf_upper_blocked(p->stream, A, p->mp, p->dinv, info, tmp, X, p->m, p->potrf_aux.side ? &p->potrf_aux : nullptr);
 }
 
@@ -754,8 +758,10 @@ void do_pass1(gprhip_problem* p, const gprhip_hypers* h, int want_grad, int64_t 
   // (the one-tile passes write c~ and the tail outright; with two tiles c~ still comes from the engine's launch, accumulated)
   if (!(small || (mid && mp == TILE)) || reuse) GPR_HIP(hipMemsetAsync(ar1_c, 0, (size_t)(mp + A1_TAIL) * sizeof(double), s));
   // K_m + (hetero) + jitter goes straight into the factor's buffer (kj is scratch of the finish stage only)
-  if (mp == TILE && p->d <= 16 && !p->engine_steps && !p->has_ms() && (p->m <= 64 ? p->small_path : p->mid_path)) {
-    PotrfKm g;  // one block of inducing points: the covariance is built inside the factorisation kernel (chol.hip, MODE 2)
+  // (tried for 65 .. 128 inducing points too, round 6: 16 384 entries on ONE CU cost 20 us at d = 8 where the cov_upper launch
+  //  spread over the chip costs 4 + its 4 us gap -- K_m phase 45 -> 68 us; it stays a launch of its own above 64)
+  if (mp == TILE && p->m <= 64 && p->d <= 16 && !p->engine_steps && !p->has_ms() && p->small_path) {
+    PotrfKm g;  // few inducing points: the covariance is built inside the factorisation kernel (chol.hip, MODE 2)
     g.cp = p->cp; g.Z = p->Z; g.m = p->m; g.d = p->d; g.jitter = h->jitter;
     g.het = p->has_het() ? p->het : nullptr; g.km = p->km;
     launch_potrf_km(g, p->umat, p->uinv, p->info, s);
@@ -809,7 +815,11 @@ void do_pass1(gprhip_problem* p, const gprhip_hypers* h, int want_grad, int64_t 
   // Overlap (GPRHIP_COV_OVERLAP=1): chunk c + 1's covariance goes out on the second stream just before chunk c's V product
   // goes out on the main one, into the other chunk buffer (pass 1 uses one of the two at a time) -- it waits only for the V
   // product that last read that buffer, i.e. it runs beside V(c).
+#ifdef GPRHIP_LAB
   const bool overlap = p->cov_overlap && cov0_ahead && p->nchunks >= 2;
+#else
+  constexpr bool overlap = false;  // (measured: no gain, profiles/r05_lab_cov_overlap.txt -- lab build only)
+#endif
   TS* const bufB1 = static_cast<TS*>(p->bufB);
   auto kbuf = [&](int c) -> TS* {
     if (Kstore) return Kstore + (int64_t)c * p->chunk * mp;
@@ -2010,14 +2020,17 @@ int gprhip_problem_create_ex(int device, int cov_kind, int precision, int64_t n,
     if (const char* e = getenv("GPRHIP_F32_COEFF_TOL")) p->f32_coeff_tol = atof(e);
     if (const char* e = getenv("GPRHIP_MERGED_X")) p->merged_x_mode = atoi(e);
     if (const char* e = getenv("GPRHIP_POTRF_ENGINE")) p->engine_steps = atoi(e) != 0;
+#ifdef GPRHIP_LAB  // the measured-slower variants (DESIGN sections 4, 14): switches of the lab build only
     if (const char* e = getenv("GPRHIP_POTRF_CHAIN")) p->potrf_chain_mode = atoi(e);
+    if (const char* e = getenv("GPRHIP_COV_OVERLAP")) p->cov_overlap = atoi(e);
+#endif
     GPR_HIP(hipStreamCreate(&p->stream));
     GPR_HIP(hipStreamCreate(&p->stream2));
-    if (const char* e = getenv("GPRHIP_COV_OVERLAP")) p->cov_overlap = atoi(e);
     for (int k = 0; k < 2; ++k) {
       GPR_HIP(hipEventCreateWithFlags(&p->ev_cov[k], hipEventDisableTiming));
       GPR_HIP(hipEventCreateWithFlags(&p->ev_vdone[k], hipEventDisableTiming));
     }
+#ifdef GPRHIP_LAB
     if (p->mp >= 3 * TILE && getenv("GPRHIP_POTRF_LOOKAHEAD") && atoi(getenv("GPRHIP_POTRF_LOOKAHEAD")) > 0) {  // (A/B runs only)
       p->potrf_aux.min_rest = atoi(getenv("GPRHIP_POTRF_LOOKAHEAD"));
       GPR_HIP(hipStreamCreate(&p->potrf_aux.side));
@@ -2026,6 +2039,7 @@ int gprhip_problem_create_ex(int device, int cov_kind, int precision, int64_t n,
         GPR_HIP(hipEventCreateWithFlags(&p->potrf_aux.ev_rest[k], hipEventDisableTiming));
       }
     }
+#endif
     GPR_HIP(hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming));
     GPR_HIP(hipEventCreateWithFlags(&p->ev_join, hipEventDisableTiming));
     GPR_HIP(hipEventCreateWithFlags(&p->ev_rf, hipEventDisableTiming));
@@ -2150,7 +2164,9 @@ void gprhip_problem_destroy(gprhip_problem* p) {
     hipEventDestroy(p->timer.k1);
   }
   for (void* a : p->allocs) hipFree(a);
+#ifdef GPRHIP_LAB
   potrf_chain_destroy(p->chain);
+#endif
   delete p;
 }
 

@@ -68,8 +68,9 @@ void potrf_upper_blocked(hipStream_t s, double* A, int mp, double* dinv, int* in
 // workspace holds the task lists and flag words of an mp x mp problem (mp / 128 >= 2 blocks; create returns null
 // otherwise) on the current device.  *info: first non-positive pivot (1-based), or POTRF_CHAIN_ABORT_CODE if a
 // dependency wait ran into its bound (an internal error: the caller reports GPRHIP_EHIP).
-struct PotrfChain;
 constexpr int POTRF_CHAIN_ABORT_CODE = 0x7ffffff0;
+#ifdef GPRHIP_LAB
+struct PotrfChain;
 PotrfChain* potrf_chain_create(int mp);
 void potrf_chain_destroy(PotrfChain* ch);
 // trace (device, [ntasks + mp/128][4] 64-bit words, or null): per task / diagonal block the 100 MHz wall-clock stamps
@@ -77,6 +78,7 @@ void potrf_chain_destroy(PotrfChain* ch);
 void potrf_upper_chain(hipStream_t s, PotrfChain* ch, double* A, int mp, double* dinv, int* info, double* Y, double* Xinv,
                        int m_real = 0, unsigned long long* trace = nullptr);
 int potrf_chain_tasks(const PotrfChain* ch, int* kinds4);  // the task list ({kind, j, a, b} each), returns its length
+#endif
 // Single-block matrices (mp = 128): A = chol(I + src) (upper, in place of a load: src = the (0,0) tile of an exchange-1
 // buffer), Xinv = A^-1, and the m-vectors that follow in pass 2 (chol.hip, potrf_diag_body<true>):
 //   b = Xinv^T cvec, t~ = Xinv b, t = uinv t~, logdet = log|I + src|, bb = |b|^2

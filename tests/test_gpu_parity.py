@@ -1555,31 +1555,52 @@ def test_two_phase_and_two_launch_x_products_agree(name, monkeypatch):
 
 
 @pytest.mark.parametrize("m", [300, 700])
-def test_opt_in_factorisation_variants_are_bit_identical(m, monkeypatch):
+def test_opt_in_factorisation_variants_are_bit_identical(m, tmp_path):
     """Round 5 built two alternatives to the three-launches-per-step factorisation of K_m + jitter and B~ (chol.hip):
     ONE persistent launch with device-side dependencies (GPRHIP_POTRF_CHAIN=1) and a look-ahead split of every step's
-    trailing update over two streams (GPRHIP_POTRF_LOOKAHEAD=n).  Both measured slower and stay off (DESIGN section 4,
-    "Round 5"), but they apply the same tile updates in the same order: whole evaluations through them return the very
-    same numbers as the default path (both switches are read when the problem is created)."""
+    trailing update over two streams (GPRHIP_POTRF_LOOKAHEAD=n).  Both measured slower ("Round 5") and
+    since round 6 live in the LAB build only (libgprhip_lab.so, `make -C gpr_amd/csrc lab`, GPRHIP_LIBRARY=lab; the production
+    library carries one factorisation and ignores the switches), but they apply the same tile updates in the same order:
+    whole evaluations through them return the very same numbers as the production library's (each variant in a fresh
+    interpreter, since the library is chosen when gpr_amd first loads it)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lab = os.path.join(root, "gpr_amd", "libgprhip_lab.so")
+    if not os.path.exists(lab):
+        subprocess.run(["make", "-C", os.path.join(root, "gpr_amd", "csrc"), "-j8", "lab"], capture_output=True, timeout=1800)
+    assert os.path.exists(lab), "gpr_amd/libgprhip_lab.so not built (make -C gpr_amd/csrc lab)"
     n, d = 4000, 5
-    X, y, Z = synth(900 + m, n, m, d)
-    kw = dict(log_ell=0.5 * np.log(d), log_sf2=0.1, sigma2=0.05, inducing=Z)
+    code = (
+        "import sys, numpy as np\n"
+        "sys.path.insert(0, %r)\n"
+        "import torch, gpr_amd\n"
+        "from tests.util import synth\n"
+        "n, m, d = %d, %d, %d\n"
+        "X, y, Z = synth(900 + m, n, m, d)\n"
+        "p = gpr_amd.Problem(gpr_amd.COV_SE_ISO, n, d, d, m)\n"
+        "p.set_inputs(X); p.set_targets(y)\n"
+        "ev = p.eval(log_ell=0.5 * np.log(d), log_sf2=0.1, sigma2=0.05, inducing=Z)\n"
+        "assert gpr_amd._lib.LIB_PATH.endswith(sys.argv[2]), gpr_amd._lib.LIB_PATH\n"
+        "np.savez(sys.argv[1], l=ev.l, ds2=ev.dl_dsigma2, grad=ev.grad, coeffs=ev.coeffs)\n") % (root, n, m, d)
     res = {}
-    for tag, env in (("default", {}), ("chain", {"GPRHIP_POTRF_CHAIN": "1"}), ("lookahead", {"GPRHIP_POTRF_LOOKAHEAD": "1"})):
-        for k, v in env.items():
-            monkeypatch.setenv(k, v)
-        p = gpr_amd.Problem(gpr_amd.COV_SE_ISO, n, d, d, m)
-        p.set_inputs(X)
-        p.set_targets(y)
-        res[tag] = p.eval(**kw)
-        p.close()
-        for k in env:
-            monkeypatch.delenv(k)
-    ref = O.evaluate_fast(O.SeIsoKernel(kw["log_ell"], kw["log_sf2"]), Z, X, y, kw["sigma2"])
-    assert M.rel_ok("l", res["default"].l, ref["l"], TOL_L)
-    for tag in ("chain", "lookahead"):
-        assert res[tag].l == res["default"].l and res[tag].dl_dsigma2 == res["default"].dl_dsigma2, tag
-        assert np.array_equal(res[tag].grad, res["default"].grad) and np.array_equal(res[tag].coeffs, res["default"].coeffs), tag
+    for tag, env in (("production", {}), ("lab", {"GPRHIP_LIBRARY": "lab"}),
+                     ("chain", {"GPRHIP_LIBRARY": "lab", "GPRHIP_POTRF_CHAIN": "1"}),
+                     ("lookahead", {"GPRHIP_LIBRARY": "lab", "GPRHIP_POTRF_LOOKAHEAD": "1"}),
+                     ("ignored", {"GPRHIP_POTRF_CHAIN": "1", "GPRHIP_POTRF_LOOKAHEAD": "1", "GPRHIP_COV_OVERLAP": "1"})):
+        out_file = str(tmp_path / (tag + ".npz"))
+        want = "libgprhip_lab.so" if env.get("GPRHIP_LIBRARY") == "lab" else "libgprhip.so"
+        run = subprocess.run([sys.executable, "-c", code, out_file, want], capture_output=True, text=True, timeout=600,
+                             env=dict({k: v for k, v in os.environ.items() if not k.startswith("GPRHIP_")}, **env))
+        assert run.returncode == 0, (tag, run.stderr[-1500:])
+        res[tag] = np.load(out_file)
+    X, y, Z = synth(900 + m, n, m, d)
+    ref = O.evaluate_fast(O.SeIsoKernel(0.5 * np.log(d), 0.1), Z, X, y, 0.05)
+    assert M.rel_ok("l", float(res["production"]["l"]), ref["l"], TOL_L)
+    for tag in ("lab", "chain", "lookahead", "ignored"):
+        assert res[tag]["l"] == res["production"]["l"] and res[tag]["ds2"] == res["production"]["ds2"], tag
+        assert np.array_equal(res[tag]["grad"], res["production"]["grad"]), tag
+        assert np.array_equal(res[tag]["coeffs"], res["production"]["coeffs"]), tag
 
 
 @pytest.mark.parametrize("n,m,d,log_ell,tol", [(2630, 176, 1, -0.0496, 3e-7), (2034, 432, 1, -0.1, 3e-7),

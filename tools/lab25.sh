@@ -1,4 +1,5 @@
 #!/bin/bash
+export GPRHIP_LIBRARY=lab  # (the round barrier lives in the lab build since round 6: make -C gpr_amd/csrc lab)
 # Round 5: fabric traffic (FETCH_SIZE) of config 3's fp32 launches with the round barrier off / on (tools/lab24.sh times them).
 #   usage (GPU box, repo root): bash tools/lab25.sh
 set -u
