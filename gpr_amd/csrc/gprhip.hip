@@ -145,6 +145,7 @@ struct gprhip_problem {
   // GPRHIP_MID_PATH=0 (read at creation): never take the one-kernel passes for 65 .. 128 inducing points (mid.hip)
   int mid_path = 1;
   double* mid_part = nullptr;    // their per-workgroup partial sums (allocated at first use)
+  int* mid_done = nullptr;       // arrival counter of their last finish launch (its last workgroup ships the results)
   double* small_part = nullptr;  // their per-workgroup partial sums (allocated at first use)
   double* small_k = nullptr;     // K_nm [rows_p][64] of the small pass 1, read back by the small pass 2
   bool small_k_valid = false;    // ... of the current kernel parameters and inducing points (as have_v)
@@ -1239,19 +1240,18 @@ void do_finish_enqueue(gprhip_problem* p, const double* ar2, bool light = false)
     a.wmat = p->wmat; a.kmred = p->kmred; a.wdiag = wdiag ? p->wdiag : nullptr;
     a.ybuf = p->kj;  // (free after the factorisation of K_m)
     a.gather_from = ar2_col; a.n_gather = n_a2; a.ex = p->ex_dev + A1_TAIL;
+    // the kernels' last workgroup writes the result block (and, two tiles, the exchange-1 tail) into the pinned mirror itself
+    if (!p->mid_done) {
+      p->mid_done = p->alloc<int>(1);
+      GPR_HIP(hipMemsetAsync(p->mid_done, 0, sizeof(int), s));
+    }
+    a.res_dev = p->res_dev; a.res_host = p->res_host; a.res_total = p->res_len + A1_TAIL + n_a2; a.done_ctr = p->mid_done;
+    if (!p->a1_in_scal) {  // (two tiles: the B~ phase is not the fused single-block kernel that leaves the tail in the result block)
+      a.a1_tail = p->ar1 + packed_upper_len(mp) + mp;
+      a.a1_host = p->ex_host;
+    }
     launch_mid_finish(a, s);
     tstop(p);
-    {  // (in pieces of at most 32 KB: above that the runtime hands a device-to-host copy to a DMA engine, whose start costs
-       //  ~17 us on this platform where the copy kernel it uses for small transfers takes 2-4 -- timeline at m = 256)
-      const int64_t total = p->res_len + A1_TAIL + n_a2, piece = 4096;
-      for (int64_t o = 0; o < total; o += piece)
-        GPR_HIP(hipMemcpyAsync(p->res_host + o, p->res_dev + o, (size_t)std::min(piece, total - o) * sizeof(double),
-                               hipMemcpyDeviceToHost, s));
-    }
-    // (two tiles: the B~ phase is not the fused single-block kernel that copies the exchange-1 tail into the result block)
-    if (!p->a1_in_scal)
-      GPR_HIP(hipMemcpyAsync(p->ex_host, p->ar1 + packed_upper_len(mp) + mp, A1_TAIL * sizeof(double),
-                             hipMemcpyDeviceToHost, s));
     return;
   }
   if (p->want_grad) {

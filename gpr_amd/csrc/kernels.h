@@ -323,7 +323,15 @@ struct MidFinishArgs {
   const double* g;                   // packed upper tiles of the reduced exchange-2 buffer: G~ = V^T diag(v) V
   int m, mp, d, km_rows;                 // km_rows: rows of kmred to write (0: sum W.*K, 1: sum W.*K.*dist, 2+k: per dimension)
   double *wmat, *kmred, *wdiag;      // out (wdiag may be null)
-  double* ybuf;                      // 128 x 128 scratch: Y = W~ U^-T between the two launches
+  double* ybuf;                      // mp x mp scratch: Y = W~ U^-T between the two launches
+  // result transfer from inside the second launch (null res_host: the caller copies): res_total doubles res_dev -> res_host
+  // (pinned, device-addressable), four doubles a1_tail -> a1_host (or null), done_ctr a zeroed device int
+  const double* res_dev = nullptr;
+  double* res_host = nullptr;
+  int64_t res_total = 0;
+  const double* a1_tail = nullptr;
+  double* a1_host = nullptr;
+  int* done_ctr = nullptr;
   const double* gather_from;         // n_gather doubles copied to ex (the exchange-2 tail behind the result block)
   int64_t n_gather;
   double* ex;

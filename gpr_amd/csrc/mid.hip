@@ -256,10 +256,21 @@ __device__ __forceinline__ void store_gram(double* part, const sd4 (&acc)[9], in
   }
 }
 
-// sum_g part[g * stride] over the workgroups' partials, in order, sixteen loads in flight at a time
+// sum_g part[g * stride] over the workgroups' partials, in order; sixty-four loads in flight at a time from 64 partials on
+// (a batch is one memory round trip: with sixteen per batch 256 partials were sixteen dependent round trips, 26 us of a
+// reduction whose ten workgroups do nothing else -- timeline at n = 10 000, m = 256), sixteen below that.  Same order of
+// additions either way.
 __device__ __forceinline__ double sum_parts(const double* __restrict__ part, int64_t stride, int ng) {
   double acc = 0.0;
-  for (int g0 = 0; g0 < ng; g0 += 16) {
+  int g0 = 0;
+  for (; g0 + 64 <= ng; g0 += 64) {
+    double v[64];
+#pragma unroll
+    for (int j = 0; j < 64; ++j) v[j] = part[(int64_t)(g0 + j) * stride];
+#pragma unroll
+    for (int j = 0; j < 64; ++j) acc += v[j];
+  }
+  for (; g0 < ng; g0 += 16) {
     double v[16];
 #pragma unroll
     for (int j = 0; j < 16; ++j) v[j] = (g0 + j < ng) ? part[(int64_t)(g0 + j) * stride] : 0.0;
@@ -920,6 +931,24 @@ __global__ __launch_bounds__(256) void mid_finish2_kernel(MidFinishArgs a) {
       if (k < d) a.kmred[(int64_t)(2 + k) * MP + crow] = g[k];
     for (int q = 2 + d; q < a.km_rows; ++q) a.kmred[(int64_t)q * MP + crow] = 0.0;
     if (a.wdiag) a.wdiag[crow] = Urow[ti * MLD + crow];
+  }
+  // The result block goes to the host from HERE: the workgroup that finishes last copies it into the pinned mirror (which the
+  // device addresses directly), instead of one or two copy launches behind the kernel -- 4 us at one tile, and at two tiles
+  // (43 KB) a 17 us gap in front of them besides (profiles/r06_timeline_n2560_m256.txt).  Writers fence at agent scope before
+  // they count themselves in (the XCDs' L2s are not coherent with each other), the last one fences again before it reads.
+  if (a.res_host) {
+    __shared__ int is_last;
+    __threadfence();
+    __syncthreads();
+    if (tid == 0) is_last = atomicAdd(a.done_ctr, 1) == (int)gridDim.x - 1;
+    __syncthreads();
+    if (is_last) {
+      __threadfence();
+      for (int64_t i = tid; i < a.res_total; i += 256) a.res_host[i] = __builtin_nontemporal_load(a.res_dev + i);
+      __syncthreads();  // (a1_host lies inside the block just copied: behind it)
+      if (a.a1_tail && tid < 4) a.a1_host[tid] = a.a1_tail[tid];
+      if (tid == 0) *a.done_ctr = 0;  // (for the next evaluation; stream order separates the launches)
+    }
   }
 }
 

@@ -92,10 +92,21 @@ __device__ __forceinline__ void gram_update(const double* T, const double* wt, i
   }
 }
 
-// sum_g part[g * stride] over the workgroups' partials, in order, sixteen loads in flight at a time
+// sum_g part[g * stride] over the workgroups' partials, in order; sixty-four loads in flight at a time from 64 partials on
+// (a batch is one memory round trip: with sixteen per batch 256 partials were sixteen dependent round trips, 26 us of a
+// reduction whose ten workgroups do nothing else -- timeline at n = 10 000, m = 256), sixteen below that.  Same order of
+// additions either way.
 __device__ __forceinline__ double sum_parts(const double* __restrict__ part, int64_t stride, int ng) {
   double acc = 0.0;
-  for (int g0 = 0; g0 < ng; g0 += 16) {
+  int g0 = 0;
+  for (; g0 + 64 <= ng; g0 += 64) {
+    double v[64];
+#pragma unroll
+    for (int j = 0; j < 64; ++j) v[j] = part[(int64_t)(g0 + j) * stride];
+#pragma unroll
+    for (int j = 0; j < 64; ++j) acc += v[j];
+  }
+  for (; g0 < ng; g0 += 16) {
     double v[16];
 #pragma unroll
     for (int j = 0; j < 16; ++j) v[j] = (g0 + j < ng) ? part[(int64_t)(g0 + j) * stride] : 0.0;
