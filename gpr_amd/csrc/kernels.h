@@ -336,6 +336,7 @@ struct MidFinishArgs {
   int64_t n_gather;
   double* ex;
 };
+constexpr int64_t MID_ROWS_TWO_TILES = 32768;  // most rows of a shard the two-tile kernels take (mid.hip: mid_path_fits)
 bool mid_path_fits(int m, int mp, int d, int D, int64_t rows, bool ms);
 int64_t mid_part_len(int mp, int d, int D);
 void launch_mid_pass1(const MidPass1Args& a, double* tile, double* cvec, double* tail, hipStream_t s);

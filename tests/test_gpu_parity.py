@@ -1899,6 +1899,35 @@ def test_row_path_thresholds_agree_with_their_neighbours(m, monkeypatch):
 
 
 @pytest.mark.gpu
+def test_shards_on_both_sides_of_the_two_tile_row_limit():
+    """mid.hip's two-tile kernels take shards of at most 32768 rows (gpr_amd/csrc/kernels.h: MID_ROWS_TWO_TILES; the engine
+    is faster above).  65537 rows over two shards: 32769 go through the engine, 32768 through mid.hip, both into the same
+    exchange buffers -- the sums and the finish do not know which family filled them."""
+    n, m, d = 2 * 32768 + 1, 200, 4
+    X, y, Z = synth(77, n, m, d)
+    hyp = dict(log_ell=0.5 * np.log(d), log_sf2=0.05, sigma2=0.15, inducing=Z)
+    ref = O.evaluate(O.SeIsoKernel(hyp["log_ell"], hyp["log_sf2"]), Z, X, y, hyp["sigma2"])
+    fams = M.families("iso", d, m)
+    ctx = gpr_amd.Context([0, 0])
+    sp = gpr_amd.ShardedDeviceProblem(ctx, gpr_amd.COV_SE_ISO, n, d, d, m)
+    sp.set_inputs(X)
+    sp.set_targets(y)
+    for i in range(2):
+        sp.problem(i).set_timing(2)
+    ev = sp.eval(**hyp)
+    taken = []
+    for i in range(2):
+        stages = set(sp.problem(i).last_timings())
+        taken.append((sp.shard(i)[2] - sp.shard(i)[1], "mid" if "p1_mid" in stages else "engine"))
+    cond = sp.problem(0).condition()[0]
+    sp.close()
+    ctx.close()
+    assert taken == [(32769, "engine"), (32768, "mid")], taken
+    assert M.rel_ok("l", ev.l, ref["l"], TOL_L) and M.rel_ok("dl_dsigma2", ev.dl_dsigma2, ref["dl_dsigma2"], TOL_DS2)
+    assert M.grad_ok(ev.grad, ref["grad"], fams, TOL_GRAD, cond=cond) and M.vec_ok("coeffs", ev.coeffs, ref["coeffs"], TOL_COEFF)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("seed", range(3100, 3106))
 def test_random_small_shapes_through_the_context(seed):
     """... and through the single-process multi-device entry: the small passes write the same exchange buffers the
