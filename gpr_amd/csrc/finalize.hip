@@ -144,21 +144,35 @@ __global__ __launch_bounds__(256) void km_traces_kernel(const double* __restrict
   double s0 = 0.0, s1 = 0.0;
   const int r0 = blockIdx.y * KM_SLAB, r1 = min(m, r0 + KM_SLAB);
   if (live) {
-    for (int r = r0; r < r1; ++r) {
-      // upper tiles of km are the valid ones; km is written full by cov_upper, W full by build_w
-      const double wk = W[(int64_t)r * mp + c] * km[(int64_t)r * mp + c];
-      const double* zr = Z + (int64_t)r * d;
-      double dist = 0.0;
+    // eight rows' W and K_m entries are loaded before any is used (round 6): one load round trip per eight rows instead of
+    // one per row -- with 32 rows per thread the kernel was 32 dependent round trips long (32 us at every m), now four.
+    // The sums take the rows in the same order as before.
+    for (int rb = r0; rb < r1; rb += 8) {
+      double wv[8], kv[8];
 #pragma unroll
-      for (int k = 0; k < DT; ++k) {
-        if (k < d) {
-          const double df = zr[k] - z[k];
-          dist += df * df;
-          g[k] += wk * df;
+      for (int u = 0; u < 8; ++u) {
+        const int r = min(rb + u, r1 - 1);
+        wv[u] = W[(int64_t)r * mp + c];  // upper tiles of km are the valid ones; km is written full by cov_upper, W full by build_w
+        kv[u] = km[(int64_t)r * mp + c];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        if (rb + u < r1) {
+          const double wk = wv[u] * kv[u];
+          const double* zr = Z + (int64_t)(rb + u) * d;
+          double dist = 0.0;
+#pragma unroll
+          for (int k = 0; k < DT; ++k) {
+            if (k < d) {
+              const double df = zr[k] - z[k];
+              dist += df * df;
+              g[k] += wk * df;
+            }
+          }
+          s0 += wk;
+          s1 += wk * dist;
         }
       }
-      s0 += wk;
-      s1 += wk * dist;
     }
   }
   double* p = part + (int64_t)blockIdx.y * (d + 2) * mp;
@@ -230,19 +244,33 @@ __global__ __launch_bounds__(256) void km_traces_ms_kernel(const double* __restr
   double s0 = 0.0;
   const int r0 = blockIdx.y * KM_SLAB, r1 = min(m, r0 + KM_SLAB);
   if (live) {
-    for (int r = r0; r < r1; ++r) {
-      const double wk = W[(int64_t)r * mp + c] * km[(int64_t)r * mp + c];
-      s0 += wk;
-      if (r == c) continue;
-      const double* zr = Z + (int64_t)r * d;
-      const double* msr = ms + (int64_t)r * d;
+    for (int rb = r0; rb < r1; rb += 8) {  // (loads of eight rows ahead of their use, as in km_traces_kernel)
+      double wv[8], kv[8];
 #pragma unroll
-      for (int k = 0; k < DT; ++k) {
-        if (k < d) {
-          const double iscale = 1.0 / ((msr[k] + msc[k]) - 1.0);
-          const double sdiff = (zr[k] - z[k]) * iscale;
-          g[k] += wk * sdiff;
-          gm[k] += wk * (iscale - sdiff * sdiff);
+      for (int u = 0; u < 8; ++u) {
+        const int r = min(rb + u, r1 - 1);
+        wv[u] = W[(int64_t)r * mp + c];
+        kv[u] = km[(int64_t)r * mp + c];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int r = rb + u;
+        if (r < r1) {
+          const double wk = wv[u] * kv[u];
+          s0 += wk;
+          if (r != c) {
+            const double* zr = Z + (int64_t)r * d;
+            const double* msr = ms + (int64_t)r * d;
+#pragma unroll
+            for (int k = 0; k < DT; ++k) {
+              if (k < d) {
+                const double iscale = 1.0 / ((msr[k] + msc[k]) - 1.0);
+                const double sdiff = (zr[k] - z[k]) * iscale;
+                g[k] += wk * sdiff;
+                gm[k] += wk * (iscale - sdiff * sdiff);
+              }
+            }
+          }
         }
       }
     }
@@ -297,6 +325,29 @@ void launch_km_traces(const double* W, const double* km, const double* Z, int m,
   else if (d <= 16) go(std::integral_constant<int, 16>{});
   else if (d <= 32) go(std::integral_constant<int, 32>{});
   else go(std::integral_constant<int, 64>{});
+  GPR_HIP(hipGetLastError());
+}
+
+// The results' way home.  Up to three blocks of doubles (result block, exchange-1 tail, exchange-2 buffer from its column
+// block on) written into the pinned host mirror by a kernel instead of by hipMemcpyAsync: behind a kernel a device-to-host
+// copy of more than 32 KB (or a second and third one) starts 17-18 us late on this runtime (profiles/r06_timeline_*), a
+// kernel starts at once, and a few workgroups storing over the host link move these 40-600 KB as fast as the copy engine.
+__global__ __launch_bounds__(256) void ship_kernel(ShipArgs a) {
+  const int64_t stride = (int64_t)gridDim.x * 256;
+#pragma unroll
+  for (int b = 0; b < 3; ++b) {
+    const double* __restrict__ src = a.src[b];
+    double* __restrict__ dst = a.dst[b];
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < a.n[b]; i += stride)
+      __builtin_nontemporal_store(__builtin_nontemporal_load(src + i), dst + i);
+  }
+}
+
+void launch_ship(const ShipArgs& a, hipStream_t s) {
+  const int64_t total = a.n[0] + a.n[1] + a.n[2];
+  if (total <= 0) return;
+  const int grid = (int)std::min<int64_t>(32, (std::max(a.n[0], std::max(a.n[1], a.n[2])) + 2047) / 2048);
+  hipLaunchKernelGGL(ship_kernel, dim3(std::max(grid, 1)), dim3(256), 0, s, a);
   GPR_HIP(hipGetLastError());
 }
 

@@ -1281,13 +1281,16 @@ void do_finish_enqueue(gprhip_problem* p, const double* ar2, bool light = false)
   // diag-W parts only after a gradient evaluation), the scalar tail of the reduced exchange-1 buffer (kept in p->ar1 by
   // pass 2), and the exchange-2 buffer from its column block on (its scalar tail only after an evidence-only evaluation)
   const int64_t res_used = NSCAL + 2 + mp + (p->want_grad ? p->km_rows() * mp + (wdiag ? mp : 0) : 0);
-  GPR_HIP(hipMemcpyAsync(p->res_host, p->res_dev, (size_t)res_used * sizeof(double), hipMemcpyDeviceToHost, s));
-  if (!p->a1_in_scal)
-    GPR_HIP(hipMemcpyAsync(p->ex_host, p->ar1 + packed_upper_len(mp) + mp, A1_TAIL * sizeof(double),
-                           hipMemcpyDeviceToHost, s));
-  // (an evidence-only evaluation reads nothing of the exchange-2 buffer)
-  if (p->want_grad)
-    GPR_HIP(hipMemcpyAsync(p->ex_host + A1_TAIL, ar2_col, (size_t)n_a2 * sizeof(double), hipMemcpyDeviceToHost, s));
+  // -- by one launch of ship_kernel (finalize.hip): three hipMemcpyAsync calls cost 17-18 us of idle stream before them
+  ShipArgs sh;
+  sh.src[0] = p->res_dev; sh.dst[0] = p->res_host; sh.n[0] = res_used;
+  if (!p->a1_in_scal) {
+    sh.src[1] = p->ar1 + packed_upper_len(mp) + mp; sh.dst[1] = p->ex_host; sh.n[1] = A1_TAIL;
+  }
+  if (p->want_grad) {  // (an evidence-only evaluation reads nothing of the exchange-2 buffer)
+    sh.src[2] = ar2_col; sh.dst[2] = p->ex_host + A1_TAIL; sh.n[2] = n_a2;
+  }
+  launch_ship(sh, s);
 }
 
 // Finish stage, second half: wait for the stream, check the factorisations, assemble l1, l2, dl/dsigma2 and the gradient
@@ -2085,7 +2088,7 @@ int gprhip_problem_create_ex(int device, int cov_kind, int precision, int64_t n,
       p->kmred = p->tvec + mp;
       p->wdiag = p->kmred + p->km_rows() * mp;
       GPR_HIP(hipHostMalloc(reinterpret_cast<void**>(&p->res_host), (size_t)(p->res_len + p->ex_len) * sizeof(double),
-                            hipHostMallocDefault));
+                            hipHostMallocPortable | hipHostMallocMapped));  // (kernels of this device write into it)
       p->ex_host = p->res_host + p->res_len;
     }
     p->r = p->alloc<double>(npad); p->is = p->alloc<double>(npad); p->yis = p->alloc<double>(npad);

@@ -232,6 +232,13 @@ void launch_sum_slices(const double* base, const TS* slices, int nslices, int64_
 void launch_to_float(const double* src, float* dst, int64_t n, hipStream_t s);
 // W~ = I - B~^-1 - t~ t~^T - G~ as a full symmetric matrix (inputs valid on upper tiles);
 // the reference's W (lib/fitc_gp.ml:1196-1203) is U^-1 W~ U^-T.
+// up to three device blocks into (device-visible) pinned host memory by a kernel (finalize.hip)
+struct ShipArgs {
+  const double* src[3] = {nullptr, nullptr, nullptr};
+  double* dst[3] = {nullptr, nullptr, nullptr};
+  int64_t n[3] = {0, 0, 0};
+};
+void launch_ship(const ShipArgs& a, hipStream_t s);
 void launch_build_w(const double* binv, const double* t, const double* G, int mp, double* W,
                     hipStream_t s);
 // Trace terms of W against K_m and its derivatives (lib/fitc_gp.ml:956-973, lib/utils.ml:196-220),
