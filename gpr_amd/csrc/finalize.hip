@@ -124,14 +124,15 @@ void launch_build_w(const double* binv, const double* t, const double* G, int mp
 // W and K_m are full symmetric here, so the reference's upper-triangle bookkeeping
 // (lib/utils.ml:196-220: 2*sum_{r != c} + diagonal) becomes a plain column sum.
 // rows of W .* K_m one block walks: short slabs, so that the m x m pass spreads over the whole chip
-constexpr int KM_SLAB = 32;
-int km_slab_rows() { return KM_SLAB; }
+// (round 6: 8 rows up to 1024 inducing points -- one batch of loads per thread, four times the workgroups; the partial
+// buffer, km_rows x mp doubles per slab, stays below 11 MB)
+int km_slab_rows(int m) { return m <= 1024 ? 8 : 32; }
 
 template <int DT>
 __global__ __launch_bounds__(256) void km_traces_kernel(const double* __restrict__ W,
                                                         const double* __restrict__ km,
                                                         const double* __restrict__ Z, int m, int mp,
-                                                        int d, double* __restrict__ part) {
+                                                        int d, double* __restrict__ part, int slab) {
   const int c = blockIdx.x * 256 + threadIdx.x;
   if (c >= mp) return;
   const bool live = c < m;
@@ -142,7 +143,7 @@ __global__ __launch_bounds__(256) void km_traces_kernel(const double* __restrict
     g[k] = 0.0;
   }
   double s0 = 0.0, s1 = 0.0;
-  const int r0 = blockIdx.y * KM_SLAB, r1 = min(m, r0 + KM_SLAB);
+  const int r0 = blockIdx.y * slab, r1 = min(m, r0 + slab);
   if (live) {
     // eight rows' W and K_m entries are loaded before any is used (round 6): one load round trip per eight rows instead of
     // one per row -- with 32 rows per thread the kernel was 32 dependent round trips long (32 us at every m), now four.
@@ -189,7 +190,7 @@ __global__ __launch_bounds__(256) void km_traces_wide_kernel(const double* __res
                                                              const double* __restrict__ km,
                                                              const double* __restrict__ Z, int m, int mp, int d,
                                                              double log_sf2, double inv_ell2_05,
-                                                             double* __restrict__ part) {
+                                                             double* __restrict__ part, int slab) {
   const int c = blockIdx.x * 256 + threadIdx.x;
   if (c >= mp) return;
   const bool live = c < m;
@@ -201,7 +202,7 @@ __global__ __launch_bounds__(256) void km_traces_wide_kernel(const double* __res
     g[k] = 0.0;
   }
   double s0 = 0.0, s1 = 0.0;
-  const int r0 = blockIdx.y * KM_SLAB, r1 = min(m, r0 + KM_SLAB);
+  const int r0 = blockIdx.y * slab, r1 = min(m, r0 + slab);
   if (live) {
     for (int r = r0; r < r1; ++r) {
       const double kv = km[(int64_t)r * mp + c];
@@ -229,7 +230,7 @@ __global__ __launch_bounds__(256) void km_traces_ms_kernel(const double* __restr
                                                            const double* __restrict__ km,
                                                            const double* __restrict__ Z,
                                                            const double* __restrict__ ms, int m, int mp, int d,
-                                                           double* __restrict__ part) {
+                                                           double* __restrict__ part, int slab) {
   const int c = blockIdx.x * 256 + threadIdx.x;
   if (c >= mp) return;
   const bool live = c < m;
@@ -242,7 +243,7 @@ __global__ __launch_bounds__(256) void km_traces_ms_kernel(const double* __restr
     gm[k] = 0.0;
   }
   double s0 = 0.0;
-  const int r0 = blockIdx.y * KM_SLAB, r1 = min(m, r0 + KM_SLAB);
+  const int r0 = blockIdx.y * slab, r1 = min(m, r0 + slab);
   if (live) {
     for (int rb = r0; rb < r1; rb += 8) {  // (loads of eight rows ahead of their use, as in km_traces_kernel)
       double wv[8], kv[8];
@@ -293,10 +294,11 @@ void launch_km_traces_ms(const double* W, const double* km, const double* Z, con
     set_error("gprhip: Cov_se_fat multiscales support kernel-space dimension d <= 64");
     throw HipFail{ST_BAD_ARG};
   }
-  dim3 grid((mp + 255) / 256, (m + KM_SLAB - 1) / KM_SLAB);
+  const int slab = km_slab_rows(m);
+  dim3 grid((mp + 255) / 256, (m + slab - 1) / slab);
   auto go = [&](auto dt) {
     hipLaunchKernelGGL((km_traces_ms_kernel<decltype(dt)::value>), grid, dim3(256), 0, s, W, km, Z, ms, m, mp,
-                       d, part);
+                       d, part, slab);
   };
   if (d <= 4) go(std::integral_constant<int, 4>{});
   else if (d <= 8) go(std::integral_constant<int, 8>{});
@@ -308,17 +310,18 @@ void launch_km_traces_ms(const double* W, const double* km, const double* Z, con
 
 void launch_km_traces(const double* W, const double* km, const double* Z, int m, int mp, int d,
                       double* part, const CovParams& cp, hipStream_t s) {
-  dim3 grid((mp + 255) / 256, (m + KM_SLAB - 1) / KM_SLAB);
+  const int slab = km_slab_rows(m);
+  dim3 grid((mp + 255) / 256, (m + slab - 1) / slab);
   if (d > 64) {
     grid.z = (d + 31) / 32;
     hipLaunchKernelGGL(km_traces_wide_kernel, grid, dim3(256), 0, s, W, km, Z, m, mp, d, cp.log_sf2, cp.inv_ell2_05,
-                       part);
+                       part, slab);
     GPR_HIP(hipGetLastError());
     return;
   }
   auto go = [&](auto dt) {
     hipLaunchKernelGGL((km_traces_kernel<decltype(dt)::value>), grid, dim3(256), 0, s, W, km, Z, m, mp,
-                       d, part);
+                       d, part, slab);
   };
   if (d <= 4) go(std::integral_constant<int, 4>{});
   else if (d <= 8) go(std::integral_constant<int, 8>{});

@@ -668,7 +668,7 @@ void memory_plan(int cov_kind, int precision, int64_t n, int D, int d, int m, in
   const int64_t nslab = (z.chunk + gslab - 1) / gslab;
   o->rest = (gprhip_exchange_len(cov_kind, D, d, m, 1) + gprhip_exchange_len(cov_kind, D, d, m, 2)) * 8 +
             nslab * col_rows * mp * 8 + (fat ? ((z.chunk + 255) / 256) * (int64_t)D * d * 8 : 0) +
-            (int64_t)((m + km_slab_rows() - 1) / km_slab_rows()) * km_rows * mp * 8 + (int64_t)(8 + km_rows + col_rows) * mp * 8;
+            (int64_t)((m + km_slab_rows(m) - 1) / km_slab_rows(m)) * km_rows * mp * 8 + (int64_t)(8 + km_rows + col_rows) * mp * 8;
   o->total = o->inputs + o->row_vectors + o->v_store + o->chunk_buffers + o->slices + o->mxm + o->rest;
 }
 
@@ -1205,7 +1205,7 @@ void do_finish_enqueue(gprhip_problem* p, const double* ar2, bool light = false)
   const double* ar2_col = ar2 + packed_upper_len(mp);
   const double* ar2_proj = ar2_col + p->col_rows() * mp;
   const double* ar2_tail = ar2_proj + (int64_t)p->dbig() * d;
-  const int nkslab = (m + km_slab_rows() - 1) / km_slab_rows();
+  const int nkslab = (m + km_slab_rows(m) - 1) / km_slab_rows(m);
   p->stage = 3;
   if (light) {
     GPR_HIP(hipMemcpyAsync(p->res_host + NSCAL, p->info, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
@@ -2114,7 +2114,7 @@ int gprhip_problem_create_ex(int device, int cov_kind, int precision, int64_t n,
     const int64_t nslab = (chunk + gslab - 1) / gslab;
     p->colpart = p->alloc<double>(nslab * p->col_rows() * mp);
     p->scalpart = p->alloc<double>(nslab * (mp / TILE) * 2);
-    p->kmpart = p->alloc<double>((int64_t)((m + km_slab_rows() - 1) / km_slab_rows()) * p->km_rows() * mp);
+    p->kmpart = p->alloc<double>((int64_t)((m + km_slab_rows(m) - 1) / km_slab_rows(m)) * p->km_rows() * mp);
     p->ar1 = p->alloc<double>(gprhip_ar1_len(p));
     p->ar2 = p->alloc<double>(gprhip_ar2_len(p));
     {

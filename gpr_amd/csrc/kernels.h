@@ -243,7 +243,7 @@ void launch_build_w(const double* binv, const double* t, const double* G, int mp
                     hipStream_t s);
 // Trace terms of W against K_m and its derivatives (lib/fitc_gp.ml:956-973, lib/utils.ml:196-220),
 // as per-column partial sums over slabs of 256 rows: part[slab][q][c], q = 0: sum_r W_rc K_rc,
-int km_slab_rows();  // rows per slab of the km_traces partial buffers
+int km_slab_rows(int m);  // rows per slab of the km_traces partial buffers
 // q = 1: sum_r W_rc K_rc |z_r - z_c|^2, q = 2+k: sum_r W_rc K_rc (z_kr - z_kc).  W, km full symmetric.
 void launch_km_traces(const double* W, const double* km, const double* Z, int m, int mp, int d,
                       double* part, const CovParams& cp, hipStream_t s);
