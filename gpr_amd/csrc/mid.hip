@@ -1014,7 +1014,7 @@ bool mid_path_fits(int m, int mp, int d, int D, int64_t rows, bool ms) {
   // (D: input dimensions in front of a projection, 0 without one; the moment matrix [1 | p | x_big] has at most two 16-row
   //  tiles -- the two row-block tiles of pass 2 leave 30 KB of the LDS for it and the row vectors)
   // Rows of the shard: these kernels are built for latency (one 64- or 32-row batch per workgroup, operands streamed from
-  // L2), the engine for throughput.  Measured crossovers (gradient evaluation, d = 8, profiles/r06_latency.txt): one tile
+  // L2), the engine for throughput.  Measured crossovers (gradient evaluation, d = 8, profiles/r06_latency_mid_vs_engine.txt): one tile
   // -- level with the engine at 10^6 rows (4.84 / 4.77 ms; evidence alone 1.45 / 1.80), ahead below (3 * 10^5: 1.64 /
   // 2.43); two tiles -- ahead to ~4 * 10^4 rows (3 * 10^4: 0.82 / 0.87), behind above (10^5: 1.74 / 1.48, 10^6: 13.6 /
   // 10.7).  Shards of one problem may fall on either side: both families fill the same exchange buffers.
