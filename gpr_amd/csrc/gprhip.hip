@@ -1225,8 +1225,14 @@ void do_finish_enqueue(gprhip_problem* p, const double* ar2, bool light = false)
     a.gather_from = ar2_col; a.n_gather = n_a2; a.ex = p->ex_dev + A1_TAIL;
     launch_small_finish(a, s);
     tstop(p);
-    GPR_HIP(hipMemcpyAsync(p->res_host, p->res_dev, (size_t)(p->res_len + A1_TAIL + n_a2) * sizeof(double),
-                           hipMemcpyDeviceToHost, s));
+    const int64_t n_res = p->res_len + A1_TAIL + n_a2;
+    if (n_res * (int64_t)sizeof(double) > 32768) {  // (d > 8 or so: above 32 KB a copy starts 17 us late, a kernel at once)
+      ShipArgs sh;
+      sh.src[0] = p->res_dev; sh.dst[0] = p->res_host; sh.n[0] = n_res;
+      launch_ship(sh, s);
+    } else {
+      GPR_HIP(hipMemcpyAsync(p->res_host, p->res_dev, (size_t)n_res * sizeof(double), hipMemcpyDeviceToHost, s));
+    }
     return;
   }
   if (p->want_grad && p->use_mid()) {
