@@ -145,6 +145,8 @@ struct gprhip_problem {
   // GPRHIP_MID_PATH=0 (read at creation): never take the one-kernel passes for 65 .. 128 inducing points (mid.hip)
   int mid_path = 1;
   double* mid_part = nullptr;    // their per-workgroup partial sums (allocated at first use)
+  int mid_gram = 1;              // GPRHIP_MID_GRAM: two tiles -- the Gram accumulations by mid.hip's own launch pair (0: the engine's)
+  double* mid_gram_part = nullptr;  // its per-slice partial tiles (allocated at first use)
   int* mid_done = nullptr;       // arrival counter of their last finish launch (its last workgroup ships the results)
   double* small_part = nullptr;  // their per-workgroup partial sums (allocated at first use)
   double* small_k = nullptr;     // K_nm [rows_p][64] of the small pass 1, read back by the small pass 2
@@ -198,7 +200,9 @@ struct gprhip_problem {
   // Results of an evaluation come back as one block as well: [scalars (NSCAL) | potrf flags (2 ints in one double) |
   // t (mp) | K_m traces (km_rows x mp) | diag W (mp)] = res_dev -> res_host (pinned), plus the tails of the two exchange
   // buffers (ex_host: [A1_TAIL | column block .. end of the exchange-2 buffer]).
-  // ex_host / ex_dev lie directly behind the result block (one transfer can bring both)
+  // ex_host / ex_dev lie directly behind the result block (one transfer can bring both).  Since round 6 the transfer is a
+  // kernel's stores into res_host (mapped pinned memory) wherever it would exceed 32 KB or take more than one copy:
+  // ship_kernel (finalize.hip) on the engine path, the last workgroup of mid_finish2_kernel (mid.hip)
   double *res_dev = nullptr, *res_host = nullptr, *ex_host = nullptr, *ex_dev = nullptr;
   bool a1_in_scal = false;  // this evaluation's exchange-1 tail is in the result block's scalars (SC_A1TAIL)
   int64_t res_len = 0, ex_len = 0;
@@ -242,6 +246,7 @@ struct gprhip_problem {
   }
   // one or two 128-column tiles of inducing points that the small path does not take (65 .. 256 of them, or fewer with more
   // input dimensions than small.hip stages): the row passes and the finish stage of mid.hip
+  bool use_mid_gram() const { return mid_gram && n <= MID_GRAM_ROWS; }
   bool use_mid() const {
     return mid_path && !f32 && !engine_steps && !use_small() && mid_path_fits(m, mp, d, has_proj() ? D : 0, n, has_ms());
   }
@@ -804,7 +809,29 @@ void do_pass1(gprhip_problem* p, const gprhip_hypers* h, int want_grad, int64_t 
       a.V = Vstore; a.r = p->r; a.is = p->is; a.yis = p->yis; a.part = p->mid_part;
       launch_mid_pass1(a, ar1, ar1_c, ar1_tail, s);
       tstop(p);
-      if (mp == TILE) {
+      if (mp > TILE && p->use_mid_gram()) {
+        // two tiles: B~_part and c~ over the resident V by mid.hip's Gram launch pair (the engine's SYRK-shaped launch, its
+        // column-sum reduction and its slice sum cost 45 us at these sizes whatever the row count)
+        tstart(p, "p1_syrk_B");
+        if (!p->mid_gram_part) p->mid_gram_part = p->alloc<double>(mid_gram_part_len());
+        MidGramArgs ga;
+        ga.V = reinterpret_cast<const double*>(Vstore); ga.w = p->is; ga.y = p->yis; ga.rows = (int)p->n;
+        ga.part = p->mid_gram_part;
+        if (p->timer.kernel) {
+          if (!p->timer.k0) {
+            GPR_HIP(hipEventCreate(&p->timer.k0));
+            GPR_HIP(hipEventCreate(&p->timer.k1));
+          }
+          GPR_HIP(hipEventRecord(p->timer.k0, s));
+        }
+        launch_mid_gram(ga, ar1, ar1_c, s);
+        if (p->timer.kernel) {
+          GPR_HIP(hipEventRecord(p->timer.k1, s));
+          p->timer.k_recorded = true;
+        }
+        tstop(p);
+      }
+      if (mp == TILE || p->use_mid_gram()) {
         p->stage = 1;
         p->have_v = true;
         p->have_k = false;
@@ -999,7 +1026,15 @@ void do_pass2(gprhip_problem* p, const double* ar1, double* ar2) {
         }
       }
       tstop(p);
-      if (mp > TILE) {  // two tiles: G~_part = V^T diag(v) V from the engine, as below
+      if (mp > TILE && p->use_mid_gram()) {  // two tiles: G~_part = V^T diag(v) V by the Gram launch pair of mid.hip
+        tstart(p, "p2_syrk_W");
+        if (!p->mid_gram_part) p->mid_gram_part = p->alloc<double>(mid_gram_part_len());
+        MidGramArgs ga;
+        ga.V = reinterpret_cast<const double*>(Vstore); ga.w = p->v; ga.y = nullptr; ga.rows = (int)p->n;
+        ga.part = p->mid_gram_part;
+        launch_mid_gram(ga, ar2, nullptr, s);
+        tstop(p);
+      } else if (mp > TILE) {  // ... or from the engine, as below (GPRHIP_MID_GRAM=0)
         tstart(p, "p2_syrk_W");
         GemmArgsT<TS> wg;
         wg.A = Vstore; wg.lda = mp; wg.B = Vstore; wg.ldb = mp; wg.C = slices; wg.ldc = mp;
@@ -2026,6 +2061,7 @@ int gprhip_problem_create_ex(int device, int cov_kind, int precision, int64_t n,
     if (const char* e = getenv("GPRHIP_W_AS_WS")) p->w_as_ws = atoi(e);
     if (const char* e = getenv("GPRHIP_SMALL_PATH")) p->small_path = atoi(e);
     if (const char* e = getenv("GPRHIP_MID_PATH")) p->mid_path = atoi(e);
+    if (const char* e = getenv("GPRHIP_MID_GRAM")) p->mid_gram = atoi(e);
     if (const char* e = getenv("GPRHIP_F32_COEFF_TOL")) p->f32_coeff_tol = atof(e);
     if (const char* e = getenv("GPRHIP_MERGED_X")) p->merged_x_mode = atoi(e);
     if (const char* e = getenv("GPRHIP_POTRF_ENGINE")) p->engine_steps = atoi(e) != 0;

@@ -343,6 +343,7 @@ struct MidFinishArgs {
   int64_t n_gather;
   double* ex;
 };
+constexpr int64_t MID_GRAM_ROWS = 4096;  // most rows of a shard whose two-tile Gram accumulations mid.hip's own launch pair takes (mid.hip: mid_gram_kernel)
 constexpr int64_t MID_ROWS_TWO_TILES = 32768;  // most rows of a shard the two-tile kernels take (mid.hip: mid_path_fits)
 bool mid_path_fits(int m, int mp, int d, int D, int64_t rows, bool ms);
 int64_t mid_part_len(int mp, int d, int D);
@@ -350,6 +351,18 @@ void launch_mid_pass1(const MidPass1Args& a, double* tile, double* cvec, double*
 void launch_mid_pass2(const MidPass2Args& a, int col_rows, double* tile, double* colblk, double* proj, double* tail,
                       hipStream_t s);
 void launch_mid_finish(const MidFinishArgs& a, hipStream_t s);
+// Two tiles: the Gram accumulation V^T diag(w) V (upper 128-tiles, packed as the exchange buffers hold them) and, with y,
+// the weighted column sums V^T y, over a shard's resident V (rows x 256) -- mid.hip's own launch pair for shards the
+// engine's SYRK-shaped launch is too heavy for (its fixed cost is 28 us whatever the row count)
+struct MidGramArgs {
+  const double* V;                   // [rows_alloc][256]
+  const double* w;                   // row weights (1/s in pass 1, v in pass 2)
+  const double* y;                   // column-sum weights (y/s) or null
+  int rows;                          // real rows of the shard
+  double* part;                      // scratch, mid_gram_part_len() doubles
+};
+int64_t mid_gram_part_len();
+void launch_mid_gram(const MidGramArgs& a, double* tiles, double* cvec, hipStream_t s);
 void launch_mid_transposes(const double* uinv, const double* rinv, int mp, double* uinvT, double* rinvT, hipStream_t s);
 
 }  // namespace gprhip

@@ -989,6 +989,160 @@ static void mid_dispatch(int d, F&& go) {
   else go(std::integral_constant<int, 16>{});
 }
 
+// ---------------------------------------------------------------------------------------- Gram accumulation, two tiles
+// G = V^T diag(w) V on the three upper 128-tiles (0,0), (0,1), (1,1) and c = V^T y, V the shard's resident [rows][256].
+// The engine's SYRK-shaped launch does this for any size; on the few thousand rows of the reference's default regime
+// (n = 1290 .. 2560 for m = 129 .. 256) its fixed cost -- workgroup entry, LDS staging, a 128-deep first stage: 28 us -- is
+// the whole launch, and its slice sum and column-sum reduction are two more launches.  Here: workgroup (tile, row slice),
+// eight wavefronts = two halves of the slice's rows x the four 64 x 64 quadrants of the tile, 16 accumulator tiles each; both
+// operands of an MFMA are rows of V (lane (l15, lq) of k-step s reads V[k + lq][column + l15]: four 128-byte runs per load),
+// fetched straight from memory four k-steps ahead of their use; the halves meet through LDS and the slice's partial tile
+// goes to memory in the packed layout of the exchange buffers.  mid_gram_reduce_kernel sums the slices in order, 16 loads
+// in flight.  Strictly-lower 16 x 16 sub-tiles of the two diagonal tiles are written as zeros, as the engine leaves them.
+// Every wavefront fetching its own fragments is four times the L2 traffic of a staged tile, and the compiler joins the
+// waits of a round of four k-steps at its top (0.75 us per k-step once the slices are long): good for short slices only --
+// the caller uses this pair up to MID_GRAM_ROWS rows and the engine above (profiles/r06_latency_gram.txt).  (An LDS-staged
+// version, three chunks of 16 rows in flight, was built and was slower still: whatever is computed from a fetched register
+// the scheduler moves up next to its load, across the barriers, and the wait with it.)
+constexpr int GRAM_MAX_SLICES = 64;
+constexpr int GRAM_TLEN = 3 * 128 * 128;       // the three tiles of one slice
+constexpr int GRAM_PLEN = GRAM_TLEN + 256;     // ... and its column sums
+constexpr int GRAM_LD = 130;                   // LDS tile of the second half's accumulators
+constexpr int GRAM_LDS = 128 * GRAM_LD * 8 + 4 * 64 * 8;
+constexpr int GRAM_NB = 4;                     // k-steps of fragments in flight
+
+__global__ __launch_bounds__(512) void mid_gram_kernel(MidGramArgs a, int rps) {
+  extern __shared__ __attribute__((aligned(16))) double glds[];
+  double* const T = glds;                      // [128][GRAM_LD]
+  double* const cs2 = T + 128 * GRAM_LD;       // [2][64] column sums of the second half
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int l15 = lane & 15, lq = lane >> 4;
+  const int t = blockIdx.x, sl = blockIdx.y;
+  const int I0 = t == 2 ? 128 : 0, J0 = t == 0 ? 0 : 128;
+  const int g = wid >> 2, wr = (wid >> 1) & 1, wc = wid & 1;
+  const int hl = rps / 2;                                    // rows per half (a multiple of 4)
+  const int kbeg = sl * rps + g * hl, kend = min(a.rows, kbeg + hl);
+  const bool sums = a.y != nullptr && t != 1 && wc == 0;     // column sums: diagonal tiles, one wave column
+  const double* const ysrc = a.y ? a.y : a.w;
+  sd4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = sd4{0.0, 0.0, 0.0, 0.0};
+  double cs[4] = {0.0, 0.0, 0.0, 0.0};
+  const double* const Va = a.V + I0 + wr * 64 + l15;
+  const double* const Vb = a.V + J0 + wc * 64 + l15;
+  double fa[GRAM_NB][4], fb[GRAM_NB][4], fw[GRAM_NB], fy[GRAM_NB];
+  auto fetch = [&](int slot, int step) {
+    const int kr = kbeg + 4 * step + lq;
+    const int kw = min(kr, a.rows - 1);   // (rows beyond the half weigh zero; they are read from a real row all the same,
+    const int64_t row = (int64_t)kw * 256;  //  so that the zero multiplies something finite whatever the padding holds)
+    const bool in = kr < kend;
+    const double wv = a.w[kw], yv = ysrc[kw];  // unconditional loads: a load under a branch ends in a wait at its end
+    fw[slot] = in ? wv : 0.0;
+    fy[slot] = (in && sums) ? yv : 0.0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) fa[slot][i] = Va[row + 16 * i];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) fb[slot][j] = Vb[row + 16 * j];
+  };
+  auto work = [&](int slot) {
+    double bw[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bw[j] = fb[slot][j] * fw[slot];
+    if (sums) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) cs[i] = fma(fa[slot][i], fy[slot], cs[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = mfma_f64(fa[slot][i], bw[j], acc[i][j]);
+  };
+  const int nsteps = (max(kend - kbeg, 0) + 3) / 4;
+  const int nloop = (nsteps + GRAM_NB - 1) / GRAM_NB * GRAM_NB;   // (whole rounds of the buffers: the extra steps weigh zero)
+#pragma unroll
+  for (int u = 0; u < GRAM_NB - 1; ++u) fetch(u, u);
+#pragma unroll 1
+  for (int s0 = 0; s0 < nloop; s0 += GRAM_NB) {
+#pragma unroll
+    for (int u = 0; u < GRAM_NB; ++u) {
+      fetch((u + GRAM_NB - 1) % GRAM_NB, s0 + u + GRAM_NB - 1);
+      work(u);
+    }
+  }
+  // the second half's accumulators through LDS, the first half adds its own and stores the slice's partial tile
+  if (g == 1) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) T[(wr * 64 + 16 * i + lq + 4 * r) * GRAM_LD + wc * 64 + 16 * j + l15] = acc[i][j][r];
+    if (sums) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        double v = cs[i];
+        v += __shfl_xor(v, 16);
+        v += __shfl_xor(v, 32);
+        if (lq == 0) cs2[wr * 64 + 16 * i + l15] = v;
+      }
+    }
+  }
+  __syncthreads();
+  if (g == 0) {
+    double* const P = a.part + (int64_t)sl * GRAM_PLEN;
+    double* const Pt = P + (int64_t)t * 128 * 128;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const bool keep = t == 1 || wr * 4 + i <= wc * 4 + j;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int rr = wr * 64 + 16 * i + lq + 4 * r, cc = wc * 64 + 16 * j + l15;
+          Pt[rr * 128 + cc] = keep ? acc[i][j][r] + T[rr * GRAM_LD + cc] : 0.0;
+        }
+      }
+    if (sums) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        double v = cs[i];
+        v += __shfl_xor(v, 16);
+        v += __shfl_xor(v, 32);
+        if (lq == 0) P[GRAM_TLEN + I0 + wr * 64 + 16 * i + l15] = v + cs2[wr * 64 + 16 * i + l15];
+      }
+    }
+  }
+}
+
+// tiles[e] = sum over the slices, in order, of their partial e (e < 3 * 128 * 128: the packed upper tiles), cvec likewise
+// from the partials' last 256 entries (cvec == null: not wanted); two entries per thread, 16 slices' loads in flight
+__global__ __launch_bounds__(256) void mid_gram_reduce_kernel(const double* __restrict__ part, int nslice,
+                                                              double* __restrict__ tiles, double* __restrict__ cvec) {
+  const int e = (blockIdx.x * 256 + threadIdx.x) * 2;
+  if (e >= GRAM_PLEN || (e >= GRAM_TLEN && !cvec)) return;
+  const double* p = part + e;
+  double s0 = 0.0, s1 = 0.0;
+  for (int z = 0; z < nslice; z += 16) {
+    double2 v[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) v[u] = *reinterpret_cast<const double2*>(p + (int64_t)min(z + u, nslice - 1) * GRAM_PLEN);
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      if (z + u < nslice) {
+        s0 += v[u].x;
+        s1 += v[u].y;
+      }
+    }
+  }
+  double* out = e < GRAM_TLEN ? tiles + e : cvec + (e - GRAM_TLEN);
+  out[0] = s0;
+  out[1] = s1;
+}
+
+int64_t mid_gram_part_len() { return (int64_t)GRAM_MAX_SLICES * GRAM_PLEN; }
+
 static void mid_attrs() {
   static uint64_t done = 0;
   once_per_device(done, [] {
@@ -1007,6 +1161,7 @@ static void mid_attrs() {
     GPRHIP_MID_SET(256, 8)
     GPRHIP_MID_SET(256, 16)
 #undef GPRHIP_MID_SET
+    set(reinterpret_cast<const void*>(&mid_gram_kernel), GRAM_LDS);
   });
 }
 
@@ -1077,6 +1232,21 @@ void launch_mid_finish(const MidFinishArgs& a, hipStream_t s) {
       hipLaunchKernelGGL((mid_finish2_kernel<MPV, DT>), dim3(MPV / 16), dim3(256), mid_lds3(MPV, DT), s, a);
     });
   });
+  GPR_HIP(hipGetLastError());
+}
+
+// tiles: the three packed upper tiles of an exchange buffer; cvec: its 256 column sums (pass 1) or null
+void launch_mid_gram(const MidGramArgs& a, double* tiles, double* cvec, hipStream_t s) {
+  mid_attrs();
+  // slices of about 48 rows (24 per half: six k-steps, i.e. little more than the fragments in flight), at most 64 of them;
+  // rows per slice a multiple of 8
+  int nslice = std::max(1, std::min(GRAM_MAX_SLICES, a.rows / 48));
+  int rps = ((a.rows + nslice - 1) / nslice + 7) / 8 * 8;
+  nslice = (a.rows + rps - 1) / rps;
+  MidGramArgs b = a;
+  if (!cvec) b.y = nullptr;
+  hipLaunchKernelGGL(mid_gram_kernel, dim3(3, nslice), dim3(512), GRAM_LDS, s, b, rps);
+  hipLaunchKernelGGL(mid_gram_reduce_kernel, dim3((GRAM_PLEN / 2 + 255) / 256), dim3(256), 0, s, a.part, nslice, tiles, cvec);
   GPR_HIP(hipGetLastError());
 }
 

@@ -1899,6 +1899,40 @@ def test_row_path_thresholds_agree_with_their_neighbours(m, monkeypatch):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("n,m,d", [(1291, 129, 3), (3000, 200, 4), (4096, 256, 8), (4097, 131, 2)])
+def test_two_tile_gram_launches_agree_with_the_engines(n, m, d, monkeypatch):
+    """129 .. 256 inducing points: B~, c~ and G~ are accumulated over the resident V by mid.hip's own launch pair
+    (mid_gram_kernel + its slice reduction; shards of at most 4096 rows, gpr_amd/csrc/kernels.h: MID_GRAM_ROWS) or --
+    GPRHIP_MID_GRAM=0, and above that size -- by the engine's SYRK-shaped launch, both into the same exchange buffers.  Each
+    against the oracle, and against each other."""
+    X, y, Z = synth(300 + m, n, m, d)
+    hyp = dict(log_ell=0.5 * np.log(d) + 0.1, log_sf2=-0.1, sigma2=0.2, inducing=Z)
+    ref = O.evaluate(O.SeIsoKernel(hyp["log_ell"], hyp["log_sf2"]), Z, X, y, hyp["sigma2"])
+    fams = M.families("iso", d, m)
+    out = {}
+    for gram in ("1", "0"):
+        monkeypatch.setenv("GPRHIP_MID_GRAM", gram)
+        p = gpr_amd.Problem(gpr_amd.COV_SE_ISO, n, d, d, m)
+        p.set_inputs(X)
+        p.set_targets(y)
+        p.set_timing(2)
+        ev = p.eval(**hyp)
+        stages = set(p.last_timings())
+        cond = p.condition()[0]
+        ev2 = p.eval(**dict(hyp, sigma2=0.3), reuse_v=True)  # (update_sigma2: pass 1 re-weights the kept V through the engine)
+        p.close()
+        assert {"p1_mid", "p1_syrk_B", "p2_mid", "p2_syrk_W"} <= stages, stages
+        assert M.rel_ok("l", ev.l, ref["l"], TOL_L) and M.rel_ok("dl_dsigma2", ev.dl_dsigma2, ref["dl_dsigma2"], TOL_DS2)
+        assert M.grad_ok(ev.grad, ref["grad"], fams, TOL_GRAD, cond=cond) and M.vec_ok("coeffs", ev.coeffs, ref["coeffs"], TOL_COEFF)
+        out[gram] = (ev, ev2)
+    for k in (0, 1):
+        assert M.rel_ok("l", out["1"][k].l, out["0"][k].l, 1e-10)
+        assert M.grad_ok(out["1"][k].grad, out["0"][k].grad, fams, 1e-8)
+    ref2 = O.evaluate(O.SeIsoKernel(hyp["log_ell"], hyp["log_sf2"]), Z, X, y, 0.3)
+    assert M.rel_ok("l", out["1"][1].l, ref2["l"], TOL_L) and M.grad_ok(out["1"][1].grad, ref2["grad"], fams, TOL_GRAD, cond=cond)
+
+
+@pytest.mark.gpu
 def test_shards_on_both_sides_of_the_two_tile_row_limit():
     """mid.hip's two-tile kernels take shards of at most 32768 rows (gpr_amd/csrc/kernels.h: MID_ROWS_TWO_TILES; the engine
     is faster above).  65537 rows over two shards: 32769 go through the engine, 32768 through mid.hip, both into the same
