@@ -890,6 +890,21 @@ void do_pass1(gprhip_problem* p, const gprhip_hypers* h, int want_grad, int64_t 
     launch_reduce_rows(p->rowpart, pass1_row_blocks(rows_p), 4, ar1_tail, 1, s);
     tstop(p);
   }
+  if (mid && reuse && mp > TILE && p->use_mid_gram()) {
+    // Model.update_sigma2 on a two-tile problem whose fresh evaluations accumulate B~ with mid.hip's launch pair: the same
+    // pair here, so that the re-weighted evaluation returns the very numbers a fresh one would
+    // (test_update_sigma2_reuses_resident_v)
+    tstart(p, "p1_syrk_B");
+    if (!p->mid_gram_part) p->mid_gram_part = p->alloc<double>(mid_gram_part_len());
+    MidGramArgs ga;
+    ga.V = reinterpret_cast<const double*>(Vstore); ga.w = p->is; ga.y = p->yis; ga.rows = (int)p->n;
+    ga.part = p->mid_gram_part;
+    launch_mid_gram(ga, ar1, ar1_c, s);
+    tstop(p);
+    p->stage = 1;
+    p->have_v = true;
+    return;
+  }
   // one SYRK-shaped launch over all rows of the shard (V is resident): B~_part = V^T diag(is) V
   // (R~^T R~ replaces the stacked QR's R, lib/fitc_gp.ml:170-182), and c~ = V^T (is .* y)
   const int64_t ktot = p->rows_total_padded();

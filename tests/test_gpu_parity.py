@@ -1919,7 +1919,7 @@ def test_two_tile_gram_launches_agree_with_the_engines(n, m, d, monkeypatch):
         ev = p.eval(**hyp)
         stages = set(p.last_timings())
         cond = p.condition()[0]
-        ev2 = p.eval(**dict(hyp, sigma2=0.3), reuse_v=True)  # (update_sigma2: pass 1 re-weights the kept V through the engine)
+        ev2 = p.eval(**dict(hyp, sigma2=0.3), reuse_v=True)  # (update_sigma2: pass 1 re-weights the kept V, same Gram launches)
         p.close()
         assert {"p1_mid", "p1_syrk_B", "p2_mid", "p2_syrk_W"} <= stages, stages
         assert M.rel_ok("l", ev.l, ref["l"], TOL_L) and M.rel_ok("dl_dsigma2", ev.dl_dsigma2, ref["dl_dsigma2"], TOL_DS2)
