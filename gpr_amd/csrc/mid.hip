@@ -1,5 +1,6 @@
 // Row passes and finish stage of problems with 65 .. 128 inducing points (one 128-column tile; d <= 16 point dimensions,
-// 1 + d + D <= 32 with a projection from D input dimensions, no multiscales, fp64, any number of rows) -- the regime the
+// 1 + d + D <= 32 with a projection from D input dimensions, no multiscales, fp64, up to 2^22 rows per shard) and, in the
+// two-tile form further down (MidGeo<256>), 129 .. 256 (up to 32768 rows per shard: mid_path_fits) -- the regime the
 // reference's own default lands in: Optim.get_kernel_inducing takes min (n_inputs / 10) 1000 inducing points
 // (lib/fitc_gp.ml:1474-1479), i.e. 65 .. 128 of them for every data set of 650 .. 1280 points.  Through the engine such an
 // evaluation is ~30 dependent launches of 5-35 us each (n = 2000, m = 128: 0.38 ms, profiles/r05_latency.txt): six
