@@ -29,6 +29,17 @@ __global__ __launch_bounds__(256) void sum_slices_kernel(const double* __restric
     const int nz = (r / TILE == c / TILE) ? nslices_diag : nslices;  // diagonal tiles of a SYRK launch: fewer slices
     const TS* sp = slices + off;
     int z = 0;
+    // sixteen slices' loads in flight, then four (round 6: with four alone a 64-slice sum was sixteen memory round trips long);
+    // the additions keep the order z = 0, 1, 2, ...
+    for (; z + 16 <= nz; z += 16) {
+      vec_t a[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) a[u] = *reinterpret_cast<const vec_t*>(sp + (int64_t)(z + u) * stride);
+#pragma unroll
+      for (int u = 0; u < 16; ++u)
+#pragma unroll
+        for (int v = 0; v < V; ++v) acc[v] = acc[v] + (double)a[u][v];
+    }
     for (; z + 4 <= nz; z += 4) {
       const vec_t a0 = *reinterpret_cast<const vec_t*>(sp + (int64_t)z * stride);
       const vec_t a1 = *reinterpret_cast<const vec_t*>(sp + (int64_t)(z + 1) * stride);
